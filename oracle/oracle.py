@@ -1,0 +1,212 @@
+"""ctypes front-end of the CPU oracle + independent numpy restatements.
+
+TEST INFRASTRUCTURE ONLY (see oracle/gq_oracle.c header): importable from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from
+guidedquant_amd/.
+
+Two independent statements are kept on purpose:
+  * the C library (fast, used at full sizes and as the CPU baseline), and
+  * the numpy functions below (`*_np`), written separately from the closed
+    form, used to cross-check the C code at small sizes.
+Reference citations are relative to the upstream GuidedQuant tree.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgq_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (no GPU needed)."""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
+            os.path.join(_HERE, "gq_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u8p, u16p, u32p = (ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint16),
+                           ctypes.POINTER(ctypes.c_uint32))
+        f32p, f64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+        u32, i32 = ctypes.c_uint32, ctypes.c_int
+        L.gq_oracle_d2h.restype = ctypes.c_uint16
+        L.gq_oracle_d2h.argtypes = [ctypes.c_double]
+        L.gq_oracle_h2d.restype = ctypes.c_double
+        L.gq_oracle_h2d.argtypes = [ctypes.c_uint16]
+        L.gq_oracle_hfma.restype = ctypes.c_uint16
+        L.gq_oracle_hfma.argtypes = [ctypes.c_uint16] * 3
+        L.gq_oracle_ap_pack.argtypes = [u8p, u32, u32, i32, u32p]
+        L.gq_oracle_ap_unpack.argtypes = [u32p, u32, u32, i32, u8p]
+        L.gq_oracle_ap_dequant.argtypes = [u32p, u16p, u32, u32, i32, u16p]
+        L.gq_oracle_ap_gemv_f64.argtypes = [u16p, u32p, u16p, u32, u32, u32, i32, f64p]
+        L.gq_oracle_ap_gemv_f16.argtypes = [u16p, u32p, u16p, u32, u32, u32, i32, u16p]
+        L.gq_oracle_set_threads.argtypes = [i32]
+        L.gq_oracle_max_threads.restype = i32
+        for name in ("gq_oracle_lutgemm_f16", "gq_oracle_qtip_decode", "gq_oracle_qtip_matvec",
+                     "gq_oracle_hadamard"):
+            pass  # bound lazily below when present
+        L._f32p, L._f64p = f32p, f64p
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _u16(a):
+    """view fp16 arrays as their bit patterns (uint16)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float16:
+        return a.view(np.uint16)
+    assert a.dtype == np.uint16
+    return a
+
+
+def set_threads(n):
+    lib().gq_oracle_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().gq_oracle_max_threads())
+
+
+# --------------------------------------------------------------------------- AP format
+def ap_pack(codes, bits):
+    """codes uint8[N,K] -> qweight int32[bits,N,K/32] (pack.py:304-321)."""
+    codes = _c(codes, np.uint8)
+    N, K = codes.shape
+    q = np.zeros((bits, N, K // 32), dtype=np.uint32)
+    rc = lib().gq_oracle_ap_pack(_p(codes, ctypes.c_uint8), N, K, bits, _p(q, ctypes.c_uint32))
+    assert rc == 0, rc
+    return q.view(np.int32)
+
+
+def ap_unpack(qweight, bits):
+    """qweight int32[>=bits,N,K/32] -> codes uint8[N,K] using the first `bits` planes (pack.py:324-347)."""
+    q = _c(qweight, np.int32).view(np.uint32)
+    _, N, wpr = q.shape
+    codes = np.zeros((N, wpr * 32), dtype=np.uint8)
+    rc = lib().gq_oracle_ap_unpack(_p(q, ctypes.c_uint32), N, wpr * 32, bits, _p(codes, ctypes.c_uint8))
+    assert rc == 0, rc
+    return codes
+
+
+def ap_dequant(qweight, lut, bits):
+    """-> W fp16[N,K]   (anyprec.cu:294-359 / finetune_utils.py:19-38)."""
+    q = _c(qweight, np.int32).view(np.uint32)
+    _, N, wpr = q.shape
+    l16 = _u16(lut)
+    assert l16.shape == (N, 1 << bits)
+    W = np.zeros((N, wpr * 32), dtype=np.uint16)
+    rc = lib().gq_oracle_ap_dequant(_p(q, ctypes.c_uint32), _p(l16, ctypes.c_uint16), N, wpr * 32, bits,
+                                    _p(W, ctypes.c_uint16))
+    assert rc == 0, rc
+    return W.view(np.float16)
+
+
+def ap_gemv_f64(x, qweight, lut, bits):
+    """Exact GEMV, x fp16[M,K] -> float64[M,N]."""
+    q = _c(qweight, np.int32).view(np.uint32)
+    _, N, wpr = q.shape
+    K = wpr * 32
+    x16 = _u16(x).reshape(-1, K)
+    M = x16.shape[0]
+    l16 = _u16(lut)
+    y = np.zeros((M, N), dtype=np.float64)
+    rc = lib().gq_oracle_ap_gemv_f64(_p(x16, ctypes.c_uint16), _p(q, ctypes.c_uint32), _p(l16, ctypes.c_uint16), M,
+                                     N, K, bits, _p(y, ctypes.c_double))
+    assert rc == 0, rc
+    return y
+
+
+def ap_gemv_f16(x, qweight, lut, bits):
+    """Order-faithful fp16 GEMV (anyprec.cu:372-542), x fp16[M,K] -> fp16[M,N]."""
+    q = _c(qweight, np.int32).view(np.uint32)
+    _, N, wpr = q.shape
+    K = wpr * 32
+    x16 = _u16(x).reshape(-1, K)
+    M = x16.shape[0]
+    l16 = _u16(lut)
+    assert l16.shape == (N, 1 << bits)
+    y = np.zeros((M, N), dtype=np.uint16)
+    rc = lib().gq_oracle_ap_gemv_f16(_p(x16, ctypes.c_uint16), _p(q, ctypes.c_uint32), _p(l16, ctypes.c_uint16), M,
+                                     N, K, bits, _p(y, ctypes.c_uint16))
+    assert rc == 0, rc
+    return y.view(np.float16)
+
+
+# --------------------------------------------------------------------------- numpy restatements
+def ap_pack_np(codes, bits):
+    """Independent statement of pack.py:304-321 + :12-83 by the byte route the
+    reference takes (packbits MSB-first per plane, then the warp byte
+    permutation with endianness flip), NOT by the closed form used in C."""
+    codes = np.asarray(codes, dtype=np.uint8)
+    N, K = codes.shape
+    nbytes = K // 8
+    planes = np.empty((bits, N, nbytes), dtype=np.uint8)
+    for p in range(bits):
+        planes[p] = np.packbits(((codes >> (bits - 1 - p)) & 1).astype(bool), axis=1)
+    out = np.empty_like(planes)
+    full = (nbytes // 128) * 128
+
+    def perm(src, tpw):
+        # src [..., nb] with nb = 4*tpw*chunks: byte index b = chunk*4*tpw + c*tpw + t
+        # goes to chunk*4*tpw + t*4 + (3-c)  (thread t's little-endian word, MSB byte first)
+        nb = src.shape[-1]
+        s = src.reshape(*src.shape[:-1], nb // (4 * tpw), 4, tpw)
+        s = np.flip(np.swapaxes(s, -1, -2), axis=-1)  # [..., chunk, t, 3-c]
+        return s.reshape(*src.shape[:-1], nb)
+
+    if full:
+        out[..., :full] = perm(planes[..., :full], 32)
+    if nbytes > full:
+        out[..., full:] = perm(planes[..., full:], (nbytes - full) // 4)
+    return np.ascontiguousarray(out).view("<u4").view(np.int32).reshape(bits, N, K // 32)
+
+
+def _f16(a64):
+    return a64.astype(np.float16)
+
+
+def ap_gemv_f16_np(x, qweight, lut, bits):
+    """Independent (vectorised-over-rows) restatement of anyprec.cu:372-542 for M==1,
+    no ksplit.  Uses numpy's float64->float16 RNE conversion for every rounding."""
+    codes = ap_unpack(qweight, bits)
+    N, K = codes.shape
+    x = np.asarray(x, dtype=np.float16).reshape(K).astype(np.float64)
+    lut = np.asarray(lut, dtype=np.float16)
+    W = np.take_along_axis(lut, codes.astype(np.int64), axis=1).astype(np.float64)  # [N,K]
+    nfull, tail = divmod(K, 1024)
+    eff = tail // 32
+    partial = np.zeros((N, 32), dtype=np.float16)
+    for i in range(nfull + (1 if tail else 0)):
+        tpw = 32 if i < nfull else eff
+        sx = np.zeros((N, tpw), dtype=np.float16)
+        sy = np.zeros((N, tpw), dtype=np.float16)
+        t = np.arange(tpw)
+        for c in (3, 2, 1, 0):
+            for k in range(4):
+                e0 = 1024 * i + 8 * tpw * c + 8 * t + 2 * k
+                sx = _f16(W[:, e0] * x[e0][None, :] + sx.astype(np.float64))
+                sy = _f16(W[:, e0 + 1] * x[e0 + 1][None, :] + sy.astype(np.float64))
+        s = _f16(sx.astype(np.float64) + sy.astype(np.float64))
+        partial[:, :tpw] = _f16(partial[:, :tpw].astype(np.float64) + s.astype(np.float64))
+    p = partial
+    for sh in (16, 8, 4, 2, 1):
+        p = _f16(p[:, :sh].astype(np.float64) + p[:, sh:2 * sh].astype(np.float64))
+    return p[:, 0].reshape(1, N)

@@ -1,0 +1,64 @@
+"""ctypes binding of libgq_hip.so (the C ABI declared in include/gq_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel call fails, a RuntimeError is
+raised.  Nothing here imports the CPU oracle.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgq_hip.so")
+_lib = None
+
+# symbols include/gq_hip.h declares; tests check that the built library exports every one
+EXPORTS = [
+    "gq_version", "gq_last_error", "gq_device_count", "gq_anyprec_gemv", "gq_anyprec_dequant", "gq_lutgemm_gemv",
+    "gq_qtip_matvec", "gq_hadamard", "gq_anyprec_gemv_fused",
+]
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into guidedquant_amd/libgq_hip.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C guidedquant_amd/csrc).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u32, i32, f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
+        L.gq_version.restype = i32
+        L.gq_last_error.restype = ctypes.c_char_p
+        L.gq_device_count.restype = i32
+        L.gq_anyprec_gemv.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, i32, vp]
+        L.gq_anyprec_dequant.argtypes = [vp, vp, vp, u32, u32, i32, vp]
+        L.gq_lutgemm_gemv.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, i32, vp]
+        L.gq_qtip_matvec.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp]
+        L.gq_hadamard.argtypes = [vp, vp, u32, u32, f32, vp]
+        L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]
+        for name in EXPORTS:
+            if name not in ("gq_last_error", ):
+                getattr(L, name).restype = i32
+        L.gq_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gq_last_error()
+        raise RuntimeError(f"{what}: {msg.decode() if msg else 'error'} (code {rc})")
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

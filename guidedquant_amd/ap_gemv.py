@@ -1,0 +1,113 @@
+"""Python module with the reference's `ap_gemv` extension surface (inference/ap_gemv/bindings.cpp:12-17):
+
+    anyprec_gemv(input, output, qweight, lut, bitwidth) -> None
+    anyprec_dequant(qweight, lut, bitwidth) -> Tensor[N, K] fp16
+    lutgemm_gemv(input, output, q_weight, alpha, q_bias, bitwidth, group_size) -> None
+
+Same argument order, same validation (messages follow inference/ap_gemv/gemv.cu:64-90,180-211; failures raise
+RuntimeError like TORCH_CHECK), work enqueued on the current torch stream of the tensors' device
+(gemv.cu:103-105).  The arithmetic runs in libgq_hip.so through the C ABI; there is no CPU fallback.
+
+One deliberate relaxation: `qweight.size(0) >= bitwidth` is accepted (the reference demands equality,
+gemv.cu:76) because the kernel's plane stride is N*K/32 regardless (anyprec.cu:446) -- this lets a
+multi-precision parent tensor be used without slicing (AnyPrecisionLinear.py:73 passes the un-pruned tensor).
+"""
+import torch
+
+from . import _lib
+
+
+def _chk(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _dev_guard(t):
+    return torch.cuda.device(t.device)
+
+
+def anyprec_gemv(input, output, qweight, lut, bitwidth):
+    bitwidth = int(bitwidth)
+    _chk(2 <= bitwidth <= 8, "Bitwidth must be between 2 and 8.")
+    _chk(input.dtype == lut.dtype and input.dtype == output.dtype,
+         "Mismatched data types between input, lut, and output tensors.")
+    _chk(qweight.dtype == torch.int32, "qweight tensor must be of type int.")
+    _chk(input.dim() == 3, "input tensor must be of shape (batch_size, seq_len, hidden_size).")
+    _chk(output.dim() == 3, "output tensor must be of shape (batch_size, seq_len, hidden_size).")
+    _chk(lut.dim() == 2 and lut.size(1) == (1 << bitwidth) and lut.size(0) == output.size(2),
+         f"lut tensor must be of shape (output_feat, 2 ** bitwidth). Expected ({output.size(2)}, {1 << bitwidth}), "
+         f"got ({', '.join(str(s) for s in lut.shape)}).")
+    _chk(qweight.dim() == 3 and qweight.size(0) >= bitwidth and qweight.size(2) == input.size(2) // 32
+         and qweight.size(1) == output.size(2),
+         f"qweight tensor must be of shape (bitwidth, output_feat, input_feat / 32). Expected ({bitwidth}, "
+         f"{output.size(2)}, {input.size(2) // 32}), got ({', '.join(str(s) for s in qweight.shape)}).")
+    _chk(input.size(1) == 1, "Only sequence length of 1 is supported.")
+    _chk(output.size(1) == 1, "Only sequence length of 1 is supported.")
+    _chk(input.is_cuda and output.is_cuda, "input and output tensors must be on GPU.")
+    _chk(qweight.is_cuda and lut.is_cuda, "qweight and lut tensors must be on GPU.")
+    _chk(input.is_contiguous(), "input tensor must be contiguous.")
+    _chk(output.is_contiguous(), "output tensor must be contiguous.")
+    _chk(qweight.is_contiguous(), "qweight tensor must be contiguous.")
+    _chk(lut.is_contiguous(), "lut tensor must be contiguous.")
+    _chk(input.dtype == torch.float16, "only float16 is supported (the reference kernels are hard-wired to half).")
+    _chk(input.size(0) == output.size(0), "input and output batch sizes differ.")
+    M, K, N = input.size(0), input.size(2), output.size(2)
+    _chk(1 <= M <= 8, "batch size must be between 1 and 8.")
+    _chk(K % 32 == 0, "input_feat must be a multiple of 32.")
+    with _dev_guard(qweight):
+        rc = _lib.lib().gq_anyprec_gemv(input.data_ptr(), output.data_ptr(), qweight.data_ptr(), lut.data_ptr(), M, N, K,
+                                        bitwidth, 0, _lib.current_stream_ptr())
+    _lib.check(rc, "anyprec_gemv")
+
+
+def anyprec_dequant(qweight, lut, bitwidth):
+    bitwidth = int(bitwidth)
+    _chk(2 <= bitwidth <= 8, "Bitwidth must be between 2 and 8.")
+    _chk(qweight.dtype == torch.int32 and qweight.dim() == 3, "qweight tensor must be int32 of shape (bitwidth, N, K/32).")
+    _chk(qweight.size(0) >= bitwidth, "qweight holds fewer planes than bitwidth.")
+    _chk(lut.dtype == torch.float16 and lut.dim() == 2 and lut.size(0) == qweight.size(1)
+         and lut.size(1) == (1 << bitwidth), "lut tensor must be float16 of shape (output_feat, 2 ** bitwidth).")
+    _chk(qweight.is_cuda and lut.is_cuda, "qweight and lut tensors must be on GPU.")
+    _chk(qweight.is_contiguous() and lut.is_contiguous(), "qweight and lut tensors must be contiguous.")
+    N, K = qweight.size(1), qweight.size(2) * 32
+    weight = torch.empty((N, K), dtype=torch.float16, device=qweight.device)  # gemv.cu:121-122
+    with _dev_guard(qweight):
+        rc = _lib.lib().gq_anyprec_dequant(qweight.data_ptr(), lut.data_ptr(), weight.data_ptr(), N, K, bitwidth,
+                                           _lib.current_stream_ptr())
+    _lib.check(rc, "anyprec_dequant")
+    return weight
+
+
+def lutgemm_gemv(input, output, q_weight, alpha, q_bias, bitwidth, group_size):
+    bitwidth, group_size = int(bitwidth), int(group_size)
+    _chk(1 <= bitwidth <= 8, "Bitwidth must be between 1 and 8.")
+    _chk(input.dtype == alpha.dtype and input.dtype == q_bias.dtype and input.dtype == output.dtype,
+         "Mismatched data types between input, alpha, q_bias, and output tensors.")
+    _chk(input.dim() == 3, "input tensor must be of shape (batch_size, seq_len, input_feat).")
+    _chk(output.dim() == 3, "output tensor must be of shape (batch_size, seq_len, output_feat).")
+    _chk(input.size(0) == 1, "Batch size must be 1 for input tensor.")
+    _chk(input.size(1) == 1, "Sequence length must be 1 for input tensor.")
+    _chk(output.size(0) == 1, "Batch size must be 1 for output tensor.")
+    _chk(output.size(1) == 1, "Sequence length must be 1 for output tensor.")
+    _chk(input.is_cuda and output.is_cuda, "input and output tensors must be on GPU.")
+    _chk(input.is_contiguous(), "input tensor must be contiguous.")
+    _chk(output.is_contiguous(), "output tensor must be contiguous.")
+    _chk(q_weight.is_contiguous(), "q_weight tensor must be contiguous.")
+    _chk(alpha.is_contiguous(), "alpha tensor must be contiguous.")
+    _chk(q_bias.is_contiguous(), "q_bias tensor must be contiguous.")
+    K, N = input.size(2), output.size(2)
+    _chk(group_size > 0 and K % group_size == 0, "group_size must divide input_feat.")
+    ng = K // group_size
+    _chk(q_weight.dim() == 3 and q_weight.size(0) == K // 32 and q_weight.size(1) == bitwidth and q_weight.size(2) == N,
+         f"q_weight tensor must be of shape (input_feat / 32, bitwidth, output_feat). Expected ({K // 32}, {bitwidth}, "
+         f"{N}), got ({', '.join(str(s) for s in q_weight.shape)}).")
+    _chk(alpha.dim() == 3 and alpha.size(0) == ng and alpha.size(1) == bitwidth and alpha.size(2) == N,
+         f"alpha tensor must be of shape (num_groups, bitwidth, output_feat). Expected ({ng}, {bitwidth}, {N}), "
+         f"got ({', '.join(str(s) for s in alpha.shape)}).")
+    _chk(q_bias.dim() == 2 and q_bias.size(0) == ng and q_bias.size(1) == N,
+         "q_bias tensor must be of shape (num_groups, output_feat).")
+    _chk(input.dtype == torch.float16 and q_weight.dtype == torch.int32, "only float16 / int32 are supported.")
+    with _dev_guard(q_weight):
+        rc = _lib.lib().gq_lutgemm_gemv(input.data_ptr(), output.data_ptr(), q_weight.data_ptr(), alpha.data_ptr(),
+                                        q_bias.data_ptr(), N, K, bitwidth, group_size, _lib.current_stream_ptr())
+    _lib.check(rc, "lutgemm_gemv")

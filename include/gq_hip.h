@@ -1,0 +1,110 @@
+/*
+ * gq_hip.h -- C ABI of libgq_hip.so, the MI355X (gfx950) implementation of
+ * GuidedQuant's quantized-linear decode path.
+ *
+ * Plain pointers + sizes, no torch types.  Every device pointer must be
+ * resident on the current HIP device; work is enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  No entry point
+ * allocates, frees, synchronises or retains a pointer, so all of them are
+ * hipGraph-capturable.  Return value: 0 on success, a negative GQ_E* code on
+ * error (never exit()/abort(), unlike the reference's HANDLE_ERROR,
+ * inference/ap_gemv/gemv.cu:20-27); gq_last_error() returns a thread-local
+ * message for the last failure.
+ *
+ * Each entry point names the reference interface it replaces (file:line in
+ * the upstream snu-mllab/GuidedQuant tree).  The reference-side bindings a
+ * maintainer would add are shown in INTEGRATION.md.
+ */
+#ifndef GQ_HIP_H
+#define GQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GQ_OK 0
+#define GQ_EINVAL (-22)   /* bad argument (shape / bitwidth / alignment) */
+#define GQ_ENOTSUP (-95)  /* valid request this build has no kernel for */
+#define GQ_EHIP (-5)      /* HIP runtime error, see gq_last_error() */
+
+#define GQ_DTYPE_F16 0
+
+/* epilogue / prologue flags of the fused GEMV entry point */
+#define GQ_EPI_NONE 0u
+#define GQ_EPI_RESIDUAL 1u  /* out[n] = residual[n] + y[n]          (fp16 add) */
+#define GQ_EPI_SILU_MUL 2u  /* N = 2*I fused gate/up: out[i] = silu(y[i]) * y[I+i], out has I entries */
+
+int gq_version(void);
+const char *gq_last_error(void);
+/* number of HIP devices visible, <0 on error; lets a host check the library is usable */
+int gq_device_count(void);
+
+/*
+ * Any-Precision LUT-GEMV.   out[m][n] = sum_k x[m][k] * lut[n][code(n,k)]
+ * Replaces ap_gemv.anyprec_gemv -> anyprec_gemv_stream -> anyprec_matmul ->
+ * matmul_kbit_32<M,bits,ksplit>  (inference/ap_gemv/bindings.cpp:14,
+ * gemv.cu:56-107, anyprec.cu:372-542,591-620).
+ *   x       fp16 [M][K]              (M = 1..8; decode uses M = 1)
+ *   out     fp16 [M][N]              written directly, no pre-zeroing needed
+ *   qweight u32  [>=bits][N][K/32]   bit-plane packed, MSB plane first
+ *                                    (any_precision/quantization/pack.py:304-321);
+ *                                    plane stride is N*K/32 words
+ *   lut     fp16 [N][2^bits]
+ * Results are bit-identical to the reference kernel's fp16 accumulation order
+ * (see DESIGN.md).  Requires K % 32 == 0, 2 <= bits <= 8.
+ */
+int gq_anyprec_gemv(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N,
+                    uint32_t K, int bits, int dtype, void *stream);
+
+/*
+ * Any-Precision dequantise.   W[n][k] = lut[n][code(n,k)]   (fp16 [N][K])
+ * Replaces ap_gemv.anyprec_dequant -> anyprec_dequant_kbit -> dequant_kbit_store<bits>
+ * (bindings.cpp:15, gemv.cu:109-134, anyprec.cu:294-359,627-645).
+ */
+int gq_anyprec_dequant(const uint32_t *qweight, const void *lut, void *W, uint32_t N, uint32_t K, int bits,
+                       void *stream);
+
+/*
+ * LUT-GEMM (BCQ) GEMV.  Replaces ap_gemv.lutgemm_gemv -> nqmv_bias
+ * (bindings.cpp:16, gemv.cu:140-228, lutgemm.cu:24-149).
+ *   x fp16 [K], out fp16 [N] (ACCUMULATED INTO, caller zeroes it as LUTGEMMLinear.py:74 does),
+ *   qweight u32 [K/32][bits][N], alpha fp16 [K/group][bits][N], q_bias fp16 [K/group][N].
+ */
+int gq_lutgemm_gemv(const void *x, void *out, const uint32_t *qweight, const void *alpha, const void *q_bias,
+                    uint32_t N, uint32_t K, int bits, int group_size, void *stream);
+
+/*
+ * QTIP trellis-decoded matvec.  out[m] = sum_k decode(compressed)[m][k] * x[k]
+ * Replaces qtip_kernels.decompress_matvec_16_9_{R}_1_{M}_1_{K} -> kernel_decompress_matvec
+ * (qtip/qtip-kernels/src/wrapper.cpp:557-645, qtip_torch.cu:14-57, inference.cu:168-471).
+ *   out f32 [M], compressed u32 [R*M*K/32], x fp16 [K], codebook fp16 [1024] (tlut [512][2]).
+ * One runtime-shaped entry point serves all 73 compile-time shapes of the reference.
+ */
+int gq_qtip_matvec(float *out, const uint32_t *compressed, const void *x, const void *codebook, uint32_t M,
+                   uint32_t K, int R, void *stream);
+
+/*
+ * Hadamard transform on the last dim, y = scale * x @ H_n (Sylvester order), n a power of two.
+ * Replaces hadamard::hadamard -> fast_hadamard_transform.hadamard_transform
+ * (inference/lib/utils/matmul_had.py:96-106).  x,y f32 [rows][n]; in-place allowed.
+ */
+int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale, void *stream);
+
+/*
+ * Fused decode-step variant of the AP GEMV: optional
+ * RMSNorm prologue on x and residual / SiLU-mul epilogue, same arithmetic and
+ * rounding points as the reference's separate kernels
+ * (inference/model.py:151-166,259-266,281-292).
+ *   norm_weight  fp16 [K] or NULL (no RMSNorm);  eps used when norm_weight != NULL
+ *   residual     fp16 [N] or NULL
+ */
+int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
+                          uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
+                          uint32_t epilogue, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GQ_HIP_H */

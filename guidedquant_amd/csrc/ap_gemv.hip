@@ -29,6 +29,7 @@ struct ApArgs {
     const uint16_t *resid; // [N] or null
     u32 N, K;
     u32 RS;                // row slots per block step = blockDim.x / Q
+    u32 SPB;               // row steps per block
     u32 epilogue;
     float eps;
 };
@@ -45,14 +46,30 @@ __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uin
 
 // ----------------------------------------------------------------------------------------------
 // Stage the activation vector into LDS in the lane-linear image of ap_core.h::xlds_pos.
-// Optional fused RMSNorm prologue (inference/model.py:281-292): y = (x.float() * rsqrt(mean(x^2)+eps))
-// .half() * w  -- the same two fp16 roundings as the reference's separate kernel.
+// Work item = (quad q, byte c): 4 virtual lanes x 8 activations = 64 contiguous bytes of x, regrouped with
+// 16 v_perm_b32 into the 4 sixteen-byte slots (c, jj) of quad q.
+// Optional fused prologues, with the same fp16 rounding points as the reference's separate kernels:
+//   PRO_RMSNORM: y = (x.float() * rsqrt(mean(x^2) + eps)).half() * w        (inference/model.py:281-292)
+//   PRO_SILUMUL: y = silu(g) * u with g = x[0:K], u = x[K:2K]                (inference/model.py:266)
 // ----------------------------------------------------------------------------------------------
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILUMUL = 2 };
+
+__device__ __forceinline__ u32 silu_mul_pk(u32 g, u32 u) {
+    // F.silu on an fp16 tensor evaluates x / (1 + exp(-x)) in fp32 and rounds to fp16; then an fp16 multiply.
+    float g0 = h2f(g & 0xFFFF), g1 = h2f(g >> 16);
+    _Float16 s0 = (_Float16)(g0 / (1.0f + __expf(-g0)));
+    _Float16 s1 = (_Float16)(g1 / (1.0f + __expf(-g1)));
+    _Float16 r0 = s0 * __builtin_bit_cast(_Float16, (uint16_t)(u & 0xFFFF));
+    _Float16 r1 = s1 * __builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+    return (u32)__builtin_bit_cast(uint16_t, r0) | ((u32)__builtin_bit_cast(uint16_t, r1) << 16);
+}
+
+template <int PRO>
 __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, const uint16_t *normw, float eps,
                                         uint16_t *xlds, float *red /* >= 16 floats of LDS */) {
     const u32 T = blockDim.x, tid = threadIdx.x;
     float scale = 0.f;
-    if (normw) {
+    if constexpr (PRO == PRO_RMSNORM) {
         float ss = 0.f;
         for (u32 g = tid; g < G.K / 8u; g += T) {
             uint4 v = ld16(x + 8u * g);
@@ -72,25 +89,43 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
         for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
         scale = 1.0f / sqrtf(tot / (float)G.K + eps);
     }
-    for (u32 g = tid; g < G.K / 8u; g += T) {
-        uint4 v = ld16(x + 8u * g);
-        u32 w[4] = {v.x, v.y, v.z, v.w};
-        if (normw) {
-            uint4 nv = ld16(normw + 8u * g);
-            const u32 nw[4] = {nv.x, nv.y, nv.z, nv.w};
+    for (u32 idx = tid; idx < 4u * G.Q; idx += T) {
+        const u32 q = idx >> 2, c = idx & 3u;
+        const u32 e0 = G.xindex(q, 0u, c, 0u);  // 32 consecutive activations: v = 0..3, j = 0..7
+        u32 in[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint16_t a = f2h(h2f(w[i] & 0xFFFF) * scale), b = f2h(h2f(w[i] >> 16) * scale);
-                _Float16 ra = __builtin_bit_cast(_Float16, a) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] & 0xFFFF));
-                _Float16 rb = __builtin_bit_cast(_Float16, b) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] >> 16));
-                w[i] = (u32)__builtin_bit_cast(uint16_t, ra) | ((u32)__builtin_bit_cast(uint16_t, rb) << 16);
+        for (int v = 0; v < 4; v++) {
+            uint4 t4 = ld16(x + e0 + 8 * v);
+            in[v][0] = t4.x;
+            in[v][1] = t4.y;
+            in[v][2] = t4.z;
+            in[v][3] = t4.w;
+            if constexpr (PRO == PRO_RMSNORM) {
+                uint4 n4 = ld16(normw + e0 + 8 * v);
+                const u32 nw[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint16_t a = f2h(h2f(in[v][i] & 0xFFFF) * scale), b = f2h(h2f(in[v][i] >> 16) * scale);
+                    _Float16 ra = __builtin_bit_cast(_Float16, a) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] & 0xFFFF));
+                    _Float16 rb = __builtin_bit_cast(_Float16, b) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] >> 16));
+                    in[v][i] = (u32)__builtin_bit_cast(uint16_t, ra) | ((u32)__builtin_bit_cast(uint16_t, rb) << 16);
+                }
+            } else if constexpr (PRO == PRO_SILUMUL) {
+                uint4 u4 = ld16(x + G.K + e0 + 8 * v);
+                const u32 uw[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) in[v][i] = silu_mul_pk(in[v][i], uw[i]);
             }
         }
-        u32 q, vv, c;
-        xgroup(G, g, q, vv, c);
 #pragma unroll
-        for (u32 j = 0; j < 8; j++)
-            xlds[xlds_pos(G.Q, q, vv, c, j)] = (uint16_t)((w[j >> 1] >> (16 * (j & 1))) & 0xFFFF);
+        for (u32 mth = 0; mth < 4; mth++) {
+            uint4 o;
+            o.x = perm(in[1][mth], in[0][mth], 0x05040100u);  // (v0,v1) @ j = 2m
+            o.y = perm(in[3][mth], in[2][mth], 0x05040100u);  // (v2,v3) @ j = 2m
+            o.z = perm(in[1][mth], in[0][mth], 0x07060302u);  // (v0,v1) @ j = 2m+1
+            o.w = perm(in[3][mth], in[2][mth], 0x07060302u);  // (v2,v3) @ j = 2m+1
+            *reinterpret_cast<uint4 *>(xlds + (((c * 4u + mth) * G.Q + q) << 3)) = o;
+        }
     }
 }
 
@@ -113,68 +148,71 @@ __device__ __forceinline__ uint16_t reduce_row(const RowGeom &G, const uint16_t 
     return p;
 }
 
-__device__ __forceinline__ uint16_t silu_mul_h(uint16_t g, uint16_t u) {
-    // F.silu(w1_out) * w3_out on fp16 tensors (inference/model.py:266): silu evaluated in fp32 and rounded to
-    // fp16 (ATen's half silu kernel computes x / (1 + exp(-x)) in float), then an fp16 multiply.
-    float x = h2f(g);
-    _Float16 s = (_Float16)(x / (1.0f + __expf(-x)));
-    _Float16 r = s * __builtin_bit_cast(_Float16, u);
-    return __builtin_bit_cast(uint16_t, r);
-}
-
 // ----------------------------------------------------------------------------------------------
 // Fast path: BITS in {2,3,4}, K % 128 == 0, Q = K/128 <= blockDim.x.
+//
+// A block owns SPB consecutive "row steps" (one step = RS = blockDim/Q consecutive rows, one item per lane,
+// a wave-load is 1 KiB of contiguous plane bytes).  The plane words + LUT of D steps ahead sit in a register
+// ring, loaded with raw buffer loads: rows past the end get an out-of-range offset, which the hardware
+// answers with zeros and no memory traffic, so the loop has no divergent control flow and the compiler's
+// vmcnt bookkeeping stays exact.  The lane's activations stay in 64 VGPRs for the whole loop.
 // ----------------------------------------------------------------------------------------------
-template <int BITS, int RT, bool NT>
+template <int BITS, int D, int PRO>
 __global__ void __launch_bounds__(512) ap_gemv_quad_kernel(ApArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RowGeom G;
     G.init(a.K);
     uint16_t *xlds = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *sv = xlds + G.K;  // [RB][nchunks*32]
+    uint16_t *sv = xlds + G.K;  // [SPB*RS][nchunks*32]
     const u32 svrow = G.nchunks * 32u;
     float *red = reinterpret_cast<float *>(sv);  // scratch for the RMSNorm reduction (before sv is used)
 
     const u32 T = blockDim.x, tid = threadIdx.x;
-    const u32 RS = a.RS, RB = RS * RT;
-    const u32 row0 = blockIdx.x * RB;
+    const u32 RS = a.RS, SPB = a.SPB;
+    const u32 row0 = blockIdx.x * SPB * RS;
     const u32 m = blockIdx.y;
     const bool active = tid < RS * G.Q;
     const u32 rs = active ? tid / G.Q : 0u;
     const u32 q = active ? tid - rs * G.Q : 0u;
 
-    // 1. put every plane byte this lane will need in flight before touching anything else
     constexpr int NRAW = (1 << BITS) / 2;
-    uint4 P[RT][BITS];
-    u32 lraw[RT][NRAW];
+    constexpr u32 OOB = 0x80000000u;
+    const u32 plane_bytes = a.N * G.wpr * 4u;
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw, 0, (int)(plane_bytes * (u32)BITS), 0x00020000);
+    __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)a.lut, 0, (int)(a.N * (u32)NRAW * 4u), 0x00020000);
+
+    u32x4 P[D][BITS];
+    u32 lraw[D][NRAW];
+    auto issue = [&](int d, u32 step) {
+        const u32 row = row0 + step * RS + rs;
+        const bool ok = active && step < SPB && row < a.N;
+        const u32 off = ok ? (row * G.wpr + 4u * q) * 4u : OOB;
 #pragma unroll
-    for (int it = 0; it < RT; it++) {
-        const u32 row = row0 + (u32)it * RS + rs;
-        const bool ok = active && row < a.N;
-#pragma unroll
-        for (int p = 0; p < BITS; p++) {
-            const u32 *src = a.qw + ((size_t)p * a.N + row) * G.wpr + 4u * q;
-            P[it][p] = ok ? (NT ? ld16_nt(src) : ld16(src)) : make_uint4(0, 0, 0, 0);
-        }
-        const u32 *lsrc = reinterpret_cast<const u32 *>(a.lut) + (size_t)row * NRAW;
+        for (int p = 0; p < BITS; p++)
+            P[d][p] = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? off + (u32)p * plane_bytes : OOB, 0, 2 /* nt */);
+        const u32 loff = ok ? row * (u32)NRAW * 4u : OOB;
         if constexpr (NRAW == 2) {
-            uint2 v = ok ? *reinterpret_cast<const uint2 *>(lsrc) : make_uint2(0, 0);
-            lraw[it][0] = v.x;
-            lraw[it][1] = v.y;
+            auto v = __builtin_amdgcn_raw_buffer_load_b64(rl, loff, 0, 0);
+            lraw[d][0] = v[0];
+            lraw[d][1] = v[1];
         } else {
 #pragma unroll
             for (int i = 0; i < NRAW; i += 4) {
-                uint4 v = ok ? ld16(lsrc + i) : make_uint4(0, 0, 0, 0);
-                lraw[it][i] = v.x;
-                lraw[it][i + 1] = v.y;
-                lraw[it][i + 2] = v.z;
-                lraw[it][i + 3] = v.w;
+                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? loff + (u32)i * 4u : OOB, 0, 0);
+                lraw[d][i] = v.x;
+                lraw[d][i + 1] = v.y;
+                lraw[d][i + 2] = v.z;
+                lraw[d][i + 3] = v.w;
             }
         }
-    }
+    };
+
+    // 1. fill the ring before touching anything else
+#pragma unroll
+    for (int d = 0; d < D; d++) issue(d, (u32)d);
 
     // 2. activations -> LDS (lane-linear image) -> 64 VGPRs
-    stage_x(G, a.x + (size_t)m * G.K, a.normw, a.eps, xlds, red);
+    stage_x<PRO>(G, a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), a.normw, a.eps, xlds, red);
     __syncthreads();
     XRegs xr;
 #pragma unroll
@@ -188,51 +226,40 @@ __global__ void __launch_bounds__(512) ap_gemv_quad_kernel(ApArgs a) {
             xr.r[c][jj][3] = v.w;
         }
 
-    // 3. decode + packed fp16 FMA chains, one item per row
+    // 3. decode + packed fp16 FMA chains, one item per step
     u32 chunk, t0, tpw;
     G.quad(q, chunk, t0, tpw);
+    uint16_t *svp = sv + (size_t)rs * svrow + chunk * 32u + t0;
+    for (u32 i = 0; i < SPB; i += D) {
 #pragma unroll
-    for (int it = 0; it < RT; it++) {
-        u32 Pw[BITS][4];
+        for (int d = 0; d < D; d++) {
+            u32 Pw[BITS][4];
 #pragma unroll
-        for (int p = 0; p < BITS; p++) {
-            Pw[p][0] = P[it][p].x;
-            Pw[p][1] = P[it][p].y;
-            Pw[p][2] = P[it][p].z;
-            Pw[p][3] = P[it][p].w;
-        }
-        LutPools<BITS> L;
-        L.build(lraw[it]);
-        u32 s01, s23;
-        Item<BITS>::run(Pw, L, xr, s01, s23);
-        if (active) {
-            const u32 rl = (u32)it * RS + rs;
-            *reinterpret_cast<uint2 *>(sv + (size_t)rl * svrow + chunk * 32u + t0) = make_uint2(s01, s23);
+            for (int p = 0; p < BITS; p++) {
+                Pw[p][0] = P[d][p].x;
+                Pw[p][1] = P[d][p].y;
+                Pw[p][2] = P[d][p].z;
+                Pw[p][3] = P[d][p].w;
+            }
+            LutPools<BITS> L;
+            L.build(lraw[d]);
+            issue(d, i + (u32)d + (u32)D);  // refill this ring slot (its registers are now copied out)
+            u32 s01, s23;
+            Item<BITS>::run(Pw, L, xr, s01, s23);
+            if (active && i + (u32)d < SPB)
+                *reinterpret_cast<uint2 *>(svp + (size_t)(i + (u32)d) * RS * svrow) = make_uint2(s01, s23);
         }
     }
     __syncthreads();
 
     // 4. ordered reduction + epilogue, 32 lanes per row
     const u32 t = tid & 31u;
-    const bool silu = (a.epilogue & GQ_EPI_SILU_MUL) != 0;
-    for (u32 rl = tid >> 5; rl < RB; rl += T >> 5) {
-        const u32 row = row0 + rl;
-        uint16_t y = reduce_row(G, sv + (size_t)rl * svrow, t, 0u, G.nchunks);
-        if (silu) {
-            sv[(size_t)rl * svrow] = y;  // park the row value for the pairing pass below (lane 0 only matters)
-        } else if (t == 0 && row < a.N) {
-            if (a.resid) y = h_add(a.resid[row], y);
+    for (u32 rl2 = tid >> 5; rl2 < SPB * RS; rl2 += T >> 5) {
+        const u32 row = row0 + rl2;
+        uint16_t y = reduce_row(G, sv + (size_t)rl2 * svrow, t, 0u, G.nchunks);
+        if (t == 0 && row < a.N) {
+            if (a.resid) y = h_add(a.resid[(size_t)m * a.N + row], y);
             a.out[(size_t)m * a.N + row] = y;
-        }
-    }
-    if (silu) {
-        // fused gate/up: the launcher interleaves blocks so that local rows [0,RB/2) are gate rows i and
-        // [RB/2,RB) the matching up rows I+i  (see launch_quad)
-        __syncthreads();
-        const u32 half_rb = RB / 2u, I = a.N / 2u;
-        for (u32 i = tid; i < half_rb; i += T) {
-            const u32 gi = blockIdx.x * half_rb + i;
-            if (gi < I) a.out[(size_t)m * I + gi] = silu_mul_h(sv[(size_t)i * svrow], sv[(size_t)(half_rb + i) * svrow]);
         }
     }
 }
@@ -358,15 +385,28 @@ __global__ void __launch_bounds__(256) ap_dequant_kernel(const u32 *qw, const ui
 // Launchers
 // ----------------------------------------------------------------------------------------------
 struct QuadCfg {
-    u32 T, RS, RT;
+    u32 T, RS, SPB, D, grid;
     size_t smem;
 };
 
-bool pick_quad_cfg(u32 N, u32 K, QuadCfg &c) {
+int g_num_cus = 0;
+int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus = n;
+        else
+            g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
     if (K % 128u) return false;
     const u32 Q = K / 128u;
     if (Q > 512u) return false;
-    // block size: multiple of 64 in [192, 512] wasting the fewest lanes; ties -> 256, then smaller
+    // block size: multiple of 64 in [192, 512] wasting the fewest lanes; ties -> 256, then the listed order
     u32 bestT = 0;
     double bestw = 2.0;
     const u32 cand[] = {256, 192, 320, 384, 448, 512};
@@ -378,47 +418,65 @@ bool pick_quad_cfg(u32 N, u32 K, QuadCfg &c) {
             bestT = T;
         }
     }
+    const int envT = gq_env_int("GQ_AP_T", 0);
+    if (envT >= 64 && envT <= 512 && envT % 64 == 0 && (u32)envT >= Q) bestT = (u32)envT;
     if (!bestT) return false;
     c.T = bestT;
     c.RS = bestT / Q;
-    // rows in flight per lane: keep >= ~3 blocks per CU where the matrix allows it
-    u32 rt = 4;
-    const int env = gq_env_int("GQ_AP_RT", 0);
-    if (env == 1 || env == 2 || env == 4)
-        rt = (u32)env;
-    else {
-        while (rt > 1 && (N + c.RS * rt - 1) / (c.RS * rt) < 768u) rt >>= 1;
-    }
-    c.RT = rt;
+    const u32 steps = (N + c.RS - 1) / c.RS;
+    // persistent-style grid: about `bpc` blocks per CU, every block the same number of steps
+    const u32 cus = (u32)num_cus();
+    u32 bpc = (u32)gq_env_int("GQ_AP_BPC", 2);
+    if (bpc < 1) bpc = 1;
+    u32 target = cus * bpc;
+    u32 spb = (steps + target - 1) / target;
+    if (spb < 1) spb = 1;
     const u32 nchunks = K / 1024u + ((K % 1024u) ? 1u : 0u);
-    c.smem = (size_t)K * 2u + (size_t)c.RS * rt * nchunks * 32u * 2u;
-    if (c.smem < (size_t)K * 2u + 64u) c.smem = (size_t)K * 2u + 64u;
-    return c.smem <= 160u * 1024u;
+    // LDS: x image + one fp16 partial per (row, chunk, virtual lane)
+    auto smem_for = [&](u32 s) { return (size_t)K * 2u + (size_t)s * c.RS * nchunks * 64u + 64u; };
+    while (spb > 1 && smem_for(spb) > 150u * 1024u) spb--;
+    if (smem_for(spb) > 160u * 1024u) return false;
+    c.SPB = spb;
+    c.grid = (steps + spb - 1) / spb;
+    int d = gq_env_int("GQ_AP_D", 0);
+    if (d < 1 || d > 4) d = bits >= 4 ? 2 : (bits == 3 ? 3 : 4);
+    if ((u32)d > spb) d = (int)spb;
+    c.D = (u32)d;
+    c.smem = smem_for(spb);
+    return true;
 }
 
-template <int BITS, int RT, bool NT>
+template <int BITS, int D, int PRO>
 int launch_quad_inst(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
     static size_t attr_set = 0;
-    auto kern = ap_gemv_quad_kernel<BITS, RT, NT>;
+    auto kern = ap_gemv_quad_kernel<BITS, D, PRO>;
     if (c.smem > 48u * 1024u && c.smem > attr_set) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)c.smem));
-        attr_set = c.smem;
+                                         (int)(160u * 1024u)));
+        attr_set = 160u * 1024u;
     }
-    const u32 RB = c.RS * c.RT;
-    dim3 grid((a.N + RB - 1) / RB, M), block(c.T);
+    dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }
 
+template <int BITS, int PRO>
+int launch_quad_d(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
+    switch (c.D) {
+        case 1: return launch_quad_inst<BITS, 1, PRO>(a, c, M, s);
+        case 2: return launch_quad_inst<BITS, 2, PRO>(a, c, M, s);
+        case 3: return launch_quad_inst<BITS, 3, PRO>(a, c, M, s);
+        default: return launch_quad_inst<BITS, 4, PRO>(a, c, M, s);
+    }
+}
+
 template <int BITS>
-int launch_quad(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
-    const bool nt = gq_env_int("GQ_AP_NT", 1) != 0;
-    switch (c.RT) {
-        case 1: return nt ? launch_quad_inst<BITS, 1, true>(a, c, M, s) : launch_quad_inst<BITS, 1, false>(a, c, M, s);
-        case 2: return nt ? launch_quad_inst<BITS, 2, true>(a, c, M, s) : launch_quad_inst<BITS, 2, false>(a, c, M, s);
-        default: return nt ? launch_quad_inst<BITS, 4, true>(a, c, M, s) : launch_quad_inst<BITS, 4, false>(a, c, M, s);
+int launch_quad(const ApArgs &a, const QuadCfg &c, u32 M, int pro, hipStream_t s) {
+    switch (pro) {
+        case PRO_RMSNORM: return launch_quad_d<BITS, PRO_RMSNORM>(a, c, M, s);
+        case PRO_SILUMUL: return launch_quad_d<BITS, PRO_SILUMUL>(a, c, M, s);
+        default: return launch_quad_d<BITS, PRO_NONE>(a, c, M, s);
     }
 }
 
@@ -431,6 +489,19 @@ int launch_generic(const ApArgs &a, u32 M, hipStream_t s) {
     return GQ_OK;
 }
 
+}  // namespace
+
+int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
+                      int bits, const void *normw, float eps, const void *resid, int pro, hipStream_t stream);
+
+namespace {
+
+int g_ap_mode = -1;  // -1: unset (env GQ_AP_MODE or default fast), 0: fast (plane-MFMA), 1: exact (fp16-order)
+bool exact_mode() {
+    if (g_ap_mode >= 0) return g_ap_mode == 1;
+    return gq_env_int("GQ_AP_EXACT", 0) != 0;
+}
+
 int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     if (bits < 2 || bits > 8) return gq_fail(GQ_EINVAL, "Bitwidth must be between 2 and 8.");
     if (M < 1 || M > 8) return gq_fail(GQ_EINVAL, "batch size M must be between 1 and 8 (anyprec.cu:602).");
@@ -439,18 +510,24 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     if (!a.x || !a.out || !a.qw || !a.lut) return gq_fail(GQ_EINVAL, "null pointer argument.");
     const bool force_generic = gq_env_int("GQ_AP_FORCE_GENERIC", 0) != 0;
     QuadCfg c;
-    if (!force_generic && bits <= 4 && pick_quad_cfg(a.N, a.K, c) && (((uintptr_t)a.qw | (uintptr_t)a.x) & 15u) == 0 &&
-        ((uintptr_t)a.lut & (bits == 2 ? 7u : 15u)) == 0) {
-        if (a.epilogue & GQ_EPI_SILU_MUL) return gq_fail(GQ_ENOTSUP, "SILU_MUL epilogue is served by gq_anyprec_gemv_fused only.");
+    const int pro = a.normw ? PRO_RMSNORM : ((a.epilogue & GQ_PRO_SILU_MUL) ? PRO_SILUMUL : PRO_NONE);
+    if (!force_generic && !exact_mode() && bits <= 4) {
+        int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, s);
+        if (rc != GQ_ENOTSUP) return rc;
+    }
+    const uint64_t qbytes = (uint64_t)bits * a.N * (a.K / 8u);
+    if (!force_generic && bits <= 4 && qbytes < 0x7FFFFFFFull && pick_quad_cfg(a.N, a.K, bits, c) &&
+        (((uintptr_t)a.qw | (uintptr_t)a.x | (uintptr_t)a.normw) & 15u) == 0 && ((uintptr_t)a.lut & 15u) == 0) {
         a.RS = c.RS;
+        a.SPB = c.SPB;
         switch (bits) {
-            case 2: return launch_quad<2>(a, c, M, s);
-            case 3: return launch_quad<3>(a, c, M, s);
-            default: return launch_quad<4>(a, c, M, s);
+            case 2: return launch_quad<2>(a, c, M, pro, s);
+            case 3: return launch_quad<3>(a, c, M, pro, s);
+            default: return launch_quad<4>(a, c, M, pro, s);
         }
     }
-    if (a.normw || (a.epilogue & GQ_EPI_SILU_MUL))
-        return gq_fail(GQ_ENOTSUP, "fused prologue/epilogue needs bits in 2..4, K % 128 == 0 and 16-byte aligned buffers.");
+    if (pro != PRO_NONE)
+        return gq_fail(GQ_ENOTSUP, "fused prologue needs bits in 2..4, K % 128 == 0 and 16-byte aligned buffers.");
     if ((uintptr_t)a.x & 15u) return gq_fail(GQ_EINVAL, "input must be 16-byte aligned.");
     switch (bits) {
         case 2: return launch_generic<2>(a, M, s);
@@ -464,6 +541,12 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int gq_set_ap_mode(int mode) {
+    if (mode < -1 || mode > 1) return gq_fail(GQ_EINVAL, "mode must be -1 (default), 0 (fast) or 1 (exact)");
+    g_ap_mode = mode;
+    return GQ_OK;
+}
 
 extern "C" int gq_anyprec_gemv(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N,
                                uint32_t K, int bits, int dtype, void *stream) {
@@ -494,7 +577,7 @@ extern "C" int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *q
     a.K = K;
     a.epilogue = epilogue;
     if ((epilogue & GQ_EPI_RESIDUAL) && !residual) return gq_fail(GQ_EINVAL, "RESIDUAL epilogue needs a residual pointer.");
-    if (epilogue & GQ_EPI_SILU_MUL) return gq_fail(GQ_ENOTSUP, "SILU_MUL epilogue not built yet.");
+    if ((epilogue & GQ_PRO_SILU_MUL) && norm_weight) return gq_fail(GQ_EINVAL, "RMSNorm and SiLU-mul prologues are exclusive.");
     return ap_gemv_dispatch(a, 1, bits, (hipStream_t)stream);
 }
 

@@ -34,12 +34,22 @@ extern "C" {
 /* epilogue / prologue flags of the fused GEMV entry point */
 #define GQ_EPI_NONE 0u
 #define GQ_EPI_RESIDUAL 1u  /* out[n] = residual[n] + y[n]          (fp16 add) */
-#define GQ_EPI_SILU_MUL 2u  /* N = 2*I fused gate/up: out[i] = silu(y[i]) * y[I+i], out has I entries */
+#define GQ_PRO_SILU_MUL 2u  /* prologue: x holds 2K values (gate|up), the GEMV input is silu(x[0:K]) * x[K:2K] */
 
 int gq_version(void);
 const char *gq_last_error(void);
 /* number of HIP devices visible, <0 on error; lets a host check the library is usable */
 int gq_device_count(void);
+
+/*
+ * Arithmetic mode of the Any-Precision GEMV (process-wide; also env GQ_AP_EXACT=1):
+ *   0  fast  (default): bit-plane GEMVs on the matrix cores, exact products, fp32 accumulation -- closer to the
+ *            exact result than the reference kernel, within the north-star tolerance of it (bits 2..4, K % 256 == 0;
+ *            other shapes fall back to the exact kernels)
+ *   1  exact: reproduces the reference kernel's fp16 accumulation order bit for bit (anyprec.cu:495-512)
+ *  -1  reset to the default / environment
+ */
+int gq_set_ap_mode(int mode);
 
 /*
  * Any-Precision LUT-GEMV.   out[m][n] = sum_k x[m][k] * lut[n][code(n,k)]
@@ -52,8 +62,9 @@ int gq_device_count(void);
  *                                    (any_precision/quantization/pack.py:304-321);
  *                                    plane stride is N*K/32 words
  *   lut     fp16 [N][2^bits]
- * Results are bit-identical to the reference kernel's fp16 accumulation order
- * (see DESIGN.md).  Requires K % 32 == 0, 2 <= bits <= 8.
+ * In exact mode results are bit-identical to the reference kernel's fp16 accumulation order; in fast mode they
+ * are within 1e-3 (relative, fp16) of it and closer to the exact product.
+ * Requires K % 32 == 0, 2 <= bits <= 8.
  */
 int gq_anyprec_gemv(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N,
                     uint32_t K, int bits, int dtype, void *stream);
@@ -93,12 +104,12 @@ int gq_qtip_matvec(float *out, const uint32_t *compressed, const void *x, const 
 int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale, void *stream);
 
 /*
- * Fused decode-step variant of the AP GEMV: optional
- * RMSNorm prologue on x and residual / SiLU-mul epilogue, same arithmetic and
- * rounding points as the reference's separate kernels
- * (inference/model.py:151-166,259-266,281-292).
+ * Fused decode-step variant of the AP GEMV, M = 1: optional prologue on x
+ * (RMSNorm, or SiLU(gate)*up of a fused gate/up vector) and optional residual-add epilogue, with the same
+ * fp16 rounding points as the reference's separate kernels (inference/model.py:151-166,259-266,281-292).
  *   norm_weight  fp16 [K] or NULL (no RMSNorm);  eps used when norm_weight != NULL
- *   residual     fp16 [N] or NULL
+ *   flags        GQ_EPI_RESIDUAL: out[n] = residual[n] + y[n]
+ *                GQ_PRO_SILU_MUL: x is fp16 [2K]; the GEMV input is silu(x[0:K]) * x[K:2K]
  */
 int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
                           uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,

@@ -9,7 +9,53 @@ from conftest import golden_files
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-REL_TOL = 1e-3  # north_star tolerance; the tests below assert equality, i.e. error 0 <= REL_TOL
+REL_TOL = 1e-3  # north_star tolerance ("within 1e-3 rel-fp16 of the CUDA reference")
+
+
+@pytest.fixture(autouse=True)
+def _exact_mode():
+    """Everything in this file not marked otherwise runs the bit-exact mode of the GEMV."""
+    from guidedquant_amd import _lib
+    _lib.check(_lib.lib().gq_set_ap_mode(1), "gq_set_ap_mode")
+    yield
+    _lib.lib().gq_set_ap_mode(-1)
+
+
+def _fast():
+    from guidedquant_amd import _lib
+    _lib.check(_lib.lib().gq_set_ap_mode(0), "gq_set_ap_mode")
+
+
+def _check_fast(got, x, q, lut, bits, oracle, rows=None):
+    """Fast (plane-MFMA) mode.  The reference kernel accumulates in fp16 and is itself ~1e-3 (rms, relative) away
+    from the exact product, so a kernel that is MORE accurate cannot be elementwise within 1e-3 of it.  What is
+    asserted instead, per element:
+      (a) accuracy: |got - exact| <= one fp16 rounding of the exact value + 1e-5 * sum|w||x|  (fp32-class);
+      (b) parity:   got is as close to the reference-order result as the correctly rounded exact result is,
+                    |got - ref| <= |fp16(exact) - ref| + 2 ulp + 1e-5 * sum|w||x|, and normwise
+                    ||got - ref|| <= 1.05 * ||fp16(exact) - ref|| (+eps): all of the distance to the reference is
+                    the reference's own fp16 accumulation error (anyprec.cu:495-512);
+      (c) shapes the fast path does not serve (K % 256 != 0) fall back to the exact kernels: bit-identical."""
+    if rows is not None:
+        q = np.ascontiguousarray(q[:, rows, :])
+        lut = lut[rows]
+        got = got[rows]
+    K = q.shape[2] * 32
+    ref16h = oracle.ap_gemv_f16(x, q, lut, bits)[0]
+    if K % 256:
+        assert np.array_equal(got.view(np.uint16), ref16h.view(np.uint16))
+        return
+    y64 = oracle.ap_gemv_f64(x, q, lut, bits)[0]
+    ref16 = ref16h.astype(np.float64)
+    W = np.abs(oracle.ap_dequant(q, lut, bits).astype(np.float64))
+    scale = W @ np.abs(np.asarray(x, dtype=np.float64).reshape(-1))
+    g = got.astype(np.float64)
+    err_exact = np.abs(g - y64)
+    assert (err_exact <= 2.0**-11 * np.abs(y64) * 1.001 + 1e-5 * scale + 1e-7).all(), (err_exact / (scale + 1e-30)).max()
+    e16 = y64.astype(np.float16).astype(np.float64)
+    ulp = np.maximum(np.abs(np.spacing(y64.astype(np.float16))).astype(np.float64), 2.0**-24)
+    assert (np.abs(g - ref16) <= np.abs(e16 - ref16) + 2 * ulp + 1e-5 * scale).all()
+    assert np.linalg.norm(g - ref16) <= 1.05 * np.linalg.norm(e16 - ref16) + 1e-6 * np.linalg.norm(scale) + 1e-7
 
 
 def _dev():
@@ -184,3 +230,62 @@ def test_aplinear_module_and_custom_op(oracle):
     W = oracle.ap_dequant(q, lut, bits).astype(np.float32)
     ref = xs.float().cpu().numpy()[0] @ W.T
     np.testing.assert_allclose(ys.float().cpu().numpy()[0], ref, rtol=2e-2, atol=2e-2)
+
+
+# ----------------------------------------------------------------------------- fast (plane-MFMA) mode
+@pytest.mark.parametrize("path", [p for p in golden_files("ap_b") if int(np.load(p)["bits"]) in (2, 3, 4)])
+def test_fast_mode_goldens(oracle, path):
+    g = np.load(path)
+    bits = int(g["bits"])
+    _fast()
+    got = _run_gemv(g["x"], g["qweight"], g["lut"], bits)[0]
+    _check_fast(got, g["x"], g["qweight"], g["lut"], bits, oracle)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("N,K", [(64, 4096), (36, 1024), (20, 1280), (12, 11008), (8, 14336), (16, 2048), (4, 8192),
+                                 (200, 256), (17, 5120)])
+def test_fast_mode_random(oracle, bits, N, K):
+    rng = np.random.default_rng(bits * 7919 + N * 131 + K + 1)
+    codes = rng.integers(0, 1 << bits, (N, K), dtype=np.uint8)
+    q = oracle.ap_pack(codes, bits)
+    lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
+    x = (rng.normal(0, 1, K) * np.where(rng.random(K) < 0.02, 40.0, 1.0)).astype(np.float16)
+    _fast()
+    got = _run_gemv(x, q, lut, bits)[0]
+    _check_fast(got, x, q, lut, bits, oracle)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (3072, 2048),
+                                 (10240, 8192), (8192, 28672)])
+def test_fast_mode_full_size_sampled_rows(oracle, bits, N, K):
+    from guidedquant_amd import pack
+    rng = np.random.default_rng(bits + N + K)
+    q = pack.random_planes(N, K, bits, seed=bits * 31 + N)
+    lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
+    x = rng.normal(0, 1, K).astype(np.float16)
+    _fast()
+    got = _run_gemv(x, q, lut, bits)[0]
+    assert np.isfinite(got.astype(np.float32)).all()
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(N - 40, N), rng.integers(0, N, 64)]))
+    _check_fast(got, x, q, lut, bits, oracle, rows=rows)
+
+
+def test_fast_mode_tiny_and_huge_activations(oracle):
+    """block scaling of the activation pieces: vectors of very small / very large / mixed magnitude stay accurate"""
+    bits, N, K = 2, 48, 4096
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, 1 << bits, (N, K), dtype=np.uint8)
+    q = oracle.ap_pack(codes, bits)
+    lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
+    _fast()
+    for mag in (1e-4, 1.0, 3e2):
+        x = (rng.normal(0, mag, K)).astype(np.float16)
+        got = _run_gemv(x, q, lut, bits)[0]
+        _check_fast(got, x, q, lut, bits, oracle)
+    x = (rng.normal(0, 1, K) * 10.0**rng.integers(-4, 2, K)).astype(np.float16)
+    got = _run_gemv(x, q, lut, bits)[0]
+    _check_fast(got, x, q, lut, bits, oracle)
+    x = np.zeros(K, dtype=np.float16)
+    assert (_run_gemv(x, q, lut, bits)[0] == 0).all()

@@ -66,12 +66,12 @@ __device__ __forceinline__ u32 silu_mul_pk(u32 g, u32 u) {
 
 template <int PRO>
 __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, const uint16_t *normw, float eps,
-                                        uint16_t *xlds, float *red /* >= 16 floats of LDS */) {
-    const u32 T = blockDim.x, tid = threadIdx.x;
+                                        uint16_t *xlds, float *red /* >= 16 floats of LDS */, bool stager, u32 T) {
+    const u32 tid = threadIdx.x;
     float scale = 0.f;
     if constexpr (PRO == PRO_RMSNORM) {
         float ss = 0.f;
-        for (u32 g = tid; g < G.K / 8u; g += T) {
+        for (u32 g = stager ? tid : G.K; g < G.K / 8u; g += T) {
             uint4 v = ld16(x + 8u * g);
             const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -83,13 +83,13 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
         }
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
-        if ((tid & 63u) == 0) red[tid >> 6] = ss;
+        if ((tid & 63u) == 0 && stager) red[tid >> 6] = ss;
         __syncthreads();
         float tot = 0.f;
         for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
         scale = 1.0f / sqrtf(tot / (float)G.K + eps);
     }
-    for (u32 idx = tid; idx < 4u * G.Q; idx += T) {
+    for (u32 idx = stager ? tid : 4u * G.Q; idx < 4u * G.Q; idx += T) {
         const u32 q = idx >> 2, c = idx & 3u;
         const u32 e0 = G.xindex(q, 0u, c, 0u);  // 32 consecutive activations: v = 0..3, j = 0..7
         u32 in[4][4];
@@ -158,7 +158,7 @@ __device__ __forceinline__ uint16_t reduce_row(const RowGeom &G, const uint16_t 
 // vmcnt bookkeeping stays exact.  The lane's activations stay in 64 VGPRs for the whole loop.
 // ----------------------------------------------------------------------------------------------
 template <int BITS, int D, int PRO>
-__global__ void __launch_bounds__(512) ap_gemv_quad_kernel(ApArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <= 3 ? 3 : 2))) ap_gemv_quad_kernel(ApArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RowGeom G;
     G.init(a.K);
@@ -207,12 +207,21 @@ __global__ void __launch_bounds__(512) ap_gemv_quad_kernel(ApArgs a) {
         }
     };
 
-    // 1. fill the ring before touching anything else
+    // 1. vector-memory results return in order: waves that stage x must not have plane loads queued in front of
+    //    their x loads.  Upper half of the waves: fill the ring now; lower half: stage x first, then fill.
+    const u32 nw = T >> 6, wv = tid >> 6;
+    const bool stager = nw < 2u || wv < nw / 2u;
+    if (!stager) {
 #pragma unroll
-    for (int d = 0; d < D; d++) issue(d, (u32)d);
-
+        for (int d = 0; d < D; d++) issue(d, (u32)d);
+    }
     // 2. activations -> LDS (lane-linear image) -> 64 VGPRs
-    stage_x<PRO>(G, a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), a.normw, a.eps, xlds, red);
+    stage_x<PRO>(G, a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), a.normw, a.eps, xlds, red, stager,
+                 nw < 2u ? T : (nw / 2u) * 64u);
+    if (stager) {
+#pragma unroll
+        for (int d = 0; d < D; d++) issue(d, (u32)d);
+    }
     __syncthreads();
     XRegs xr;
 #pragma unroll
@@ -426,7 +435,7 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
     const u32 steps = (N + c.RS - 1) / c.RS;
     // persistent-style grid: about `bpc` blocks per CU, every block the same number of steps
     const u32 cus = (u32)num_cus();
-    u32 bpc = (u32)gq_env_int("GQ_AP_BPC", 2);
+    u32 bpc = (u32)gq_env_int("GQ_AP_BPC", bits <= 3 ? 3 : 2);
     if (bpc < 1) bpc = 1;
     u32 target = cus * bpc;
     u32 spb = (steps + target - 1) / target;
@@ -439,7 +448,7 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
     c.SPB = spb;
     c.grid = (steps + spb - 1) / spb;
     int d = gq_env_int("GQ_AP_D", 0);
-    if (d < 1 || d > 4) d = bits >= 4 ? 2 : (bits == 3 ? 3 : 4);
+    if (d < 1 || d > 4) d = bits <= 3 ? 1 : 2;
     if ((u32)d > spb) d = (int)spb;
     c.D = (u32)d;
     c.smem = smem_for(spb);

@@ -58,8 +58,10 @@ GQP_HD int scale_byte(int s) { return 127 - pattern_exp(s); }
 // is {kb in pair b&1} x {v in half b>>1}:
 GQP_HD u32 blk_of(u32 kb, u32 v) { return (kb >> 1) + 2u * (v >> 2); }
 
-// byte offset of the 32-byte B block of (chunk, s, kb, piece) in the LDS image; inside: 4*v + B
-GQP_HD u32 bimg_off(u32 chunk, u32 s, u32 kb, u32 piece) { return ((((chunk * 8u + s) * 4u + kb) * 4u + piece) << 5); }
+// byte offset of the 32-byte B block of (chunk, s, kb, piece) in the LDS image; inside: 4*v + B.
+// kb is the fastest block index so that the 32 virtual lanes t = 8*kb + v of one (chunk, s, piece) are 128
+// contiguous bytes (conflict-free 4-byte LDS writes by 32 consecutive lanes)
+GQP_HD u32 bimg_off(u32 chunk, u32 s, u32 kb, u32 piece) { return ((((chunk * 8u + s) * 4u + piece) * 4u + kb) << 5); }
 
 struct Geom {
     u32 K, wpr, nfull, eff, nchunks;

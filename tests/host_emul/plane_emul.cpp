@@ -29,7 +29,7 @@ static void run(const Geom &G, const uint16_t *x, const uint32_t *qw, const uint
     for (u32 e = 0; e < G.K; e++) {
         u32 chunk, s, kb, v, B;
         locate_x(G, e, chunk, s, kb, v, B);
-        float &mxb = bmax[(chunk * 8 + s) * 4 + blk_of(kb, v)];
+        float &mxb = bmax[(chunk * 8 + 0) * 4 + blk_of(kb, v)];
         mxb = fmaxf(mxb, fabsf(h2f(x[e])));
     }
     for (size_t i = 0; i < bmax.size(); i++)
@@ -38,7 +38,7 @@ static void run(const Geom &G, const uint16_t *x, const uint32_t *qw, const uint
     for (u32 e = 0; e < G.K; e++) {
         u32 chunk, s, kb, v, B;
         locate_x(G, e, chunk, s, kb, v, B);
-        const int eb = beb[(chunk * 8 + s) * 4 + blk_of(kb, v)];
+        const int eb = beb[(chunk * 8 + 0) * 4 + blk_of(kb, v)];
         float r = h2f(x[e]) * ldexpf(1.0f, 15 - eb);
         X += h2f(x[e]);
         for (u32 p = 0; p < 4; p++) {
@@ -73,7 +73,7 @@ static void run(const Geom &G, const uint16_t *x, const uint32_t *qw, const uint
                                 double av = bf8_to_f32((uint8_t)(a >> (8 * B)));
                                 if (av == 0.0) continue;
                                 // the hardware applies to element (kb, v) the scale supplied by lane group blk_of(kb, v)
-                                const double sb = ldexp(1.0, beb[(chunk * 8 + s) * 4 + blk_of(kb, v)] - 15);
+                                const double sb = ldexp(1.0, beb[(chunk * 8 + 0) * 4 + blk_of(kb, v)] - 15);
                                 for (u32 p = 0; p < 4; p++)
                                     T[r * NP + cm] += av * scale * sb * bf8_to_f32(bimg[bimg_off(chunk, s, kb, p) + 4 * v + B]);
                             }

@@ -14,7 +14,8 @@ _lib = None
 # symbols include/gq_hip.h declares; tests check that the built library exports every one
 EXPORTS = [
     "gq_version", "gq_last_error", "gq_device_count", "gq_anyprec_gemv", "gq_anyprec_dequant", "gq_lutgemm_gemv",
-    "gq_qtip_matvec", "gq_hadamard", "gq_anyprec_gemv_fused", "gq_set_ap_mode",
+    "gq_qtip_matvec", "gq_hadamard", "gq_anyprec_gemv_fused", "gq_set_ap_mode", "gq_embed_lookup", "gq_attn_decode",
+    "gq_dense_gemv_f16",
 ]
 
 
@@ -46,6 +47,9 @@ def lib():
         L.gq_hadamard.argtypes = [vp, vp, u32, u32, f32, vp]
         L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]
         L.gq_set_ap_mode.argtypes = [i32]
+        L.gq_embed_lookup.argtypes = [vp, vp, vp, u32, u32, vp]
+        L.gq_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, vp]
+        L.gq_dense_gemv_f16.argtypes = [vp, vp, vp, u32, u32, vp, f32, vp]
         for name in EXPORTS:
             if name not in ("gq_last_error", ):
                 getattr(L, name).restype = i32

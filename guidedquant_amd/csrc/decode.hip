@@ -1,0 +1,303 @@
+// decode.hip -- the non-quantized pieces of one bs=1 decode step, gfx950:
+//   * token embedding lookup                      (inference/model.py:123 tok_embeddings)
+//   * RoPE + KV-cache update + single-query attention  (inference/model.py:206-241, 336-341, 63-79)
+//   * dense fp16 GEMV with optional RMSNorm prologue   (final norm + lm_head `output`, inference/model.py:93-94,128-129)
+// All entry points read the token id / position from DEVICE memory so a captured hipGraph can be replayed for
+// every token without re-recording.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gq_internal.h"
+
+namespace {
+
+typedef uint32_t u32;
+typedef _Float16 h16;
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(h16, h); }
+__device__ __forceinline__ h16 u2h(uint16_t h) { return __builtin_bit_cast(h16, h); }
+__device__ __forceinline__ uint16_t h2u(h16 h) { return __builtin_bit_cast(uint16_t, h); }
+
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+    auto comb = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    v = comb(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+    v = comb(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+    v = comb(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));
+    v = comb(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));
+    // row_bcast15 -> rows 1,3 ; row_bcast31 -> rows 2,3 ; lanes not written keep `old` = identity for the combine
+    const float ident = MAX ? -3.0e38f : 0.f;
+    v = comb(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)));
+    v = comb(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+__global__ void embed_kernel(const int *tok, const uint16_t *table, uint16_t *out, u32 D, u32 V) {
+    u32 t = (u32)tok[0];
+    if (t >= V) t = 0;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < D / 8u; i += gridDim.x * blockDim.x)
+        reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(table + (size_t)t * D)[i];
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// One block per query head.  RoPE exactly as apply_rotary_pos_emb on fp16 tensors (inference/model.py:336-341):
+//   q_embed = (q * cos) + (rotate_half(q) * sin)   -- three fp16-rounded operations, cos/sin are fp16 tables
+// built by the host from fp32 (LlamaRotaryEmbedding.forward, model.py:379-405).  The rotated k and the v of this
+// token are written to the cache at `pos` (KVCache.update, model.py:69-79) by the first head of each KV group.
+// Scores / softmax / weighted sum run in fp32 from the fp16 operands; the output is rounded to fp16 once.
+template <int HD>
+__global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, const int *pos_ptr, const uint16_t *cos_t,
+                                                          const uint16_t *sin_t, uint16_t *kc, uint16_t *vc, uint16_t *out,
+                                                          u32 H, u32 Hkv, u32 max_seq, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *sc = reinterpret_cast<float *>(smem);  // [max_seq] scores / probabilities
+    float *qs = sc + max_seq;                     // [HD]
+    float *kcur = qs + HD;                        // [HD]
+    float *vcur = kcur + HD;                      // [HD]
+    float *red = vcur + HD;                       // [4 * HD] partial outputs + 8 scratch
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    const u32 h = blockIdx.x, group = H / Hkv, g = h / group;
+    u32 pos = (u32)pos_ptr[0];
+    if (pos >= max_seq) pos = max_seq - 1;
+    const uint16_t *q = qkv + (size_t)h * HD;
+    const uint16_t *k = qkv + (size_t)H * HD + (size_t)g * HD;
+    const uint16_t *v = qkv + (size_t)(H + Hkv) * HD + (size_t)g * HD;
+    uint16_t *kcg = kc + (size_t)g * max_seq * HD;
+    uint16_t *vcg = vc + (size_t)g * max_seq * HD;
+    if (tid < HD) {
+        const u32 d = tid;
+        const h16 c = u2h(cos_t[(size_t)pos * HD + d]), s = u2h(sin_t[(size_t)pos * HD + d]);
+        const h16 qd = u2h(q[d]), kd = u2h(k[d]);
+        const h16 qr = d < HD / 2 ? -u2h(q[d + HD / 2]) : u2h(q[d - HD / 2]);
+        const h16 kr = d < HD / 2 ? -u2h(k[d + HD / 2]) : u2h(k[d - HD / 2]);
+        const h16 qe = (h16)(qd * c) + (h16)(qr * s);
+        const h16 ke = (h16)(kd * c) + (h16)(kr * s);
+        qs[d] = (float)qe;
+        kcur[d] = (float)ke;
+        vcur[d] = h2f(v[d]);
+        if (h % group == 0) {
+            kcg[(size_t)pos * HD + d] = h2u(ke);
+            vcg[(size_t)pos * HD + d] = v[d];
+        }
+    }
+    __syncthreads();
+    // scores: one wave per position, HD/64 dims per lane
+    constexpr int E = HD / 64;
+    float qreg[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) qreg[e] = qs[l * E + e];
+    for (u32 t = w; t <= pos; t += 4) {
+        float p = 0.f;
+        if (t == pos) {
+#pragma unroll
+            for (int e = 0; e < E; e++) p += qreg[e] * kcur[l * E + e];
+        } else {
+            const uint16_t *kt = kcg + (size_t)t * HD + l * E;
+#pragma unroll
+            for (int e = 0; e < E; e++) p += qreg[e] * h2f(kt[e]);
+        }
+        p = wave_reduce<false>(p);
+        if (l == 0) sc[t] = p * scale;
+    }
+    __syncthreads();
+    float mx = -3.0e38f;
+    for (u32 t = tid; t <= pos; t += 256) mx = fmaxf(mx, sc[t]);
+    mx = wave_reduce<true>(mx);
+    if (l == 0) red[4 * HD + w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[4 * HD], red[4 * HD + 1]), fmaxf(red[4 * HD + 2], red[4 * HD + 3]));
+    float sum = 0.f;
+    for (u32 t = tid; t <= pos; t += 256) {
+        const float e = __expf(sc[t] - mx);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = wave_reduce<false>(sum);
+    if (l == 0) red[4 * HD + 4 + w] = sum;
+    __syncthreads();
+    sum = red[4 * HD + 4] + red[4 * HD + 5] + red[4 * HD + 6] + red[4 * HD + 7];
+    // weighted sum of values: wave w takes positions t = w, w+4, ...
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) acc[e] = 0.f;
+    for (u32 t = w; t <= pos; t += 4) {
+        const float p = sc[t];
+        if (t == pos) {
+#pragma unroll
+            for (int e = 0; e < E; e++) acc[e] += p * vcur[l * E + e];
+        } else {
+            const uint16_t *vt = vcg + (size_t)t * HD + l * E;
+#pragma unroll
+            for (int e = 0; e < E; e++) acc[e] += p * h2f(vt[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) red[w * HD + l * E + e] = acc[e];
+    __syncthreads();
+    if (tid < HD) {
+        const float o = (red[tid] + red[HD + tid] + red[2 * HD + tid] + red[3 * HD + tid]) / sum;
+        out[(size_t)h * HD + tid] = h2u((h16)o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dense fp16 GEMV
+// out[n] = sum_k x[k] * W[n][k], fp32 accumulation (v_dot2_f32_f16), fp16 output -- what nn.Linear(fp16) gives at M = 1.
+// Optional RMSNorm prologue on x (final norm before lm_head).  One wave = RW rows at a time, 16-byte loads,
+// all K/512 * RW loads of a row group in flight.
+template <int RW>
+__global__ void __launch_bounds__(256) dense_gemv_kernel(const uint16_t *x, const uint16_t *W, uint16_t *out, u32 N, u32 K,
+                                                         const uint16_t *normw, float eps, u32 rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
+    float *red = reinterpret_cast<float *>(xs + K);
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    float nscale = 1.f;
+    if (normw) {
+        float ss = 0.f;
+        for (u32 g = tid; g < K / 8u; g += 256) {
+            const uint4 v = reinterpret_cast<const uint4 *>(x)[g];
+            const u32 ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float a = h2f(ww[i] & 0xFFFF), b = h2f(ww[i] >> 16);
+                ss += a * a;
+                ss += b * b;
+            }
+        }
+        ss = wave_reduce<false>(ss);
+        if (l == 0) red[w] = ss;
+        __syncthreads();
+        nscale = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+    }
+    for (u32 g = tid; g < K / 8u; g += 256) {
+        uint4 v = reinterpret_cast<const uint4 *>(x)[g];
+        if (normw) {
+            const uint4 nv = reinterpret_cast<const uint4 *>(normw)[g];
+            u32 ww[4] = {v.x, v.y, v.z, v.w};
+            const u32 nw[4] = {nv.x, nv.y, nv.z, nv.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const h16 a = (h16)(h2f(ww[i] & 0xFFFF) * nscale) * u2h((uint16_t)(nw[i] & 0xFFFF));
+                const h16 b = (h16)(h2f(ww[i] >> 16) * nscale) * u2h((uint16_t)(nw[i] >> 16));
+                ww[i] = (u32)h2u(a) | ((u32)h2u(b) << 16);
+            }
+            v = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        }
+        reinterpret_cast<uint4 *>(xs)[g] = v;
+    }
+    __syncthreads();
+    const u32 row_begin = blockIdx.x * rows_per_block;
+    const u32 row_end = min(row_begin + rows_per_block, N);
+    for (u32 r0 = row_begin + w * RW; r0 < row_end; r0 += 4 * RW) {
+        float acc[RW];
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] = 0.f;
+        for (u32 k0 = l * 8u; k0 < K; k0 += 512u) {
+            const uint4 xv = *reinterpret_cast<const uint4 *>(xs + k0);
+            uint4 wv[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) {
+                const u32 row = min(r0 + (u32)r, N - 1u);
+                const u32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W + (size_t)row * K + k0));
+                wv[r] = make_uint4(t4.x, t4.y, t4.z, t4.w);
+            }
+#pragma unroll
+            for (int r = 0; r < RW; r++) {
+                acc[r] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, wv[r].x), __builtin_bit_cast(h16x2, xv.x), acc[r], false);
+                acc[r] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, wv[r].y), __builtin_bit_cast(h16x2, xv.y), acc[r], false);
+                acc[r] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, wv[r].z), __builtin_bit_cast(h16x2, xv.z), acc[r], false);
+                acc[r] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, wv[r].w), __builtin_bit_cast(h16x2, xv.w), acc[r], false);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            const float s = wave_reduce<false>(acc[r]);
+            if (l == 0 && r0 + (u32)r < row_end) out[r0 + r] = h2u((h16)s);
+        }
+    }
+}
+
+int g_cu = 0;
+int cu_count() {
+    if (!g_cu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_cu = n;
+        else
+            g_cu = 256;
+    }
+    return g_cu;
+}
+
+}  // namespace
+
+extern "C" int gq_embed_lookup(const int *token, const void *table, void *out, uint32_t dim, uint32_t vocab, void *stream) {
+    if (!token || !table || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (dim % 8u) return gq_fail(GQ_EINVAL, "embedding dim must be a multiple of 8.");
+    hipLaunchKernelGGL(embed_kernel, dim3((dim / 8u + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, token,
+                       (const uint16_t *)table, (uint16_t *)out, dim, vocab);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                              void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                              float scale, void *stream) {
+    if (!qkv || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (n_kv_head == 0 || n_head % n_kv_head) return gq_fail(GQ_EINVAL, "n_head must be a multiple of n_kv_head.");
+    if (head_dim != 64 && head_dim != 128) return gq_fail(GQ_ENOTSUP, "head_dim must be 64 or 128.");
+    const size_t smem = ((size_t)max_seq + 7u * head_dim + 16u) * 4u;
+    if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "max_seq too large for the single-pass attention kernel.");
+    hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 128) {
+        static bool set = false;
+        if (smem > 48u * 1024u && !set) {
+            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_decode_kernel<128>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set = true;
+        }
+        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(n_head), dim3(256), smem, s, (const uint16_t *)qkv, pos,
+                           (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
+                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale);
+    } else {
+        static bool set = false;
+        if (smem > 48u * 1024u && !set) {
+            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_decode_kernel<64>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set = true;
+        }
+        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(n_head), dim3(256), smem, s, (const uint16_t *)qkv, pos,
+                           (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
+                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale);
+    }
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint32_t K, const void *norm_weight,
+                                 float eps, void *stream) {
+    if (!x || !W || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (K == 0 || K % 512u || N == 0) return gq_fail(GQ_EINVAL, "dense GEMV needs N > 0 and K a positive multiple of 512.");
+    if ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)norm_weight) & 15u)) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
+    const size_t smem = (size_t)K * 2u + 64u;
+    if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "K too large.");
+    constexpr int RW = 4;
+    const u32 ncu = (u32)cu_count();
+    // ~4 blocks per CU, every block a multiple of 4 waves * RW rows
+    u32 rpb = (N + ncu * 4u - 1u) / (ncu * 4u);
+    rpb = ((rpb + 4u * RW - 1u) / (4u * RW)) * (4u * RW);
+    const u32 grid = (N + rpb - 1u) / rpb;
+    static bool set = false;
+    if (smem > 48u * 1024u && !set) {
+        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dense_gemv_kernel<RW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        set = true;
+    }
+    hipLaunchKernelGGL(dense_gemv_kernel<RW>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const uint16_t *)x,
+                       (const uint16_t *)W, (uint16_t *)out, N, K, (const uint16_t *)norm_weight, eps, rpb);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}

@@ -1,0 +1,232 @@
+"""Decode harness mirroring inference/generate.py of the reference: sampling (`logits_to_probs`, `sample`,
+`multinomial_sample_one_no_sync`, :53-73), `decode_one_token` (:82-86), `decode_n_tokens` with a captured graph
+(:92-139), `generate` (:146-193), `load_model` backend switch with `random_init` (:195-245), the tokens/s and
+"Bandwidth achieved" metrics (:247-266, :374-389).
+
+Differences forced by the environment (no network: no tokenizer, no checkpoints): prompts are token-id tensors
+(BOS-only by default, as `encode_bos`), weights are synthetic (`random_init=True`, the reference's own switch), and
+`torch.compile(mode="max-autotune")` is replaced by the fused HIP decode step + one hipGraph per token step.
+"""
+import itertools
+import time
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import pack
+from .APLinear import APLinear
+from .LUTGEMMLinear import LUTGEMMLinear
+from .model import Transformer
+
+
+def multinomial_sample_one_no_sync(probs_sort):  # does multinomial sampling without a cuda synchronization
+    q = torch.empty_like(probs_sort).exponential_(1)
+    return torch.argmax(probs_sort / q, dim=-1, keepdim=True).to(dtype=torch.int)
+
+
+def logits_to_probs(logits, temperature: float = 1.0, top_k: Optional[int] = None):
+    logits = logits / max(temperature, 1e-5)
+    if top_k is not None:
+        v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+        pivot = v.select(-1, -1).unsqueeze(-1)
+        logits = torch.where(logits < pivot, -float("Inf"), logits)
+    probs = torch.nn.functional.softmax(logits, dim=-1)
+    return probs
+
+
+def sample(logits, temperature: float = 1.0, top_k: Optional[int] = None):
+    logits = logits.float()
+    probs = logits_to_probs(logits[:, -1], temperature, top_k)
+    idx_next = multinomial_sample_one_no_sync(probs)
+    return idx_next, probs
+
+
+def prefill(model: Transformer, x: torch.Tensor, input_pos: torch.Tensor, **sampling_kwargs) -> torch.Tensor:
+    logits = model(x, input_pos)
+    return sample(logits, **sampling_kwargs)[0]
+
+
+def decode_one_token(model: Transformer, x: torch.Tensor, input_pos: torch.Tensor, **sampling_kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x: [1,1] token ids, input_pos: [1] (int32).  Uses the fused HIP step when the model supports it."""
+    assert input_pos.shape[-1] == 1
+    if model.native_ready():
+        logits = model.decode_native(x.view(1), input_pos.view(1))
+    else:
+        logits = model(x, input_pos)
+    return sample(logits, **sampling_kwargs)
+
+
+class DecodeGraph:
+    """One captured hipGraph of `decode_one_token` with static token / position / output tensors
+    (the manual-graph path of generate.py:95-113)."""
+
+    def __init__(self, model: Transformer, device, **sampling_kwargs):
+        self.model = model
+        self.tok = torch.zeros((1, 1), dtype=torch.int32, device=device)
+        self.pos = torch.zeros((1, ), dtype=torch.int32, device=device)
+        self.next_tok = torch.zeros((1, 1), dtype=torch.int32, device=device)
+        self.next_prob = torch.zeros((1, model.config.vocab_size), dtype=torch.float32, device=device)
+        self.sampling_kwargs = sampling_kwargs
+        # warm up on a side stream (lazy kernel attributes, allocator), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        torch.cuda.synchronize()
+
+    def _step(self):
+        t, p = decode_one_token(self.model, self.tok, self.pos, **self.sampling_kwargs)
+        self.next_tok.copy_(t)
+        self.next_prob.copy_(p)
+
+    def step(self, advance=True):
+        """replay one token step; by default feeds the sampled token back and advances the position on device"""
+        self.graph.replay()
+        if advance:
+            self.tok.copy_(self.next_tok)
+            self.pos.add_(1)
+
+
+def decode_n_tokens(model: Transformer, cur_token: torch.Tensor, input_pos: torch.Tensor, num_new_tokens: int,
+                    use_graph=True, callback=lambda _: _, graph: Optional[DecodeGraph] = None, **sampling_kwargs):
+    new_tokens, new_probs = [], []
+    if use_graph:
+        g = graph or DecodeGraph(model, cur_token.device, **sampling_kwargs)
+        g.tok.copy_(cur_token.view(1, 1))
+        g.pos.copy_(input_pos.view(1))
+        for _ in range(num_new_tokens):
+            g.step()
+            new_tokens.append(g.next_tok.clone())
+            callback(new_tokens[-1])
+            new_probs.append(g.next_prob.clone())
+    else:
+        for _ in range(num_new_tokens):
+            next_token, next_prob = decode_one_token(model, cur_token, input_pos, **sampling_kwargs)
+            input_pos = input_pos + 1
+            new_tokens.append(next_token.clone())
+            callback(new_tokens[-1])
+            new_probs.append(next_prob.clone())
+            cur_token = next_token.clone().view(1, 1)
+    torch.cuda.synchronize()
+    return new_tokens, new_probs
+
+
+@torch.no_grad()
+def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, batch_size: int = 1, callback=lambda x: x,
+             use_graph=True, graph: Optional[DecodeGraph] = None, **sampling_kwargs) -> torch.Tensor:
+    T = prompt.size(-1)
+    T_new = T + max_new_tokens
+    max_seq_length = min(T_new, model.config.block_size)
+    device, dtype = prompt.device, prompt.dtype
+    model.setup_caches(max_batch_size=batch_size, max_seq_length=max_seq_length)
+    seq = torch.empty(batch_size, T_new, dtype=dtype, device=device)
+    prompt = prompt.view(1, -1).repeat(batch_size, 1)
+    seq[:, :T] = prompt
+    input_pos = torch.arange(0, T, device=device, dtype=torch.int32)
+    if T != 1:
+        next_token = prefill(model, prompt.view(batch_size, -1), input_pos, **sampling_kwargs).clone()
+        seq[:, T] = next_token.squeeze()
+        input_pos = torch.tensor([T], device=device, dtype=torch.int32).view(1)
+        generated, _ = decode_n_tokens(model, next_token.view(batch_size, -1), input_pos, max_new_tokens - 1,
+                                       use_graph=use_graph, callback=callback, graph=graph, **sampling_kwargs)
+        seq[:, T + 1:] = torch.cat(generated, dim=-1)
+    else:
+        generated, _ = decode_n_tokens(model, prompt.view(batch_size, -1), input_pos, max_new_tokens, use_graph=use_graph,
+                                       callback=callback, graph=graph, **sampling_kwargs)
+        seq[:, 1:] = torch.cat(generated, dim=-1)
+    return seq
+
+
+def random_init_(model: Transformer, seed: int = 0, lut_std: float = 0.02, cheap: bool = True):
+    """`--random_init` equivalent: fill every parameter/buffer with synthetic values of the right format.
+    Quantized linears get uniformly random codes (= uniformly random plane words, the packing is a bijection) and
+    per-row sorted N(0, lut_std^2) centroids."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    dev = model.output.weight.device
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(seed)
+    for name, mod in model.named_modules():
+        if isinstance(mod, APLinear):
+            mod.qweight.copy_(torch.randint(-2**31, 2**31 - 1, mod.qweight.shape, dtype=torch.int32, device=dev, generator=gd))
+            lut = (torch.randn(mod.lut.shape, device=dev, generator=gd) * lut_std).sort(dim=1).values
+            mod.lut.copy_(lut.to(mod.lut.dtype))
+        elif isinstance(mod, LUTGEMMLinear):
+            mod.qweight.copy_(torch.randint(-2**31, 2**31 - 1, mod.qweight.shape, dtype=torch.int32, device=dev, generator=gd))
+            mod.alpha.copy_((torch.rand(mod.alpha.shape, device=dev, generator=gd) * lut_std).to(mod.alpha.dtype))
+            mod.q_bias.copy_((torch.randn(mod.q_bias.shape, device=dev, generator=gd) * lut_std).to(mod.q_bias.dtype))
+        elif isinstance(mod, nn.Linear):
+            mod.weight.data.copy_((torch.randn(mod.weight.shape, device=dev, generator=gd) * 0.02).to(mod.weight.dtype))
+        elif isinstance(mod, nn.Embedding):
+            mod.weight.data.copy_((torch.randn(mod.weight.shape, device=dev, generator=gd) * 0.02).to(mod.weight.dtype))
+    return model
+
+
+def load_model(model_name, device, backend, bitwidth, random_init=True, checkpoint_path=None, dtype=torch.float16,
+               halve_layers=False):
+    linear_kwargs = {}
+    if backend == "ap":
+        linear_class = APLinear
+        linear_kwargs["bitwidth"] = bitwidth
+        linear_kwargs["device"] = device
+    elif backend == "lutgemm":
+        linear_class = LUTGEMMLinear
+        linear_kwargs["bitwidth"] = bitwidth
+        linear_kwargs["group_size"] = -1
+        linear_kwargs["device"] = device
+    elif backend is None:
+        linear_class = nn.Linear
+        assert bitwidth == 16
+    else:
+        raise ValueError(f"unknown backend {backend!r} (ap | lutgemm | None)")
+    model = Transformer.from_name(name=model_name, dtype=dtype, linear_class=linear_class, linear_kwargs=linear_kwargs,
+                                  halve_layers=halve_layers, fuse_linears=True)
+    if not random_init:
+        import os
+        checkpoint = torch.load(os.path.join(checkpoint_path, "converted_pytorch_model.bin"), mmap=True, weights_only=True)
+        model.load_state_dict(checkpoint, assign=True, strict=True)
+    model = model.to(device=device, dtype=dtype)
+    if random_init:
+        random_init_(model)
+    return model.eval()
+
+
+def _get_model_size(model):
+    """bytes of parameters AND buffers of every non-Embedding child (generate.py:247-266)"""
+    model_size = 0
+    params = 0
+    for name, child in model.named_children():
+        if not isinstance(child, torch.nn.Embedding):
+            model_size += sum(p.numel() * p.dtype.itemsize for p in itertools.chain(child.parameters(), child.buffers()))
+            params += sum(p.numel() for p in itertools.chain(child.parameters(), child.buffers()))
+    return model_size, params
+
+
+def benchmark_decode(model: Transformer, device, num_samples=5, max_new_tokens=100, top_k=32, temperature=0.0, seed=1234,
+                     bos_id=128000):
+    """tokens/s as the reference measures it (generate.py:344-389): BOS-only prompt, one warm-up generate, then
+    `num_samples` timed generate() calls; mean/std of tokens/s and model-level bandwidth."""
+    torch.manual_seed(seed)
+    prompt = torch.tensor([bos_id % model.config.vocab_size], dtype=torch.int32, device=device)
+    model.setup_caches(1, 1 + max_new_tokens)
+    graph = DecodeGraph(model, device, temperature=temperature, top_k=top_k)
+    tps = []
+    for i in range(-1, num_samples):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = generate(model, prompt, max_new_tokens, use_graph=True, graph=graph, temperature=temperature, top_k=top_k)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        if i >= 0:
+            tps.append((y.size(-1) - prompt.size(-1)) / t)
+    model_size, _ = _get_model_size(model)
+    return dict(tokens_per_sec=float(np.mean(tps)), std=float(np.std(tps)), bandwidth_GBps=model_size * float(np.mean(tps)) / 1e9,
+                model_size=model_size)

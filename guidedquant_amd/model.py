@@ -1,0 +1,330 @@
+"""gpt-fast style Transformer -- the caller of the quantized linears, mirroring inference/model.py of the reference.
+
+Same public surface: `ModelArgs`, `transformer_configs`, `KVCache`, `Transformer.from_name(dtype, name, linear_class,
+linear_kwargs, halve_layers, fuse_linears)`, `setup_caches`, `forward(idx, input_pos)`; same module tree and state-dict
+keys (`layers.{i}.attention.{wqkv,wo}`, `layers.{i}.feed_forward.{w1w3,w2}`, `..._layernorm.weight`, `norm.weight`,
+`output.weight`, `tok_embeddings.weight`; inference/sqllm_llama_convert_fuse.py:73-116), so a
+`converted_pytorch_model.bin` written for the reference loads unchanged.
+
+Two execution paths:
+  * `forward(idx, input_pos)`: plain PyTorch ops around `linear_class` modules -- the reference's semantics
+    (model.py:121-130, 151-166, 206-266), used for prefill, for any linear class, and as the on-device statement the
+    fused path is tested against.  RoPE is re-stated here (`rope_tables`): the reference imports
+    `ROPE_INIT_FUNCTIONS["default"]`, which the installed transformers no longer has (model.py:15,353).
+  * `decode_native(tok, pos)`: one bs=1 decode step as 5 HIP launches per layer through the C ABI
+    (RMSNorm -> wqkv | RoPE + KV update + attention | wo + residual | RMSNorm -> w1w3 | SiLU*up -> w2 + residual),
+    an embedding lookup and a fused final-norm + lm_head GEMV: no allocation, no host sync, token / position read
+    from device memory, so the whole step is hipGraph-capturable (generate.py).
+
+Model table: the reference's entries (model.py:53-61) plus Llama-3.2-1B-Instruct and Llama-3.3-70B-Instruct, which
+BASELINE.json's configs name and the reference table lacks.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.nn import functional as F
+
+from . import _lib
+
+
+def find_multiple(n: int, k: int) -> int:
+    if n % k == 0:
+        return n
+    return n + k - (n % k)
+
+
+@dataclass
+class ModelArgs:
+    block_size: int = 2048
+    vocab_size: int = 32000
+    n_layer: int = 32
+    n_head: int = 32
+    dim: int = 4096
+    intermediate_size: int = None
+    n_local_heads: int = -1
+    head_dim: int = 64
+    rope_base: float = 10000
+    norm_eps: float = 1e-5
+    rope_scaling: Optional[dict] = None
+    model_name: Optional[str] = None
+
+    def __post_init__(self):
+        if self.n_local_heads == -1:
+            self.n_local_heads = self.n_head
+        if self.intermediate_size is None:
+            hidden_dim = 4 * self.dim
+            n_hidden = int(2 * hidden_dim / 3)
+            self.intermediate_size = find_multiple(n_hidden, 256)
+        self.head_dim = self.dim // self.n_head
+
+    @classmethod
+    def from_name(cls, name: str):
+        assert name in transformer_configs, f"Unknown model name: {name}, available: {transformer_configs.keys()}"
+        return cls(**transformer_configs[name])
+
+
+transformer_configs = {
+    "meta-llama/Meta-Llama-3-8B": dict(model_name="Meta-Llama-3-8B", block_size=8192, n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336, vocab_size=128256, rope_base=500000),
+    "meta-llama/Meta-Llama-3-8B-Instruct": dict(model_name="Meta-Llama-3-8B-Instruct", block_size=8192, n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336, vocab_size=128256, rope_base=500000),
+    "meta-llama/Meta-Llama-3.1-8B": dict(model_name="Meta-Llama-3.1-8B", block_size=8192, n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336, vocab_size=128256, rope_base=500000),
+    "meta-llama/Meta-Llama-3.1-8B-Instruct": dict(model_name="Meta-Llama-3.1-8B-Instruct", block_size=8192, n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336, vocab_size=128256, rope_base=500000),
+    "meta-llama/Llama-2-7b": dict(model_name="Llama-2-7b", block_size=4096, n_layer=32, n_head=32, n_local_heads=32, dim=4096, intermediate_size=11008, vocab_size=32000, rope_base=10000),
+    "meta-llama/Llama-2-13b": dict(model_name="Llama-2-13b", block_size=4096, n_layer=40, n_head=40, n_local_heads=40, dim=5120, intermediate_size=13824, vocab_size=32000, rope_base=10000),
+    "meta-llama/Llama-2-70b": dict(model_name="Llama-2-70b", block_size=4096, n_layer=80, n_head=64, n_local_heads=8, dim=8192, intermediate_size=28672, vocab_size=32000, rope_base=10000),
+    # not in the reference table: public HF configs
+    "meta-llama/Llama-3.2-1B-Instruct": dict(model_name="Llama-3.2-1B-Instruct", block_size=8192, n_layer=16, n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192, vocab_size=128256, rope_base=500000),
+    "meta-llama/Llama-3.3-70B-Instruct": dict(model_name="Llama-3.3-70B-Instruct", block_size=8192, n_layer=80, n_head=64, n_local_heads=8, dim=8192, intermediate_size=28672, vocab_size=128256, rope_base=500000),
+}
+
+
+def rope_tables(head_dim: int, max_seq: int, base: float, device, dtype=torch.float16):
+    """cos/sin [max_seq, head_dim] as LlamaRotaryEmbedding.forward produces them for rope_type "default"
+    (model.py:343-405): inv_freq = base^-(2i/d) in fp32, freqs = pos * inv_freq, emb = cat(freqs, freqs),
+    cos/sin in fp32, then cast to the activation dtype (attention_scaling == 1)."""
+    inv_freq = 1.0 / (base**(torch.arange(0, head_dim, 2, dtype=torch.int64).to(dtype=torch.float32, device=device) / head_dim))
+    pos = torch.arange(max_seq, device=device, dtype=torch.float32)
+    freqs = torch.outer(pos, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype).contiguous(), emb.sin().to(dtype).contiguous()
+
+
+def rotate_half(x):
+    x1 = x[..., :x.shape[-1] // 2]
+    x2 = x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=1):
+    cos = cos.unsqueeze(unsqueeze_dim)
+    sin = sin.unsqueeze(unsqueeze_dim)
+    q_embed = (q * cos) + (rotate_half(q) * sin)
+    k_embed = (k * cos) + (rotate_half(k) * sin)
+    return q_embed, k_embed
+
+
+class KVCache(nn.Module):
+
+    def __init__(self, max_batch_size, max_seq_length, n_heads, head_dim, dtype=torch.half, device=None):
+        super().__init__()
+        cache_shape = (max_batch_size, n_heads, max_seq_length, head_dim)
+        self.register_buffer('k_cache', torch.zeros(cache_shape, dtype=dtype, device=device))
+        self.register_buffer('v_cache', torch.zeros(cache_shape, dtype=dtype, device=device))
+
+    def update(self, input_pos, k_val, v_val):
+        assert input_pos.shape[0] == k_val.shape[2]
+        k_out = self.k_cache
+        v_out = self.v_cache
+        k_out[:, :, input_pos] = k_val
+        v_out[:, :, input_pos] = v_val
+        return k_out, v_out
+
+
+class RMSNorm(nn.Module):
+
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def _norm(self, x):
+        return x * torch.rsqrt(torch.mean(x * x, dim=-1, keepdim=True) + self.eps)
+
+    def forward(self, x: Tensor) -> Tensor:
+        output = self._norm(x.float()).type_as(x)
+        return output * self.weight
+
+
+class Attention(nn.Module):
+
+    def __init__(self, config: ModelArgs, linear_class=nn.Linear, linear_kwargs=None, fuse_linears=True) -> None:
+        super().__init__()
+        assert config.dim % config.n_head == 0
+        total_head_dim = (config.n_head + 2 * config.n_local_heads) * config.head_dim
+        if fuse_linears:
+            self.wqkv = linear_class(config.dim, total_head_dim, bias=False, **(linear_kwargs or {}))
+        else:
+            self.wq = linear_class(config.dim, config.n_head * config.head_dim, bias=False, **(linear_kwargs or {}))
+            self.wk = linear_class(config.dim, config.n_local_heads * config.head_dim, bias=False, **(linear_kwargs or {}))
+            self.wv = linear_class(config.dim, config.n_local_heads * config.head_dim, bias=False, **(linear_kwargs or {}))
+        self.wo = linear_class(config.dim, config.dim, bias=False, **(linear_kwargs or {}))
+        self.kv_cache = None
+        self.n_head = config.n_head
+        self.head_dim = config.head_dim
+        self.n_local_heads = config.n_local_heads
+        self.dim = config.dim
+        self.config = config
+        self.fuse_linears = fuse_linears
+
+    def forward(self, x: Tensor, mask: Tensor, input_pos: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+        bsz, seqlen, _ = x.shape
+        kv_size = self.n_local_heads * self.head_dim
+        if self.fuse_linears:
+            q, k, v = self.wqkv(x).split([self.dim, kv_size, kv_size], dim=-1)
+        else:
+            q, k, v = self.wq(x), self.wk(x), self.wv(x)
+        q = q.view(bsz, seqlen, self.n_head, self.head_dim)
+        k = k.view(bsz, seqlen, self.n_local_heads, self.head_dim)
+        v = v.view(bsz, seqlen, self.n_local_heads, self.head_dim)
+        q, k, v = map(lambda t: t.transpose(1, 2), (q, k, v))
+        q, k = apply_rotary_pos_emb(q, k, cos[input_pos].unsqueeze(0), sin[input_pos].unsqueeze(0))
+        if self.kv_cache is not None:
+            k, v = self.kv_cache.update(input_pos, k, v)
+        k = k.repeat_interleave(self.n_head // self.n_local_heads, dim=1)
+        v = v.repeat_interleave(self.n_head // self.n_local_heads, dim=1)
+        y = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0)
+        y = y.transpose(1, 2).contiguous().view(bsz, seqlen, -1)
+        return self.wo(y)
+
+
+class FeedForward(nn.Module):
+
+    def __init__(self, config: ModelArgs, linear_class=nn.Linear, linear_kwargs=None, fuse_linears=True) -> None:
+        super().__init__()
+        self.config = config
+        self.fuse_linears = fuse_linears
+        if fuse_linears:
+            self.w1w3 = linear_class(config.dim, config.intermediate_size * 2, bias=False, **(linear_kwargs or {}))
+        else:
+            self.w1 = linear_class(config.dim, config.intermediate_size, bias=False, **(linear_kwargs or {}))
+            self.w3 = linear_class(config.dim, config.intermediate_size, bias=False, **(linear_kwargs or {}))
+        self.w2 = linear_class(config.intermediate_size, config.dim, bias=False, **(linear_kwargs or {}))
+        self.act_fn = F.silu
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.fuse_linears:
+            # .clone(): the quantized linears return their persistent output buffer by reference
+            w1_out, w3_out = self.w1w3(x).split([self.config.intermediate_size, self.config.intermediate_size], dim=-1)
+        else:
+            w1_out = self.w1(x).clone()
+            w3_out = self.w3(x)
+        return self.w2(self.act_fn(w1_out) * w3_out)
+
+
+class TransformerBlock(nn.Module):
+
+    def __init__(self, config: ModelArgs, linear_class=nn.Linear, linear_kwargs=None, fuse_linears=True) -> None:
+        super().__init__()
+        self.attention = Attention(config, linear_class, linear_kwargs, fuse_linears)
+        self.feed_forward = FeedForward(config, linear_class, linear_kwargs, fuse_linears)
+        if "llama" in config.model_name.lower():
+            self.input_layernorm = RMSNorm(config.dim, config.norm_eps)
+            self.post_attention_layernorm = RMSNorm(config.dim, config.norm_eps)
+        else:
+            raise NotImplementedError
+
+    def forward(self, x: Tensor, input_pos: Tensor, mask: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+        h = x + self.attention(self.input_layernorm(x), mask, input_pos, cos, sin)
+        out = self.feed_forward(self.post_attention_layernorm(h))
+        return h + out
+
+
+class Transformer(nn.Module):
+
+    def __init__(self, dtype, config: ModelArgs, linear_class=nn.Linear, linear_kwargs=None, halve_layers=False,
+                 fuse_linears=True) -> None:
+        super().__init__()
+        self.config = config
+        self.dtype = dtype
+        if halve_layers:
+            config.n_layer = config.n_layer // 2
+        self.tok_embeddings = nn.Embedding(config.vocab_size, config.dim)
+        self.layers = nn.ModuleList(
+            TransformerBlock(config, linear_class, linear_kwargs, fuse_linears) for _ in range(config.n_layer))
+        self.norm = RMSNorm(config.dim, eps=config.norm_eps)
+        self.output = nn.Linear(config.dim, config.vocab_size, bias=False)
+        self.max_batch_size = -1
+        self.max_seq_length = -1
+        self.cache_initialized = False
+        self.fuse_linears = fuse_linears
+        self._native = None
+
+    @classmethod
+    def from_name(cls, dtype, name: str, linear_class=nn.Linear, linear_kwargs=None, halve_layers=False,
+                  fuse_linears=True) -> "Transformer":
+        return cls(dtype, ModelArgs.from_name(name), linear_class=linear_class, linear_kwargs=linear_kwargs,
+                   halve_layers=halve_layers, fuse_linears=fuse_linears)
+
+    def setup_caches(self, max_batch_size, max_seq_length):
+        if self.max_seq_length >= max_seq_length and self.max_batch_size >= max_batch_size:
+            return
+        head_dim = self.config.dim // self.config.n_head
+        max_seq_length = find_multiple(max_seq_length, 8)
+        self.max_seq_length = max_seq_length
+        self.max_batch_size = max_batch_size
+        dtype = self.output.weight.dtype
+        device = self.output.weight.device
+        for b in self.layers:
+            b.attention.kv_cache = KVCache(max_batch_size, max_seq_length, self.config.n_local_heads, head_dim, dtype, device)
+        self.causal_mask = torch.tril(torch.ones(self.max_seq_length, self.max_seq_length, dtype=torch.bool, device=device))
+        self.rope_cos, self.rope_sin = rope_tables(head_dim, max_seq_length, self.config.rope_base, device, dtype)
+        self.cache_initialized = True
+        self._native = None
+
+    def forward(self, idx: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:
+        assert self.cache_initialized, "Caches must be initialized first"
+        mask = self.causal_mask[None, None, input_pos]
+        x = self.tok_embeddings(idx)
+        for layer in self.layers:
+            x = layer(x, input_pos, mask, self.rope_cos, self.rope_sin)
+        x = self.norm(x)
+        return self.output(x)
+
+    # ------------------------------------------------------------------------------------------ fused HIP decode step
+    def native_ready(self) -> bool:
+        from .APLinear import APLinear
+        if not (self.fuse_linears and self.cache_initialized and self.output.weight.is_cuda):
+            return False
+        if self.output.weight.dtype != torch.float16 or self.max_batch_size != 1:
+            return False
+        for b in self.layers:
+            for m in (b.attention.wqkv, b.attention.wo, b.feed_forward.w1w3, b.feed_forward.w2):
+                if not isinstance(m, APLinear) or m.bias is not None or m.bitwidth > 4 or m.in_features % 128:
+                    return False
+        return True
+
+    def _native_state(self):
+        if self._native is None:
+            dev = self.output.weight.device
+            c = self.config
+            f16 = dict(dtype=torch.float16, device=dev)
+            self._native = dict(
+                x=torch.zeros(c.dim, **f16), h=torch.zeros(c.dim, **f16), y=torch.zeros(c.dim, **f16),
+                qkv=torch.zeros((c.n_head + 2 * c.n_local_heads) * c.head_dim, **f16),
+                gu=torch.zeros(2 * c.intermediate_size, **f16), logits=torch.zeros(1, 1, c.vocab_size, **f16))
+        return self._native
+
+    def decode_native(self, tok: Tensor, pos: Tensor) -> Tensor:
+        """One bs=1 decode step.  tok, pos: int32 device tensors with one element.  Returns logits fp16 [1,1,V]
+        (a persistent buffer, like the quantized linears' outputs).  Enqueues on the current stream only."""
+        assert tok.dtype == torch.int32 and pos.dtype == torch.int32 and tok.is_cuda and pos.is_cuda
+        L = _lib.lib()
+        st = _lib.current_stream_ptr()
+        c = self.config
+        b = self._native_state()
+        x, h, y, qkv, gu, logits = b["x"], b["h"], b["y"], b["qkv"], b["gu"], b["logits"]
+        ck = _lib.check
+        ck(L.gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), c.dim, c.vocab_size, st),
+           "gq_embed_lookup")
+        scale = 1.0 / math.sqrt(c.head_dim)
+        for blk in self.layers:
+            at, ff = blk.attention, blk.feed_forward
+            ck(L.gq_anyprec_gemv_fused(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
+                                       at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
+                                       c.norm_eps, None, 0, st), "wqkv")
+            ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
+                                at.kv_cache.k_cache.data_ptr(), at.kv_cache.v_cache.data_ptr(), y.data_ptr(), c.n_head,
+                                c.n_local_heads, c.head_dim, self.max_seq_length, scale, st), "attn")
+            ck(L.gq_anyprec_gemv_fused(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
+                                       at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, st), "wo")
+            ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(),
+                                       2 * c.intermediate_size, c.dim, ff.w1w3.bitwidth,
+                                       blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 0, st), "w1w3")
+            ck(L.gq_anyprec_gemv_fused(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,
+                                       c.intermediate_size, ff.w2.bitwidth, None, 0.0, h.data_ptr(), 1 | 2, st), "w2")
+        ck(L.gq_dense_gemv_f16(x.data_ptr(), self.output.weight.data_ptr(), logits.data_ptr(), c.vocab_size, c.dim,
+                               self.norm.weight.data_ptr(), c.norm_eps, st), "lm_head")
+        return logits

@@ -115,6 +115,26 @@ int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *qweight, con
                           uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
                           uint32_t epilogue, void *stream);
 
+/*
+ * The non-quantized pieces of one bs=1 decode step (inference/model.py:121-130,151-166,206-241).  Token id and
+ * position are read from DEVICE memory so a captured hipGraph can be replayed per token.
+ */
+/* x = tok_embeddings[token]                    table fp16 [vocab][dim], out fp16 [dim] */
+int gq_embed_lookup(const int *token, const void *table, void *out, uint32_t dim, uint32_t vocab, void *stream);
+
+/* RoPE(q,k) at *pos, KV-cache update at *pos, softmax(q k^T / sqrt(d)) v over positions 0..*pos.
+ *   qkv fp16 [(n_head + 2 n_kv_head) * head_dim] (fused wqkv output: q | k | v, model.py:211)
+ *   cos/sin fp16 [max_seq][head_dim] (LlamaRotaryEmbedding tables, model.py:379-405)
+ *   k_cache, v_cache fp16 [n_kv_head][max_seq][head_dim] (KVCache, model.py:63-79);  out fp16 [n_head * head_dim] */
+int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                   void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                   float scale, void *stream);
+
+/* out[n] = sum_k rmsnorm?(x)[k] * W[n][k]      dense fp16 GEMV (lm_head `output`, model.py:94,128-129); fp32
+ * accumulation, fp16 output; norm_weight == NULL skips the RMSNorm prologue.  K % 512 == 0. */
+int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint32_t K, const void *norm_weight, float eps,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

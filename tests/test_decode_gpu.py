@@ -1,0 +1,151 @@
+"""GPU: the fused HIP decode step (embedding, RMSNorm->wqkv, RoPE+KV+attention, wo+residual, RMSNorm->w1w3,
+SiLU*up->w2+residual, final norm + lm_head) against the plain-PyTorch statement of the reference model
+(guidedquant_amd.model.Transformer.forward = inference/model.py semantics) on the same synthetic weights.
+The quantized GEMVs are bit-identical in both paths (exact mode); the tolerance covers fp32-vs-fp16 attention
+arithmetic, reduction order of the norms and the dense lm_head accumulation order."""
+import math
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-2  # relative to max|logit|: fp16 pipeline, different (fp32) internal arithmetic in attention / norms
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _exact_mode():
+    from guidedquant_amd import _lib
+    _lib.check(_lib.lib().gq_set_ap_mode(1), "gq_set_ap_mode")
+    yield
+    _lib.lib().gq_set_ap_mode(-1)
+
+
+def _tiny_model(bits, hd=64):
+    from guidedquant_amd.APLinear import APLinear
+    from guidedquant_amd.generate import random_init_
+    from guidedquant_amd.model import ModelArgs, Transformer
+    d = _dev()
+    n_head = 8
+    cfg = ModelArgs(block_size=256, vocab_size=1024, n_layer=2, n_head=n_head, dim=n_head * hd, intermediate_size=1024,
+                    n_local_heads=2, rope_base=500000, model_name="llama-test")
+    m = Transformer(torch.float16, cfg, linear_class=APLinear, linear_kwargs=dict(bitwidth=bits, device=d))
+    m = m.to(device=d, dtype=torch.float16)
+    random_init_(m, seed=bits, lut_std=0.05)
+    g = torch.Generator(device=d)
+    g.manual_seed(1)
+    for b in m.layers:
+        b.input_layernorm.weight.data.copy_((1 + 0.1 * torch.randn(cfg.dim, device=d, generator=g)).half())
+        b.post_attention_layernorm.weight.data.copy_((1 + 0.1 * torch.randn(cfg.dim, device=d, generator=g)).half())
+    m.norm.weight.data.copy_((1 + 0.1 * torch.randn(cfg.dim, device=d, generator=g)).half())
+    return m.eval()
+
+
+@pytest.mark.parametrize("bits,hd", [(2, 64), (3, 64), (4, 128)])
+def test_decode_native_matches_torch_forward(bits, hd):
+    d = _dev()
+    m = _tiny_model(bits, hd)
+    m.setup_caches(1, 32)
+    assert m.native_ready()
+    toks = [5, 17, 900, 3, 3, 512, 44, 1023]
+    ref_logits = []
+    with torch.no_grad():
+        for p, t in enumerate(toks):
+            lg = m(torch.tensor([[t]], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d))
+            ref_logits.append(lg.float().clone())
+    ref_k = [b.attention.kv_cache.k_cache.clone() for b in m.layers]
+    ref_v = [b.attention.kv_cache.v_cache.clone() for b in m.layers]
+    for b in m.layers:
+        b.attention.kv_cache.k_cache.zero_()
+        b.attention.kv_cache.v_cache.zero_()
+    with torch.no_grad():
+        for p, t in enumerate(toks):
+            lg = m.decode_native(torch.tensor([t], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d))
+            torch.cuda.synchronize()
+            a, r = lg.float().view(-1), ref_logits[p].view(-1)
+            scale = r.abs().max().item()
+            assert torch.isfinite(a).all()
+            assert (a - r).abs().max().item() <= TOL * scale, (p, (a - r).abs().max().item(), scale)
+    for i, b in enumerate(m.layers):
+        n = len(toks)
+        dk = (b.attention.kv_cache.k_cache[:, :, :n].float() - ref_k[i][:, :, :n].float()).abs().max().item()
+        dv = (b.attention.kv_cache.v_cache[:, :, :n].float() - ref_v[i][:, :, :n].float()).abs().max().item()
+        sk = ref_k[i][:, :, :n].float().abs().max().item()
+        assert dk <= TOL * sk and dv <= TOL * sk, (i, dk, dv, sk)
+
+
+@pytest.mark.parametrize("hd,H,Hkv", [(64, 8, 2), (128, 4, 4), (128, 32, 8)])
+def test_attention_kernel(hd, H, Hkv):
+    from guidedquant_amd import _lib
+    from guidedquant_amd.model import apply_rotary_pos_emb, rope_tables
+    d = _dev()
+    L = _lib.lib()
+    max_seq = 64
+    g = torch.Generator(device=d)
+    g.manual_seed(hd + H)
+    cos, sin = rope_tables(hd, max_seq, 500000.0, d)
+    kc = torch.zeros(1, Hkv, max_seq, hd, dtype=torch.float16, device=d)
+    vc = torch.zeros_like(kc)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    out = torch.zeros(H * hd, dtype=torch.float16, device=d)
+    for p in range(20):
+        qkv = torch.randn((H + 2 * Hkv) * hd, device=d, generator=g).half()
+        pos = torch.tensor([p], dtype=torch.int32, device=d)
+        _lib.check(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(),
+                                    vc.data_ptr(), out.data_ptr(), H, Hkv, hd, max_seq, 1.0 / math.sqrt(hd),
+                                    _lib.current_stream_ptr()), "attn")
+        q, k, v = qkv.split([H * hd, Hkv * hd, Hkv * hd])
+        q = q.view(1, 1, H, hd).transpose(1, 2)
+        k = k.view(1, 1, Hkv, hd).transpose(1, 2)
+        v = v.view(1, 1, Hkv, hd).transpose(1, 2)
+        q, k = apply_rotary_pos_emb(q, k, cos[p:p + 1].unsqueeze(0), sin[p:p + 1].unsqueeze(0))
+        kc_ref[:, :, p] = k[:, :, 0]
+        vc_ref[:, :, p] = v[:, :, 0]
+        kk = kc_ref[:, :, :p + 1].float().repeat_interleave(H // Hkv, dim=1)
+        vv = vc_ref[:, :, :p + 1].float().repeat_interleave(H // Hkv, dim=1)
+        att = torch.softmax((q.float() @ kk.transpose(-1, -2)) / math.sqrt(hd), dim=-1) @ vv
+        ref = att.transpose(1, 2).reshape(-1)
+        torch.cuda.synchronize()
+        assert torch.equal(kc[:, :, :p + 1], kc_ref[:, :, :p + 1]), "rotated keys must be bit-identical (fp16 RoPE)"
+        assert torch.equal(vc[:, :, :p + 1], vc_ref[:, :, :p + 1])
+        assert (out.float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("N,K,norm", [(1000, 512, False), (128256, 4096, True), (3000, 2048, True)])
+def test_dense_gemv(N, K, norm):
+    from guidedquant_amd import _lib
+    d = _dev()
+    L = _lib.lib()
+    g = torch.Generator(device=d)
+    g.manual_seed(N)
+    W = (torch.randn(N, K, device=d, generator=g) * 0.02).half()
+    x = torch.randn(K, device=d, generator=g).half()
+    nw = (1 + 0.1 * torch.randn(K, device=d, generator=g)).half()
+    out = torch.zeros(N, dtype=torch.float16, device=d)
+    _lib.check(L.gq_dense_gemv_f16(x.data_ptr(), W.data_ptr(), out.data_ptr(), N, K, nw.data_ptr() if norm else None, 1e-5,
+                                   _lib.current_stream_ptr()), "dense")
+    xr = x
+    if norm:
+        xf = x.float()
+        xr = (xf * torch.rsqrt((xf * xf).mean() + 1e-5)).half() * nw
+    ref = W.float() @ xr.float()
+    torch.cuda.synchronize()
+    assert (out.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+
+
+def test_generate_with_graph_matches_eager():
+    from guidedquant_amd.generate import generate
+    d = _dev()
+    m = _tiny_model(2)
+    prompt = torch.tensor([1], dtype=torch.int32, device=d)
+    torch.manual_seed(0)
+    a = generate(m, prompt, 12, use_graph=True, temperature=0.0, top_k=32)
+    torch.manual_seed(0)
+    b = generate(m, prompt, 12, use_graph=False, temperature=0.0, top_k=32)
+    assert a.shape == (1, 13)
+    assert torch.equal(a, b)

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--bits", type=int, default=2)
     ap.add_argument("--mode", choices=["default", "exact", "fast"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-sampling", action="store_true", help="sample with the reference's torch ops instead of the fused HIP sampler")
     args = ap.parse_args()
 
     import torch
@@ -77,7 +78,7 @@ def main():
     cfg = model.config
     model.setup_caches(1, SEQ_NEW_TOKENS + 1)
     assert model.native_ready()
-    graph = DecodeGraph(model, dev, temperature=0.0, top_k=32)
+    graph = DecodeGraph(model, dev, native_sampling=not args.torch_sampling, temperature=0.0, top_k=32)
     bos = torch.tensor([[128000 % cfg.vocab_size]], dtype=torch.int32, device=dev)
     zero = torch.zeros((1, ), dtype=torch.int32, device=dev)
 
@@ -151,7 +152,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "Llama-3.1-8B-Instruct 2-bit Any-Precision (LNQ format), fused QKV/UpGate, bs=1 decode, "
                                    "BOS prompt, 100 new tokens per sequence, top_k=32, temperature=0",
-                       "bits": args.bits, "parallelism": "replicas" if world > 1 else "single", "ap_mode": mode,
+                       "bits": args.bits, "parallelism": "replicas" if world > 1 else "single", "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
                        "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
     float *qs = sc + max_seq;                     // [HD]
     float *kcur = qs + HD;                        // [HD]
     float *vcur = kcur + HD;                      // [HD]
-    float *red = vcur + HD;                       // [4 * HD] partial outputs + 8 scratch
+    float *red = vcur + HD;                       // [4 * HD] (+8 scratch at 4*HD)
+    float *red2 = red + 4 * HD + 16;              // [4 waves * positions-per-wave-instruction][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
     const u32 h = blockIdx.x, group = H / Hkv, g = h / group;
     u32 pos = (u32)pos_ptr[0];
@@ -84,23 +85,44 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
         }
     }
     __syncthreads();
-    // scores: one wave per position, HD/64 dims per lane
-    constexpr int E = HD / 64;
-    float qreg[E];
+    // scores: 16 lanes per position (8 dims = one 16-byte load per lane, a position's row is one coalesced 256-byte
+    // line pair), 4 positions per wave-instruction, U independent iterations in flight per wave.
+    constexpr int LPP = HD / 8;          // lanes per position: 16 (HD=128) or 8 (HD=64)
+    constexpr int PPW = 64 / LPP;        // positions per wave instruction
+    constexpr int U = 4;
+    const u32 sub = l / LPP, ld = l % LPP;
+    float qreg[8];
 #pragma unroll
-    for (int e = 0; e < E; e++) qreg[e] = qs[l * E + e];
-    for (u32 t = w; t <= pos; t += 4) {
-        float p = 0.f;
-        if (t == pos) {
+    for (int e = 0; e < 8; e++) qreg[e] = qs[ld * 8 + e];
+    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += 4 * PPW * U) {
+        uint4 kv[U];
 #pragma unroll
-            for (int e = 0; e < E; e++) p += qreg[e] * kcur[l * E + e];
-        } else {
-            const uint16_t *kt = kcg + (size_t)t * HD + l * E;
-#pragma unroll
-            for (int e = 0; e < E; e++) p += qreg[e] * h2f(kt[e]);
+        for (int u = 0; u < U; u++) {
+            const u32 t = t0 + (u32)u * PPW + sub;
+            kv[u] = t < pos ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
         }
-        p = wave_reduce<false>(p);
-        if (l == 0) sc[t] = p * scale;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 t = t0 + (u32)u * PPW + sub;
+            const u32 ww[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+            float p = 0.f;
+            if (t == pos) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) p += qreg[e] * kcur[ld * 8 + e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    p += qreg[2 * e] * h2f((uint16_t)(ww[e] & 0xFFFF));
+                    p += qreg[2 * e + 1] * h2f((uint16_t)(ww[e] >> 16));
+                }
+            }
+            // sum over the LPP lanes of this position (xor butterflies inside a 16-lane DPP row)
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
+            if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
+            if (ld == 0 && t <= pos) sc[t] = p * scale;
+        }
     }
     __syncthreads();
     float mx = -3.0e38f;
@@ -119,27 +141,148 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
     if (l == 0) red[4 * HD + 4 + w] = sum;
     __syncthreads();
     sum = red[4 * HD + 4] + red[4 * HD + 5] + red[4 * HD + 6] + red[4 * HD + 7];
-    // weighted sum of values: wave w takes positions t = w, w+4, ...
-    float acc[E];
+    // weighted sum of values, same lane layout: lane (sub, ld) accumulates 8 dims over its positions
+    float acc[8];
 #pragma unroll
-    for (int e = 0; e < E; e++) acc[e] = 0.f;
-    for (u32 t = w; t <= pos; t += 4) {
-        const float p = sc[t];
-        if (t == pos) {
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += 4 * PPW * U) {
+        uint4 vv[U];
 #pragma unroll
-            for (int e = 0; e < E; e++) acc[e] += p * vcur[l * E + e];
-        } else {
-            const uint16_t *vt = vcg + (size_t)t * HD + l * E;
+        for (int u = 0; u < U; u++) {
+            const u32 t = t0 + (u32)u * PPW + sub;
+            vv[u] = t < pos ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
-            for (int e = 0; e < E; e++) acc[e] += p * h2f(vt[e]);
+        for (int u = 0; u < U; u++) {
+            const u32 t = t0 + (u32)u * PPW + sub;
+            if (t > pos) continue;
+            const float p = sc[t];
+            if (t == pos) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += p * vcur[ld * 8 + e];
+            } else {
+                const u32 ww[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc[2 * e] += p * h2f((uint16_t)(ww[e] & 0xFFFF));
+                    acc[2 * e + 1] += p * h2f((uint16_t)(ww[e] >> 16));
+                }
+            }
         }
     }
+    // red: [4 waves * PPW position groups][HD]
 #pragma unroll
-    for (int e = 0; e < E; e++) red[w * HD + l * E + e] = acc[e];
+    for (int e = 0; e < 8; e++) red2[(w * PPW + sub) * HD + ld * 8 + e] = acc[e];
     __syncthreads();
     if (tid < HD) {
-        const float o = (red[tid] + red[HD + tid] + red[2 * HD + tid] + red[3 * HD + tid]) / sum;
-        out[(size_t)h * HD + tid] = h2u((h16)o);
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * PPW; i++) o += red2[i * HD + tid];
+        out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sampling
+// Top-k sampling exactly as generate.py:53-73 defines the distribution: logits / max(T, 1e-5), keep the top k,
+// softmax, then draw with the exponential race  argmax_i p_i / q_i, q ~ Exp(1)   (multinomial_sample_one_no_sync).
+// Equivalent form used here: argmax_i (logit_i / T - log q_i) over the k candidates.  The random numbers come from a
+// counter-based hash of (seed, step counter in device memory) -- torch's Philox stream is not reproduced (the
+// reference's sampling is not reproducible across runs either: no fixed generator on the sampled path).
+// Two launches: per-block candidates, then a single-block merge.  Writes the next token AND feeds it back into
+// `tok_io` / increments `pos_io` so a captured graph advances by itself.
+constexpr int SAMP_BLOCKS = 128, SAMP_K = 32;
+
+__device__ __forceinline__ u32 hash32(u32 x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// each block: top-K of its slice via K rounds of block-wide argmax (K small), slice staged in LDS as fp32
+__global__ void __launch_bounds__(256) sample_stage1(const uint16_t *logits, u32 V, float *cand_val, int *cand_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *vals = reinterpret_cast<float *>(smem);
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    const u32 per = (V + SAMP_BLOCKS - 1) / SAMP_BLOCKS;
+    const u32 lo = blockIdx.x * per, hi = min(lo + per, V);
+    const u32 n = hi > lo ? hi - lo : 0u;
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    for (u32 i = tid; i < n; i += 256) vals[i] = h2f(logits[lo + i]);
+    __syncthreads();
+    for (int k = 0; k < SAMP_K; k++) {
+        float bv = -3.0e38f;
+        int bi = -1;
+        for (u32 i = tid; i < n; i += 256)
+            if (vals[i] > bv) { bv = vals[i]; bi = (int)i; }
+        // wave argmax (value, then lowest index)
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            const float ov = __shfl_xor(bv, sh, 64);
+            const int oi = __shfl_xor(bi, sh, 64);
+            if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
+        }
+        if (l == 0) { rv[w] = bv; ri[w] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = rv[0]; int fi = ri[0];
+            for (int j = 1; j < 4; j++) if (rv[j] > fv || (rv[j] == fv && ri[j] >= 0 && (fi < 0 || ri[j] < fi))) { fv = rv[j]; fi = ri[j]; }
+            cand_val[blockIdx.x * SAMP_K + k] = fv;
+            cand_idx[blockIdx.x * SAMP_K + k] = fi >= 0 ? (int)lo + fi : -1;
+            if (fi >= 0) vals[fi] = -3.0e38f;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) sample_stage2(const float *cand_val, const int *cand_idx, int top_k, float temperature,
+                                                     u32 seed, int *counter, int *tok_io, int *pos_io, int *next_tok) {
+    __shared__ float v[SAMP_BLOCKS * SAMP_K];
+    __shared__ int ix[SAMP_BLOCKS * SAMP_K];
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    __shared__ float topv[SAMP_K];
+    __shared__ int topi[SAMP_K];
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    constexpr int NC = SAMP_BLOCKS * SAMP_K;
+    for (int i = tid; i < NC; i += 256) { v[i] = cand_val[i]; ix[i] = cand_idx[i]; }
+    __syncthreads();
+    const int K = top_k < 1 ? 1 : (top_k > SAMP_K ? SAMP_K : top_k);
+    for (int k = 0; k < K; k++) {
+        float bv = -3.0e38f; int bi = -1;
+        for (int i = tid; i < NC; i += 256)
+            if (ix[i] >= 0 && (v[i] > bv || (v[i] == bv && bi >= 0 && ix[i] < ix[bi]))) { bv = v[i]; bi = i; }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            const float ov = __shfl_xor(bv, sh, 64);
+            const int oi = __shfl_xor(bi, sh, 64);
+            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && ix[oi] < ix[bi]))) { bv = ov; bi = oi; }
+        }
+        if (l == 0) { rv[w] = bv; ri[w] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = rv[0]; int fi = ri[0];
+            for (int j = 1; j < 4; j++) if (ri[j] >= 0 && (fi < 0 || rv[j] > fv || (rv[j] == fv && ix[ri[j]] < ix[fi]))) { fv = rv[j]; fi = ri[j]; }
+            topv[k] = fv; topi[k] = fi >= 0 ? ix[fi] : 0;
+            if (fi >= 0) ix[fi] = -1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float T = fmaxf(temperature, 1e-5f);
+        const u32 ctr = (u32)counter[0];
+        float best = -3.0e38f; int bt = topi[0];
+        for (int k = 0; k < K; k++) {
+            // q ~ Exp(1):  -log(u), u in (0,1]
+            const u32 r = hash32(seed ^ hash32(ctr * 0x9E3779B9u + (u32)k + 1u));
+            const float u = ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
+            const float q = -__logf(u);
+            const float score = topv[k] / T - __logf(q);
+            if (score > best) { best = score; bt = topi[k]; }
+        }
+        next_tok[0] = bt;
+        counter[0] = (int)(ctr + 1u);
+        if (tok_io) tok_io[0] = bt;
+        if (pos_io) pos_io[0] = pos_io[0] + 1;
     }
 }
 
@@ -249,7 +392,7 @@ extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_t
     if (!qkv || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (n_kv_head == 0 || n_head % n_kv_head) return gq_fail(GQ_EINVAL, "n_head must be a multiple of n_kv_head.");
     if (head_dim != 64 && head_dim != 128) return gq_fail(GQ_ENOTSUP, "head_dim must be 64 or 128.");
-    const size_t smem = ((size_t)max_seq + 7u * head_dim + 16u) * 4u;
+    const size_t smem = ((size_t)max_seq + 7u * head_dim + 32u + (size_t)(4u * 64u / (head_dim / 8u)) * head_dim) * 4u;
     if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "max_seq too large for the single-pass attention kernel.");
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 128) {
@@ -298,6 +441,19 @@ extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32
     }
     hipLaunchKernelGGL(dense_gemv_kernel<RW>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const uint16_t *)x,
                        (const uint16_t *)W, (uint16_t *)out, N, K, (const uint16_t *)norm_weight, eps, rpb);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
+                              float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, void *stream) {
+    if (!logits || !counter || !work_val || !work_idx || !next_tok) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (top_k > SAMP_K) return gq_fail(GQ_ENOTSUP, "top_k > 32 is not supported by the fused sampler.");
+    const u32 per = (vocab + SAMP_BLOCKS - 1) / SAMP_BLOCKS;
+    if ((size_t)per * 4u > 64u * 1024u) return gq_fail(GQ_ENOTSUP, "vocab too large for the fused sampler.");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sample_stage1, dim3(SAMP_BLOCKS), dim3(256), (size_t)per * 4u, s, (const uint16_t *)logits, vocab, work_val, work_idx);
+    hipLaunchKernelGGL(sample_stage2, dim3(1), dim3(256), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

@@ -62,8 +62,17 @@ class DecodeGraph:
     """One captured hipGraph of `decode_one_token` with static token / position / output tensors
     (the manual-graph path of generate.py:95-113)."""
 
-    def __init__(self, model: Transformer, device, **sampling_kwargs):
+    def __init__(self, model: Transformer, device, native_sampling=False, seed=1234, **sampling_kwargs):
+        """native_sampling: draw the token with the fused HIP sampler (gq_sample_topk: same distribution as `sample`,
+        own counter-based RNG, top_k <= 32) and feed token / position back inside the graph; `next_prob` is then
+        not produced.  Default False = the reference's torch sampling ops, captured in the graph."""
         self.model = model
+        self.native_sampling = bool(native_sampling) and model.native_ready() and (sampling_kwargs.get("top_k") or 0) <= 32 \
+            and sampling_kwargs.get("top_k") is not None
+        self.seed = seed
+        self.rng_counter = torch.zeros((1, ), dtype=torch.int32, device=device)
+        self.work_val = torch.zeros((128 * 32, ), dtype=torch.float32, device=device)
+        self.work_idx = torch.zeros((128 * 32, ), dtype=torch.int32, device=device)
         self.tok = torch.zeros((1, 1), dtype=torch.int32, device=device)
         self.pos = torch.zeros((1, ), dtype=torch.int32, device=device)
         self.next_tok = torch.zeros((1, 1), dtype=torch.int32, device=device)
@@ -83,6 +92,16 @@ class DecodeGraph:
         torch.cuda.synchronize()
 
     def _step(self):
+        if self.native_sampling:
+            from . import _lib
+            logits = self.model.decode_native(self.tok.view(1), self.pos.view(1))
+            kw = self.sampling_kwargs
+            _lib.check(_lib.lib().gq_sample_topk(logits.data_ptr(), self.model.config.vocab_size, int(kw["top_k"]),
+                                                float(kw.get("temperature", 1.0)), int(self.seed), self.rng_counter.data_ptr(),
+                                                self.work_val.data_ptr(), self.work_idx.data_ptr(), self.tok.data_ptr(),
+                                                self.pos.data_ptr(), self.next_tok.data_ptr(), _lib.current_stream_ptr()),
+                       "gq_sample_topk")
+            return
         t, p = decode_one_token(self.model, self.tok, self.pos, **self.sampling_kwargs)
         self.next_tok.copy_(t)
         self.next_prob.copy_(p)
@@ -90,7 +109,7 @@ class DecodeGraph:
     def step(self, advance=True):
         """replay one token step; by default feeds the sampled token back and advances the position on device"""
         self.graph.replay()
-        if advance:
+        if advance and not self.native_sampling:
             self.tok.copy_(self.next_tok)
             self.pos.add_(1)
 

@@ -135,6 +135,13 @@ int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const
 int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint32_t K, const void *norm_weight, float eps,
                       void *stream);
 
+/* Top-k sampling with the reference's distribution (inference/generate.py:53-73: logits / max(T,1e-5), top-k, softmax,
+ * exponential-race draw).  work_val / work_idx: 128*32 floats / ints of scratch; counter: one int of RNG state in
+ * device memory (incremented per call).  If tok_io / pos_io are non-NULL the sampled token is written to *tok_io and
+ * *pos_io is incremented, so a captured decode graph advances by itself.  top_k <= 32. */
+int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
+                   float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

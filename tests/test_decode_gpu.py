@@ -149,3 +149,63 @@ def test_generate_with_graph_matches_eager():
     b = generate(m, prompt, 12, use_graph=False, temperature=0.0, top_k=32)
     assert a.shape == (1, 13)
     assert torch.equal(a, b)
+
+
+def test_fused_sampler_matches_reference_distribution():
+    """temperature -> 0: the exponential race picks the arg-max logit (as the reference's sample() does); at T = 1 the
+    empirical distribution over many draws matches softmax(top-k logits)."""
+    from guidedquant_amd import _lib
+    d = _dev()
+    L = _lib.lib()
+    V = 128256
+    g = torch.Generator(device=d)
+    g.manual_seed(3)
+    logits = (torch.randn(V, device=d, generator=g) * 2).half()
+    counter = torch.zeros(1, dtype=torch.int32, device=d)
+    wv = torch.zeros(128 * 32, dtype=torch.float32, device=d)
+    wi = torch.zeros(128 * 32, dtype=torch.int32, device=d)
+    nt = torch.zeros(1, dtype=torch.int32, device=d)
+    tok = torch.zeros(1, dtype=torch.int32, device=d)
+    pos = torch.zeros(1, dtype=torch.int32, device=d)
+
+    def draw(T, k):
+        _lib.check(L.gq_sample_topk(logits.data_ptr(), V, k, T, 77, counter.data_ptr(), wv.data_ptr(), wi.data_ptr(),
+                                    tok.data_ptr(), pos.data_ptr(), nt.data_ptr(), _lib.current_stream_ptr()), "sample")
+        return int(nt.item())
+
+    assert draw(0.0, 32) == int(logits.float().argmax().item())
+    assert int(tok.item()) == int(nt.item()) and int(pos.item()) == 1 and int(counter.item()) == 1
+    # stage-1/2 top-k equals torch.topk
+    top = torch.topk(logits.float(), 32)
+    draws = [draw(1.0, 32) for _ in range(3000)]
+    assert set(draws) <= set(top.indices.tolist())
+    p = torch.softmax(top.values, dim=0).cpu().numpy()
+    import numpy as np
+    cnt = np.array([draws.count(int(i)) for i in top.indices.tolist()], dtype=np.float64) / len(draws)
+    assert np.abs(cnt - p).max() < 0.04, (cnt, p)
+    assert int(pos.item()) == 3001
+
+
+def test_native_sampling_graph_advances_by_itself():
+    from guidedquant_amd.generate import DecodeGraph
+    d = _dev()
+    m = _tiny_model(2)
+    m.setup_caches(1, 32)
+    g = DecodeGraph(m, d, native_sampling=True, temperature=0.0, top_k=32)
+    assert g.native_sampling
+    g.tok.fill_(1)
+    g.pos.zero_()
+    seq = []
+    for _ in range(10):
+        g.step()
+        seq.append(int(g.next_tok.item()))
+    assert int(g.pos.item()) == 10
+    # greedy (T=0) tokens equal the torch-sampling path
+    g2 = DecodeGraph(m, d, native_sampling=False, temperature=0.0, top_k=32)
+    g2.tok.fill_(1)
+    g2.pos.zero_()
+    seq2 = []
+    for _ in range(10):
+        g2.step()
+        seq2.append(int(g2.next_tok.item()))
+    assert seq == seq2

@@ -197,92 +197,123 @@ __device__ __forceinline__ u32 hash32(u32 x) {
     return x;
 }
 
-// each block: top-K of its slice via K rounds of block-wide argmax (K small), slice staged in LDS as fp32
-__global__ void __launch_bounds__(256) sample_stage1(const uint16_t *logits, u32 V, float *cand_val, int *cand_idx) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *vals = reinterpret_cast<float *>(smem);
-    __shared__ float rv[4];
-    __shared__ int ri[4];
-    const u32 per = (V + SAMP_BLOCKS - 1) / SAMP_BLOCKS;
-    const u32 lo = blockIdx.x * per, hi = min(lo + per, V);
-    const u32 n = hi > lo ? hi - lo : 0u;
-    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
-    for (u32 i = tid; i < n; i += 256) vals[i] = h2f(logits[lo + i]);
-    __syncthreads();
-    for (int k = 0; k < SAMP_K; k++) {
-        float bv = -3.0e38f;
-        int bi = -1;
-        for (u32 i = tid; i < n; i += 256)
-            if (vals[i] > bv) { bv = vals[i]; bi = (int)i; }
-        // wave argmax (value, then lowest index)
+// Selection of the K largest by binary search on a UNIQUE integer key (monotone image of the fp16 value in the high
+// bits, inverted index in the low bits so that ties go to the lowest index): nbits rounds of "count keys >= candidate"
+// (registers + one DPP wave reduction + one LDS combine per round) instead of K rounds of block-wide arg-max.
+__device__ __forceinline__ u32 ordered_key16(uint16_t h) { return (h & 0x8000u) ? (u32)(uint16_t)~h : ((u32)h | 0x8000u); }
+
+template <int NW, int EPT, typename KeyT>
+__device__ __forceinline__ KeyT select_threshold(const KeyT (&key)[EPT], int nbits, int K, int *cnt_lds, u32 w, u32 l) {
+    // returns the K-th largest key (keys are unique, so exactly K keys are >= the result when >= K valid keys exist)
+    KeyT t = 0;
+    for (int bit = nbits - 1; bit >= 0; bit--) {
+        const KeyT cand = t | ((KeyT)1 << bit);
+        int c = 0;
 #pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) {
-            const float ov = __shfl_xor(bv, sh, 64);
-            const int oi = __shfl_xor(bi, sh, 64);
-            if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
-        }
-        if (l == 0) { rv[w] = bv; ri[w] = bi; }
+        for (int e = 0; e < EPT; e++) c += key[e] >= cand ? 1 : 0;
+        float cf = wave_reduce<false>((float)c);  // counts <= 64 * EPT: exact in fp32
+        if (l == 0) cnt_lds[(bit & 1) * NW + w] = (int)cf;
         __syncthreads();
-        if (tid == 0) {
-            float fv = rv[0]; int fi = ri[0];
-            for (int j = 1; j < 4; j++) if (rv[j] > fv || (rv[j] == fv && ri[j] >= 0 && (fi < 0 || ri[j] < fi))) { fv = rv[j]; fi = ri[j]; }
-            cand_val[blockIdx.x * SAMP_K + k] = fv;
-            cand_idx[blockIdx.x * SAMP_K + k] = fi >= 0 ? (int)lo + fi : -1;
-            if (fi >= 0) vals[fi] = -3.0e38f;
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) tot += cnt_lds[(bit & 1) * NW + i];
+        if (tot >= K) t = cand;
+    }
+    return t;
+}
+
+// stage 1: each of the 128 blocks selects the top-32 of its slice (<= 1024 logits, 4 per thread in registers)
+__global__ void __launch_bounds__(256) sample_stage1(const uint16_t *logits, u32 V, float *cand_val, int *cand_idx) {
+    __shared__ int cnt[8];
+    __shared__ int slot;
+    const u32 per = (V + SAMP_BLOCKS - 1) / SAMP_BLOCKS;  // <= 1024
+    const u32 lo = blockIdx.x * per, hi = min(lo + per, V);
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    u32 key[4];
+    uint16_t raw[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const u32 li = tid * 4u + (u32)e, gi = lo + li;
+        raw[e] = gi < hi ? logits[gi] : (uint16_t)0xFC00;  // -inf padding
+        key[e] = gi < hi ? ((ordered_key16(raw[e]) << 10) | (1023u - li)) : 0u;
+    }
+    if (tid == 0) slot = 0;
+    const u32 t = select_threshold<4, 4, u32>(key, 26, SAMP_K, cnt, w, l);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        if (key[e] >= t && key[e] != 0u) {
+            const int sidx = atomicAdd(&slot, 1);
+            if (sidx < SAMP_K) {
+                cand_val[blockIdx.x * SAMP_K + sidx] = h2f(raw[e]);
+                cand_idx[blockIdx.x * SAMP_K + sidx] = (int)(lo + tid * 4u + (u32)e);
+            }
         }
-        __syncthreads();
+    __syncthreads();
+    for (int i = slot + (int)tid; i < SAMP_K; i += 256) {  // slice shorter than K: pad
+        cand_val[blockIdx.x * SAMP_K + i] = -3.0e38f;
+        cand_idx[blockIdx.x * SAMP_K + i] = -1;
     }
 }
 
-__global__ void __launch_bounds__(256) sample_stage2(const float *cand_val, const int *cand_idx, int top_k, float temperature,
-                                                     u32 seed, int *counter, int *tok_io, int *pos_io, int *next_tok) {
-    __shared__ float v[SAMP_BLOCKS * SAMP_K];
-    __shared__ int ix[SAMP_BLOCKS * SAMP_K];
-    __shared__ float rv[4];
-    __shared__ int ri[4];
-    __shared__ float topv[SAMP_K];
-    __shared__ int topi[SAMP_K];
+// stage 2: one block, 4096 candidates (4 per thread), select the global top-k, then the exponential-race draw
+__global__ void __launch_bounds__(1024) sample_stage2(const float *cand_val, const int *cand_idx, int top_k, float temperature,
+                                                      u32 seed, int *counter, int *tok_io, int *pos_io, int *next_tok) {
+    __shared__ int cnt[32];
+    __shared__ float selv[SAMP_K];
+    __shared__ int seli[SAMP_K];
+    __shared__ int slot;
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
-    constexpr int NC = SAMP_BLOCKS * SAMP_K;
-    for (int i = tid; i < NC; i += 256) { v[i] = cand_val[i]; ix[i] = cand_idx[i]; }
-    __syncthreads();
-    const int K = top_k < 1 ? 1 : (top_k > SAMP_K ? SAMP_K : top_k);
-    for (int k = 0; k < K; k++) {
-        float bv = -3.0e38f; int bi = -1;
-        for (int i = tid; i < NC; i += 256)
-            if (ix[i] >= 0 && (v[i] > bv || (v[i] == bv && bi >= 0 && ix[i] < ix[bi]))) { bv = v[i]; bi = i; }
+    unsigned long long key[4];
+    float val[4];
+    int idx[4];
 #pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) {
-            const float ov = __shfl_xor(bv, sh, 64);
-            const int oi = __shfl_xor(bi, sh, 64);
-            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && ix[oi] < ix[bi]))) { bv = ov; bi = oi; }
-        }
-        if (l == 0) { rv[w] = bv; ri[w] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            float fv = rv[0]; int fi = ri[0];
-            for (int j = 1; j < 4; j++) if (ri[j] >= 0 && (fi < 0 || rv[j] > fv || (rv[j] == fv && ix[ri[j]] < ix[fi]))) { fv = rv[j]; fi = ri[j]; }
-            topv[k] = fv; topi[k] = fi >= 0 ? ix[fi] : 0;
-            if (fi >= 0) ix[fi] = -1;
-        }
-        __syncthreads();
+    for (int e = 0; e < 4; e++) {
+        const u32 c = tid * 4u + (u32)e;
+        val[e] = cand_val[c];
+        idx[e] = cand_idx[c];
+        const uint16_t hb = __builtin_bit_cast(uint16_t, (h16)val[e]);  // candidates are fp16 values: exact
+        key[e] = idx[e] >= 0 ? (((unsigned long long)ordered_key16(hb) << 17) | (unsigned long long)(131071u - (u32)idx[e])) : 0ull;
     }
-    if (tid == 0) {
+    if (tid == 0) slot = 0;
+    const int K = top_k < 1 ? 1 : (top_k > SAMP_K ? SAMP_K : top_k);
+    const unsigned long long t = select_threshold<16, 4, unsigned long long>(key, 33, K, cnt, w, l);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        if (key[e] >= t && key[e] != 0ull) {
+            const int sidx = atomicAdd(&slot, 1);
+            if (sidx < SAMP_K) {
+                selv[sidx] = val[e];
+                seli[sidx] = idx[e];
+            }
+        }
+    __syncthreads();
+    if (w == 0) {
+        const int n = min(slot, K);
         const float T = fmaxf(temperature, 1e-5f);
         const u32 ctr = (u32)counter[0];
-        float best = -3.0e38f; int bt = topi[0];
-        for (int k = 0; k < K; k++) {
-            // q ~ Exp(1):  -log(u), u in (0,1]
-            const u32 r = hash32(seed ^ hash32(ctr * 0x9E3779B9u + (u32)k + 1u));
+        float score = -3.0e38f;
+        int tokc = 0x7FFFFFFF;
+        if ((int)l < n) {
+            // q ~ Exp(1) = -log(u), u in (0,1]; the random number is tied to the TOKEN id, not to the slot
+            const u32 r = hash32(seed ^ hash32(ctr * 0x9E3779B9u + (u32)seli[l] + 1u));
             const float u = ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
-            const float q = -__logf(u);
-            const float score = topv[k] / T - __logf(q);
-            if (score > best) { best = score; bt = topi[k]; }
+            score = selv[l] / T - __logf(-__logf(u));
+            tokc = seli[l];
         }
-        next_tok[0] = bt;
-        counter[0] = (int)(ctr + 1u);
-        if (tok_io) tok_io[0] = bt;
-        if (pos_io) pos_io[0] = pos_io[0] + 1;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            const float os = __shfl_xor(score, sh, 64);
+            const int ot = __shfl_xor(tokc, sh, 64);
+            if (os > score || (os == score && ot < tokc)) { score = os; tokc = ot; }
+        }
+        if (l == 0) {
+            next_tok[0] = tokc;
+            counter[0] = (int)(ctr + 1u);
+            if (tok_io) tok_io[0] = tokc;
+            if (pos_io) pos_io[0] = pos_io[0] + 1;
+        }
     }
 }
 
@@ -450,10 +481,10 @@ extern "C" int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, flo
     if (!logits || !counter || !work_val || !work_idx || !next_tok) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (top_k > SAMP_K) return gq_fail(GQ_ENOTSUP, "top_k > 32 is not supported by the fused sampler.");
     const u32 per = (vocab + SAMP_BLOCKS - 1) / SAMP_BLOCKS;
-    if ((size_t)per * 4u > 64u * 1024u) return gq_fail(GQ_ENOTSUP, "vocab too large for the fused sampler.");
+    if (per > 1024u || vocab > 131072u) return gq_fail(GQ_ENOTSUP, "vocab too large for the fused sampler (<= 131072).");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sample_stage1, dim3(SAMP_BLOCKS), dim3(256), (size_t)per * 4u, s, (const uint16_t *)logits, vocab, work_val, work_idx);
-    hipLaunchKernelGGL(sample_stage2, dim3(1), dim3(256), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok);
+    hipLaunchKernelGGL(sample_stage1, dim3(SAMP_BLOCKS), dim3(256), 0, s, (const uint16_t *)logits, vocab, work_val, work_idx);
+    hipLaunchKernelGGL(sample_stage2, dim3(1), dim3(1024), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

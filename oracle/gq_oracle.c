@@ -303,3 +303,91 @@ int gq_oracle_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------- */
+/* LUT-GEMM (BCQ) GEMV  == nqmv_bias  (inference/ap_gemv/lutgemm.cu:24-149),  */
+/* launched by lutgemm_gemv_templated (gemv.cu:140-168).                      */
+/* PARITY UNPINNED: the reference holds no test, producer or CPU statement of */
+/* this op; this is a restatement of the CUDA kernel's arithmetic.            */
+/*                                                                            */
+/* One CUDA block per 32-activation tile kt builds 4 tables of 256 halves:    */
+/* entry lut[y][v] = sum_{i<8} (bit_i(v) ? +x : -x)[32kt + 8y + i], summed    */
+/* left to right in half for v < 64 (bits 6,7 clear), then extended with      */
+/* "+ 2*x[6]" and "+ 2*x[7]" (lutgemm.cu:40-78).  Per output m:               */
+/*   o  = q_bias[g][m] * (lut[0][255]+lut[1][255]+lut[2][255]+lut[3][255])    */
+/*   o += alpha_b * (lut[0][byte0] + lut[1][byte1] + lut[2][byte2] +          */
+/*                   lut[3][byte3]) for every plane b, alpha_b = alpha[g][0][m]*/
+/*        * 2^b (only plane 0 of alpha is read, doubled per plane :143-144)   */
+/* all in half; the tile result is atomically added (half2) to out[m]         */
+/* (:147), in an order the reference does not define.  This restatement adds  */
+/* the tiles in ascending kt (one valid execution of the atomics).            */
+/* ------------------------------------------------------------------------- */
+static void lutgemm_build_tile(const uint16_t *x32, uint16_t lut[4][256]) {
+    for (int y = 0; y < 4; y++) {
+        const uint16_t *xi = x32 + 8 * y;
+        for (int v = 0; v < 64; v++) {
+            uint16_t acc = 0;
+            for (int i = 0; i < 8; i++) {
+                uint16_t sgn = ((v >> i) & 1) ? 0x3C00 : 0xBC00; /* +1 / -1 */
+                uint16_t term = h_mul(sgn, xi[i]);
+                acc = (i == 0) ? term : h_add(acc, term); /* "+ a*x0 + b*x1 ..." left to right; the leading + is unary */
+            }
+            lut[y][v] = acc;
+        }
+        for (int s = 6; s < 8; s++) {
+            uint16_t iv = h_mul(0x4000 /* 2.0 */, xi[s]);
+            for (int v = 1 << s; v < (1 << (s + 1)); v++) lut[y][v] = h_add(lut[y][v - (1 << s)], iv);
+        }
+    }
+}
+
+int gq_oracle_lutgemm_f16(const uint16_t *x, const uint32_t *W, const uint16_t *alpha, const uint16_t *q_bias, uint32_t N,
+                          uint32_t K, int bits, int group_size, uint16_t *out /* accumulated into */) {
+    if (K % 32u || bits < 1 || bits > 8 || group_size <= 0 || K % (uint32_t)group_size) return -1;
+    uint32_t ntiles = K / 32u;
+    for (uint32_t kt = 0; kt < ntiles; kt++) {
+        uint16_t lut[4][256];
+        lutgemm_build_tile(x + 32u * kt, lut);
+        uint32_t g = (kt * 32u) / (uint32_t)group_size;
+        uint16_t all = 0;
+        for (int y = 0; y < 4; y++) all = h_add(all, lut[y][255]);
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < (int64_t)N; m++) {
+            uint16_t o = h_add(0, h_mul(q_bias[(size_t)g * N + m], all));
+            uint16_t a = alpha[(size_t)g * bits * N + m];
+            for (int b = 0; b < bits; b++) {
+                uint32_t w = W[((size_t)kt * bits + b) * N + m];
+                uint16_t t = 0;
+                for (int y = 0; y < 4; y++) t = h_add(t, lut[y][(w >> (8 * y)) & 255u]);
+                o = h_add(o, h_mul(a, t));
+                a = h_mul(a, 0x4000);
+            }
+            out[m] = h_add(out[m], o);
+        }
+    }
+    return 0;
+}
+
+int gq_oracle_lutgemm_f64(const uint16_t *x, const uint32_t *W, const uint16_t *alpha, const uint16_t *q_bias, uint32_t N,
+                          uint32_t K, int bits, int group_size, double *out) {
+    if (K % 32u || bits < 1 || bits > 8 || group_size <= 0 || K % (uint32_t)group_size) return -1;
+    for (uint32_t m = 0; m < N; m++) out[m] = 0.0;
+    for (uint32_t kt = 0; kt < K / 32u; kt++) {
+        uint32_t g = (kt * 32u) / (uint32_t)group_size;
+        double xs = 0;
+        for (int i = 0; i < 32; i++) xs += h2d(x[32u * kt + i]);
+        for (uint32_t m = 0; m < N; m++) {
+            double acc = h2d(q_bias[(size_t)g * N + m]) * xs;
+            double a = h2d(alpha[(size_t)g * bits * N + m]);
+            for (int b = 0; b < bits; b++) {
+                uint32_t w = W[((size_t)kt * bits + b) * N + m];
+                double t = 0;
+                for (int i = 0; i < 32; i++) t += ((w >> i) & 1u) ? h2d(x[32u * kt + i]) : -h2d(x[32u * kt + i]);
+                acc += a * t;
+                a *= 2.0;
+            }
+            out[m] += acc;
+        }
+    }
+    return 0;
+}

@@ -52,9 +52,8 @@ def lib():
         L.gq_oracle_ap_gemv_f16.argtypes = [u16p, u32p, u16p, u32, u32, u32, i32, u16p]
         L.gq_oracle_set_threads.argtypes = [i32]
         L.gq_oracle_max_threads.restype = i32
-        for name in ("gq_oracle_lutgemm_f16", "gq_oracle_qtip_decode", "gq_oracle_qtip_matvec",
-                     "gq_oracle_hadamard"):
-            pass  # bound lazily below when present
+        L.gq_oracle_lutgemm_f16.argtypes = [u16p, u32p, u16p, u16p, u32, u32, i32, i32, u16p]
+        L.gq_oracle_lutgemm_f64.argtypes = [u16p, u32p, u16p, u16p, u32, u32, i32, i32, f64p]
         L._f32p, L._f64p = f32p, f64p
         _lib = L
     return _lib
@@ -210,3 +209,28 @@ def ap_gemv_f16_np(x, qweight, lut, bits):
     for sh in (16, 8, 4, 2, 1):
         p = _f16(p[:, :sh].astype(np.float64) + p[:, sh:2 * sh].astype(np.float64))
     return p[:, 0].reshape(1, N)
+
+
+# --------------------------------------------------------------------------- LUT-GEMM (parity unpinned, see gq_oracle.c)
+def lutgemm_f16(x, qweight, alpha, q_bias, bits, group_size, out=None):
+    """Reference-order fp16 LUT-GEMM GEMV (lutgemm.cu:24-149), tiles added in ascending order.
+    qweight int32[K/32, bits, N], alpha fp16[K/g, bits, N], q_bias fp16[K/g, N]; returns fp16[N] (out += ...)."""
+    q = _c(qweight, np.int32).view(np.uint32)
+    kt, b, N = q.shape
+    assert b == bits
+    K = kt * 32
+    o = np.zeros(N, dtype=np.uint16) if out is None else _u16(out).copy()
+    rc = lib().gq_oracle_lutgemm_f16(_p(_u16(x), ctypes.c_uint16), _p(q, ctypes.c_uint32), _p(_u16(alpha), ctypes.c_uint16),
+                                     _p(_u16(q_bias), ctypes.c_uint16), N, K, bits, group_size, _p(o, ctypes.c_uint16))
+    assert rc == 0, rc
+    return o.view(np.float16)
+
+
+def lutgemm_f64(x, qweight, alpha, q_bias, bits, group_size):
+    q = _c(qweight, np.int32).view(np.uint32)
+    kt, b, N = q.shape
+    o = np.zeros(N, dtype=np.float64)
+    rc = lib().gq_oracle_lutgemm_f64(_p(_u16(x), ctypes.c_uint16), _p(q, ctypes.c_uint32), _p(_u16(alpha), ctypes.c_uint16),
+                                     _p(_u16(q_bias), ctypes.c_uint16), N, kt * 32, bits, group_size, _p(o, ctypes.c_double))
+    assert rc == 0, rc
+    return o

@@ -391,3 +391,109 @@ int gq_oracle_lutgemm_f64(const uint16_t *x, const uint32_t *W, const uint16_t *
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* QTIP packed trellis: decode + matvec.                                      */
+/* Format writer: qtip/lib/codebook/bitshift.py:294-327 (pack_trellis) + the  */
+/* kernel swizzle qtip/lib/algo/finetune.py:291-296; python inverse           */
+/* inference/lib/utils/kernel_decompress.py:5-55 (decode_compressed) -- the   */
+/* golden vectors in tests/golden/qtip_*.npz are its outputs.  Decode rule    */
+/* (HYB code, quantlut_sym, bitshift.py:72-80): state = 16-bit window of the  */
+/* tile's big-endian bit stream at bit offset 2R*p (circular in the tile),    */
+/* idx = state*(state+1) mod 2^32, q = (idx >> 6) & 511, value = tlut[q][e],  */
+/* negated iff e == 0 and bit 15 of idx is set.  Pair p of a 16x16 tile is    */
+/* the mma m16n8k16 A-fragment slot: a = p/16, b = (p/4)%4, cc = (p/2)%2,     */
+/* d = p%2 -> row a + 8d, cols 2b + 8cc + {0,1}.  Tile (tm,tk) lives in the   */
+/* 2x2 tile block (tm/2, tk/2) of 128R bytes; stream byte n = s*R + rr of     */
+/* tile (a4 = tm%2, a3 = tk%2) is source byte ((2s+a3)*2+a4)*R + (R-1-rr).    */
+/* Matvec == kernel_decompress_matvec (qtip/qtip-kernels/src/inference.cu:    */
+/* 168-425): fp16 weights x fp16 x, fp32 accumulation, fp32 output.           */
+/* ------------------------------------------------------------------------- */
+int gq_oracle_qtip_decode(const uint32_t *compressed, const uint16_t *tlut /* [512][2] */, uint32_t M, uint32_t K, int R,
+                          uint16_t *W /* [M][K] */) {
+    if (M % 32u || K % 32u || R < 2 || R > 4) return -1;
+    const uint8_t *src = (const uint8_t *)compressed;
+    uint32_t tile_bytes = 32u * (uint32_t)R;
+#pragma omp parallel for schedule(static)
+    for (int64_t tm = 0; tm < (int64_t)(M / 16u); tm++)
+        for (uint32_t tk = 0; tk < K / 16u; tk++) {
+            uint8_t stream[32 * 4 + 4];
+            size_t base = ((size_t)(tm / 2) * (K / 32u) + tk / 2u) * 128u * (uint32_t)R;
+            uint32_t a4 = (uint32_t)tm % 2u, a3 = tk % 2u;
+            for (uint32_t s = 0; s < 32; s++)
+                for (uint32_t rr = 0; rr < (uint32_t)R; rr++)
+                    stream[s * R + rr] = src[base + ((2u * s + a3) * 2u + a4) * R + ((uint32_t)R - 1u - rr)];
+            for (uint32_t p = 0; p < 128; p++) {
+                uint32_t off = 2u * (uint32_t)R * p; /* bit offset */
+                uint32_t st = 0;
+                for (uint32_t bb = 0; bb < 16; bb++) {
+                    uint32_t bit = (off + bb) % (8u * tile_bytes);
+                    st = (st << 1) | ((stream[bit / 8u] >> (7u - bit % 8u)) & 1u);
+                }
+                uint32_t idx = st * (st + 1u);
+                uint32_t q = (idx >> 6) & 0x1FFu;
+                uint32_t a = p / 16u, b = (p / 4u) % 4u, cc = (p / 2u) % 2u, d = p % 2u;
+                uint32_t r = 16u * (uint32_t)tm + a + 8u * d, c = 16u * tk + 2u * b + 8u * cc;
+                uint16_t v0 = tlut[2u * q], v1 = tlut[2u * q + 1u];
+                if (idx & 0x8000u) v0 ^= 0x8000u;
+                W[(size_t)r * K + c] = v0;
+                W[(size_t)r * K + c + 1u] = v1;
+            }
+        }
+    return 0;
+}
+
+int gq_oracle_qtip_matvec(const uint32_t *compressed, const uint16_t *tlut, const uint16_t *x, uint32_t M, uint32_t K, int R,
+                          double *out) {
+    uint16_t *W = (uint16_t *)malloc((size_t)M * K * 2u);
+    if (!W) return -2;
+    int rc = gq_oracle_qtip_decode(compressed, tlut, M, K, R, W);
+    if (rc) {
+        free(W);
+        return rc;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < (int64_t)M; m++) {
+        double acc = 0;
+        for (uint32_t k = 0; k < K; k++) acc += h2d(W[(size_t)m * K + k]) * h2d(x[k]);
+        out[m] = acc;
+    }
+    free(W);
+    return 0;
+}
+
+/* quantlut_sym expansion of the 9-bit table to all 2^16 states (bitshift.py:72-80) */
+void gq_oracle_quantlut_sym(const uint16_t *tlut /* [512][2] */, uint16_t *expanded /* [65536][2] */) {
+    for (uint32_t st = 0; st < 65536u; st++) {
+        uint32_t idx = st * (st + 1u);
+        uint32_t q = (idx >> 6) & 0x1FFu;
+        uint16_t v0 = tlut[2u * q], v1 = tlut[2u * q + 1u];
+        if (idx & 0x8000u) v0 = d2h(-h2d(v0)); /* "* sflp" with sflp = -1 (sign flip, -0 * x) */
+        expanded[2u * st] = v0;
+        expanded[2u * st + 1u] = v1;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Hadamard:  y = x @ H_n * scale, Sylvester order (n a power of two) ==      */
+/* fast_hadamard_transform.hadamard_transform as used by matmul_hadU_cuda     */
+/* (inference/lib/utils/matmul_had.py:96-119); with a K x K factor matrix     */
+/* hadK for n = K * 2^j: reshape [K, n/K], FWHT over the last dim, then       */
+/* hadK @ (matmul_had.py:109-119).  Pinned against matmul_hadU goldens.       */
+/* ------------------------------------------------------------------------- */
+int gq_oracle_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale) {
+    if (n == 0 || (n & (n - 1u))) return -1;
+    for (uint32_t r = 0; r < rows; r++) {
+        float *yr = y + (size_t)r * n;
+        if (yr != x + (size_t)r * n) memcpy(yr, x + (size_t)r * n, (size_t)n * 4u);
+        for (uint32_t h = 1; h < n; h <<= 1)
+            for (uint32_t i = 0; i < n; i += 2u * h)
+                for (uint32_t j = i; j < i + h; j++) {
+                    float a = yr[j], b = yr[j + h];
+                    yr[j] = a + b;
+                    yr[j + h] = a - b;
+                }
+        for (uint32_t i = 0; i < n; i++) yr[i] *= scale;
+    }
+    return 0;
+}

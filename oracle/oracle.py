@@ -54,6 +54,11 @@ def lib():
         L.gq_oracle_max_threads.restype = i32
         L.gq_oracle_lutgemm_f16.argtypes = [u16p, u32p, u16p, u16p, u32, u32, i32, i32, u16p]
         L.gq_oracle_lutgemm_f64.argtypes = [u16p, u32p, u16p, u16p, u32, u32, i32, i32, f64p]
+        L.gq_oracle_qtip_decode.argtypes = [u32p, u16p, u32, u32, i32, u16p]
+        L.gq_oracle_qtip_matvec.argtypes = [u32p, u16p, u16p, u32, u32, i32, f64p]
+        L.gq_oracle_quantlut_sym.argtypes = [u16p, u16p]
+        L.gq_oracle_quantlut_sym.restype = None
+        L.gq_oracle_hadamard.argtypes = [f32p, f32p, u32, u32, ctypes.c_float]
         L._f32p, L._f64p = f32p, f64p
         _lib = L
     return _lib
@@ -234,3 +239,52 @@ def lutgemm_f64(x, qweight, alpha, q_bias, bits, group_size):
                                      _p(_u16(q_bias), ctypes.c_uint16), N, kt * 32, bits, group_size, _p(o, ctypes.c_double))
     assert rc == 0, rc
     return o
+
+
+# --------------------------------------------------------------------------- QTIP
+def qtip_decode(compressed, tlut, M, K, R):
+    """compressed int32[R*M*K/32], tlut fp16[512,2] -> W fp16[M,K]  (kernel_decompress.py:5-55)"""
+    c = _c(compressed, np.int32).view(np.uint32).reshape(-1)
+    assert c.size * 32 == R * M * K
+    W = np.zeros((M, K), dtype=np.uint16)
+    rc = lib().gq_oracle_qtip_decode(_p(c, ctypes.c_uint32), _p(_u16(tlut).reshape(-1), ctypes.c_uint16), M, K, R,
+                                     _p(W, ctypes.c_uint16))
+    assert rc == 0, rc
+    return W.view(np.float16)
+
+
+def qtip_matvec(compressed, tlut, x, M, K, R):
+    c = _c(compressed, np.int32).view(np.uint32).reshape(-1)
+    out = np.zeros(M, dtype=np.float64)
+    rc = lib().gq_oracle_qtip_matvec(_p(c, ctypes.c_uint32), _p(_u16(tlut).reshape(-1), ctypes.c_uint16),
+                                     _p(_u16(x).reshape(-1), ctypes.c_uint16), M, K, R, _p(out, ctypes.c_double))
+    assert rc == 0, rc
+    return out
+
+
+def quantlut_sym(tlut):
+    out = np.zeros((65536, 2), dtype=np.uint16)
+    lib().gq_oracle_quantlut_sym(_p(_u16(tlut).reshape(-1), ctypes.c_uint16), _p(out, ctypes.c_uint16))
+    return out.view(np.float16)
+
+
+def hadamard(x, scale):
+    x = _c(x, np.float32)
+    rows, n = x.reshape(-1, x.shape[-1]).shape
+    y = np.zeros_like(x)
+    rc = lib().gq_oracle_hadamard(_p(x, ctypes.c_float), _p(y, ctypes.c_float), rows, n, float(scale))
+    assert rc == 0, rc
+    return y
+
+
+def matmul_hadU(x, hadK=None, transpose=False):
+    """x @ H_n / sqrt(n) as matmul_hadU / matmul_hadU_cuda define it (matmul_had.py:70-119); hadK: the K x K factor
+    for n = K * 2^j (None for a power of two)."""
+    x = np.asarray(x, dtype=np.float32)
+    n = x.shape[-1]
+    if hadK is None or hadK.size == 0:
+        return hadamard(x, n**-0.5)
+    Kf = hadK.shape[0]
+    hk = hadK.T if transpose else hadK
+    inp = hadamard(x.reshape(-1, Kf, n // Kf), n**-0.5).reshape(-1, Kf, n // Kf)
+    return (hk.astype(np.float32) @ inp).reshape(x.shape)

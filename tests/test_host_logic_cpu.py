@@ -1,0 +1,112 @@
+"""CPU: host-side logic -- the product's packer against reference goldens, module surfaces, model tree / state-dict
+contract, argument validation that must raise (not crash) without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files
+
+
+@pytest.mark.parametrize("path", golden_files("ap_b"))
+def test_product_packer_matches_reference(path):
+    from guidedquant_amd import pack
+    g = np.load(path)
+    b = int(g["bits"])
+    assert np.array_equal(pack.pack_codes(g["codes"], b), g["qweight"])
+    assert np.array_equal(pack.unpack_codes(g["qweight"], b), g["codes"])
+
+
+def test_random_planes_are_a_valid_packing():
+    from guidedquant_amd import pack
+    q = pack.random_planes(8, 1056, 3, seed=1)
+    codes = pack.unpack_codes(q, 3)
+    assert codes.max() <= 7 and np.array_equal(pack.pack_codes(codes, 3), q)
+
+
+def test_module_surfaces_on_cpu_device():
+    from guidedquant_amd.APLinear import APLinear
+    from guidedquant_amd.AnyPrecisionLinear import AnyPrecisionLinear
+    from guidedquant_amd.LUTGEMMLinear import LUTGEMMLinear
+    a = APLinear(4096, 6144, 2, device="cpu")
+    assert a.qweight.shape == (2, 6144, 128) and a.qweight.dtype == torch.int32
+    assert a.lut.shape == (6144, 4) and a.lut.dtype == torch.float16 and a.output.shape == (1, 1, 6144)
+    assert set(a.state_dict()) == {"qweight", "lut"}
+    l = LUTGEMMLinear(4096, 4096, 3, -1, device="cpu")
+    assert l.group_size == 4096 and l.qweight.shape == (128, 3, 4096) and l.alpha.shape == (1, 3, 4096) and l.q_bias.shape == (1, 4096)
+    h = AnyPrecisionLinear(4096, 1024, [2, 3, 4], bias=False, device="cpu", dtype=torch.float16)
+    assert h.qweight.shape == (4, 1024, 128) and {"lut2", "lut3", "lut4"} <= set(h.state_dict())
+    h.precisions = [2, 3]
+    h.prune_precisions()
+    assert h.qweight.shape == (3, 1024, 128) and "lut4" not in h.state_dict()
+    with pytest.raises(RuntimeError, match="precisions are supported"):
+        h.set_precision(4)
+
+
+def test_validation_raises_on_cpu_tensors():
+    from guidedquant_amd import ap_gemv
+    x = torch.zeros(1, 1, 128, dtype=torch.float16)
+    out = torch.zeros(1, 1, 8, dtype=torch.float16)
+    q = torch.zeros(2, 8, 4, dtype=torch.int32)
+    lut = torch.zeros(8, 4, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="must be on GPU"):
+        ap_gemv.anyprec_gemv(x, out, q, lut, 2)
+    with pytest.raises(RuntimeError, match="Bitwidth must be between 2 and 8"):
+        ap_gemv.anyprec_gemv(x, out, q, lut, 1)
+    with pytest.raises(RuntimeError, match="must be on GPU"):
+        ap_gemv.anyprec_dequant(q, lut, 2)
+
+
+def test_model_tree_and_state_dict_contract():
+    """keys/shapes a `converted_pytorch_model.bin` of the reference carries (sqllm_llama_convert_fuse.py:71-116)"""
+    from guidedquant_amd.APLinear import APLinear
+    from guidedquant_amd.model import Transformer, transformer_configs
+    assert "meta-llama/Llama-3.2-1B-Instruct" in transformer_configs and "meta-llama/Llama-3.3-70B-Instruct" in transformer_configs
+    with torch.device("meta"):
+        m = Transformer.from_name(torch.float16, "meta-llama/Meta-Llama-3.1-8B-Instruct", linear_class=APLinear,
+                                  linear_kwargs=dict(bitwidth=2, device="meta"))
+    sd = m.state_dict()
+    assert sd["layers.0.attention.wqkv.qweight"].shape == (2, 6144, 128)
+    assert sd["layers.0.attention.wqkv.lut"].shape == (6144, 4)
+    assert sd["layers.31.attention.wo.qweight"].shape == (2, 4096, 128)
+    assert sd["layers.5.feed_forward.w1w3.qweight"].shape == (2, 28672, 128)
+    assert sd["layers.5.feed_forward.w2.qweight"].shape == (2, 4096, 448)
+    assert sd["output.weight"].shape == (128256, 4096) and sd["tok_embeddings.weight"].shape == (128256, 4096)
+    assert "layers.0.input_layernorm.weight" in sd and "layers.0.post_attention_layernorm.weight" in sd and "norm.weight" in sd
+    assert len(m.layers) == 32
+    # quantized bytes per token of the 2-bit 8B model: 1.745 GB
+    qbytes = sum(v.numel() * 4 for k, v in sd.items() if k.endswith("qweight"))
+    assert qbytes == 1744830464
+
+
+def test_rope_tables_and_generic_forward_on_cpu():
+    """the torch statement of the model runs on CPU with nn.Linear (config 1 plumbing, no GPU)"""
+    from guidedquant_amd.model import ModelArgs, Transformer, rope_tables
+    cos, sin = rope_tables(64, 16, 500000.0, "cpu", torch.float32)
+    assert cos.shape == (16, 64) and torch.allclose(cos[0], torch.ones(64)) and torch.allclose(sin[0], torch.zeros(64))
+    cfg = ModelArgs(block_size=64, vocab_size=128, n_layer=2, n_head=4, dim=256, intermediate_size=512, n_local_heads=2,
+                    model_name="llama-test")
+    m = Transformer(torch.float32, cfg).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.setup_caches(1, 16)
+    with torch.no_grad():
+        a = m(torch.tensor([[3, 5, 7]]), torch.arange(3))
+        m2 = Transformer(torch.float32, cfg).eval()
+        m2.load_state_dict(sd)
+        m2.setup_caches(1, 16)
+        outs = [m2(torch.tensor([[t]]), torch.tensor([p])) for p, t in enumerate([3, 5, 7])]
+    assert torch.allclose(a[0, 2], outs[2][0, 0], atol=1e-4)  # incremental decode == prefill
+
+
+def test_qtip_host_side():
+    from guidedquant_amd import qtip
+    assert qtip.get_hadK(4096) == (None, 1)
+    with pytest.raises(NotImplementedError, match="not vendored|GQ_HADAMARD_TABLES"):
+        qtip.get_hadK(11008)
+    assert qtip.has_kernel('quantlut_sym', 16, 2, 2, 9, 16, 16) and not qtip.has_kernel('lut', 16, 2, 2, 9, 16, 16)
+    lin = qtip.QuantizedLinear(256, 512, 16, 16, 16, 3, 2, 9, 'quantlut_sym')
+    assert lin.trellis.shape == (32 * 16, 48) and lin.tlut.shape == (512, 2) and lin.SU.shape == (256, ) and lin.SV.dtype == torch.float32
+    assert {"trellis", "tlut", "SU", "SV", "rcp", "tp_rank"} == set(lin.state_dict())
+    f = qtip.qtip_kernels.decompress_matvec_16_9_2_1_4096_1_4096
+    with pytest.raises(RuntimeError, match="float32"):
+        f(torch.zeros(4096, 1, dtype=torch.float16), torch.zeros(1, dtype=torch.int32), torch.zeros(4096, 1, dtype=torch.float16),
+          torch.zeros(1024, dtype=torch.float16))

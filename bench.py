@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--bits", type=int, default=2)
     ap.add_argument("--mode", choices=["default", "exact", "fast"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallel", choices=["replicas", "pp"], default="replicas",
+                    help="N>1: independent replicas (default) or the layer pipeline with point-to-point hops (pp)")
     ap.add_argument("--torch-sampling", action="store_true", help="sample with the reference's torch ops instead of the fused HIP sampler")
     args = ap.parse_args()
 
@@ -95,6 +97,21 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    pp = world > 1 and args.parallel == "pp"
+    if pp:
+        # layer pipeline: stage r owns a contiguous layer range, `world` sequences in flight, hidden state hops r -> r+1
+        # and token ids hop back to stage 0 over RCCL send/recv; a "step" is still one decoded token (summed over
+        # the sequences), so the job decodes args.steps tokens per rank-equivalent = world * args.steps in total
+        from guidedquant_amd.pipeline import PipelinedDecoder, stage_ranges
+        rng = stage_ranges(cfg.n_layer, world, head_cost_layers=6.0)[rank]
+        dec = PipelinedDecoder(model, rank, world, rng, n_seq=world, max_new_tokens=max(args.steps, args.warmup),
+                               temperature=0.0, top_k=32, bos_id=128000 % cfg.vocab_size)
+
+        def run_steps(n):  # noqa: F811
+            dec.pos = [0] * dec.n_seq
+            with torch.no_grad():
+                dec.run(n)
 
     run_steps(args.warmup)
     barrier()
@@ -152,7 +169,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "Llama-3.1-8B-Instruct 2-bit Any-Precision (LNQ format), fused QKV/UpGate, bs=1 decode, "
                                    "BOS prompt, 100 new tokens per sequence, top_k=32, temperature=0",
-                       "bits": args.bits, "parallelism": "replicas" if world > 1 else "single", "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
+                       "bits": args.bits, "parallelism": ("pp%d (layer pipeline, p2p hops, %d sequences in flight)" % (world, world)) if pp else ("replicas" if world > 1 else "single"), "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
                        "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -278,7 +278,7 @@ class Transformer(nn.Module):
         from .APLinear import APLinear
         if not (self.fuse_linears and self.cache_initialized and self.output.weight.is_cuda):
             return False
-        if self.output.weight.dtype != torch.float16 or self.max_batch_size != 1:
+        if self.output.weight.dtype != torch.float16 or self.max_batch_size < 1:
             return False
         for b in self.layers:
             for m in (b.attention.wqkv, b.attention.wo, b.feed_forward.w1w3, b.feed_forward.w2):
@@ -297,27 +297,29 @@ class Transformer(nn.Module):
                 gu=torch.zeros(2 * c.intermediate_size, **f16), logits=torch.zeros(1, 1, c.vocab_size, **f16))
         return self._native
 
-    def decode_native(self, tok: Tensor, pos: Tensor) -> Tensor:
-        """One bs=1 decode step.  tok, pos: int32 device tensors with one element.  Returns logits fp16 [1,1,V]
-        (a persistent buffer, like the quantized linears' outputs).  Enqueues on the current stream only."""
-        assert tok.dtype == torch.int32 and pos.dtype == torch.int32 and tok.is_cuda and pos.is_cuda
+    def native_embed(self, tok: Tensor, x: Tensor):
+        _lib.check(_lib.lib().gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), self.config.dim,
+                                              self.config.vocab_size, _lib.current_stream_ptr()), "gq_embed_lookup")
+
+    def native_layers(self, x: Tensor, pos: Tensor, l0: int, l1: int, slot: int = 0):
+        """layers [l0, l1) of one decode step, in place on the hidden state `x` (fp16 [dim]); `slot` = batch index of
+        the KV caches to use (layer-pipelined decode keeps one sequence per slot)."""
         L = _lib.lib()
         st = _lib.current_stream_ptr()
         c = self.config
         b = self._native_state()
-        x, h, y, qkv, gu, logits = b["x"], b["h"], b["y"], b["qkv"], b["gu"], b["logits"]
+        h, y, qkv, gu = b["h"], b["y"], b["qkv"], b["gu"]
         ck = _lib.check
-        ck(L.gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), c.dim, c.vocab_size, st),
-           "gq_embed_lookup")
         scale = 1.0 / math.sqrt(c.head_dim)
-        for blk in self.layers:
+        kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2  # bytes per batch slot
+        for blk in self.layers[l0:l1]:
             at, ff = blk.attention, blk.feed_forward
             ck(L.gq_anyprec_gemv_fused(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
                                        at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
                                        c.norm_eps, None, 0, st), "wqkv")
             ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
-                                at.kv_cache.k_cache.data_ptr(), at.kv_cache.v_cache.data_ptr(), y.data_ptr(), c.n_head,
-                                c.n_local_heads, c.head_dim, self.max_seq_length, scale, st), "attn")
+                                at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
+                                y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, st), "attn")
             ck(L.gq_anyprec_gemv_fused(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
                                        at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, st), "wo")
             ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(),
@@ -325,6 +327,19 @@ class Transformer(nn.Module):
                                        blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 0, st), "w1w3")
             ck(L.gq_anyprec_gemv_fused(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,
                                        c.intermediate_size, ff.w2.bitwidth, None, 0.0, h.data_ptr(), 1 | 2, st), "w2")
-        ck(L.gq_dense_gemv_f16(x.data_ptr(), self.output.weight.data_ptr(), logits.data_ptr(), c.vocab_size, c.dim,
-                               self.norm.weight.data_ptr(), c.norm_eps, st), "lm_head")
-        return logits
+
+    def native_head(self, x: Tensor) -> Tensor:
+        b = self._native_state()
+        c = self.config
+        _lib.check(_lib.lib().gq_dense_gemv_f16(x.data_ptr(), self.output.weight.data_ptr(), b["logits"].data_ptr(), c.vocab_size,
+                                                c.dim, self.norm.weight.data_ptr(), c.norm_eps, _lib.current_stream_ptr()), "lm_head")
+        return b["logits"]
+
+    def decode_native(self, tok: Tensor, pos: Tensor) -> Tensor:
+        """One bs=1 decode step.  tok, pos: int32 device tensors with one element.  Returns logits fp16 [1,1,V]
+        (a persistent buffer, like the quantized linears' outputs).  Enqueues on the current stream only."""
+        assert tok.dtype == torch.int32 and pos.dtype == torch.int32 and tok.is_cuda and pos.is_cuda
+        x = self._native_state()["x"]
+        self.native_embed(tok, x)
+        self.native_layers(x, pos, 0, len(self.layers))
+        return self.native_head(x)

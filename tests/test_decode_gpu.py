@@ -209,3 +209,21 @@ def test_native_sampling_graph_advances_by_itself():
         g2.step()
         seq2.append(int(g2.next_tok.item()))
     assert seq == seq2
+
+
+def test_pipelined_decoder_native_single_rank():
+    """the layer-pipeline driver on one rank (native fused kernels, 2 sequences with their own KV slots) reproduces the
+    plain greedy decode of the same model"""
+    from guidedquant_amd.generate import generate
+    from guidedquant_amd.pipeline import PipelinedDecoder
+    d = _dev()
+    m = _tiny_model(2)
+    dec = PipelinedDecoder(m, 0, 1, range(0, m.config.n_layer), n_seq=2, max_new_tokens=10, temperature=0.0, top_k=32, bos_id=1)
+    assert dec.native
+    with torch.no_grad():
+        out = dec.run(10)
+    torch.cuda.synchronize()
+    assert out[0].tolist() == out[1].tolist()
+    m2 = _tiny_model(2)
+    ref = generate(m2, torch.tensor([1], dtype=torch.int32, device=d), 10, use_graph=False, temperature=0.0, top_k=32)
+    assert out[0].tolist() == ref[0, 1:].tolist()

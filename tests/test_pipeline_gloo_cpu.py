@@ -1,0 +1,86 @@
+"""CPU, world_size 2, gloo: the layer-pipelined decode (point-to-point hidden-state hops, token feedback to stage 0)
+produces exactly the tokens of the single-process decode."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build_model():
+    from guidedquant_amd.model import ModelArgs, Transformer
+    torch.manual_seed(0)
+    cfg = ModelArgs(block_size=64, vocab_size=97, n_layer=4, n_head=4, dim=128, intermediate_size=256, n_local_heads=2,
+                    model_name="llama-test")
+    return Transformer(torch.float32, cfg).eval()
+
+
+def _worker(rank, world, port, ntok, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from guidedquant_amd.pipeline import PipelinedDecoder, stage_ranges
+        torch.set_num_threads(1)
+        model = _build_model()
+        rng = stage_ranges(model.config.n_layer, world)[rank]
+        dec = PipelinedDecoder(model, rank, world, rng, n_seq=world, max_new_tokens=ntok, temperature=0.0, top_k=8, bos_id=3,
+                               native=False)
+        with torch.no_grad():
+            out = dec.run(ntok)
+        if rank == 0:
+            q.put(out.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stage_ranges_cover_and_balance():
+    from guidedquant_amd.pipeline import stage_ranges
+    for n, w in [(32, 1), (32, 2), (32, 8), (80, 8), (16, 4), (4, 2)]:
+        rs = stage_ranges(n, w)
+        assert len(rs) == w and rs[0].start == 0 and rs[-1].stop == n
+        assert all(rs[i].stop == rs[i + 1].start for i in range(w - 1)) and all(len(r) >= 1 for r in rs)
+    rs = stage_ranges(32, 8, head_cost_layers=8.0)
+    assert len(rs[-1]) < len(rs[0])  # the head's cost is charged to the last stage
+
+
+@pytest.mark.timeout(300)
+def test_pipelined_decode_equals_single_process():
+    from guidedquant_amd.pipeline import PipelinedDecoder
+    ntok = 6
+    model = _build_model()
+    dec = PipelinedDecoder(model, 0, 1, range(0, model.config.n_layer), n_seq=2, max_new_tokens=ntok, temperature=0.0, top_k=8,
+                           bos_id=3, native=False)
+    with torch.no_grad():
+        want = dec.run(ntok).tolist()
+    assert want[0] == want[1]  # both sequences start from the same BOS and decode greedily
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ntok, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        got = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert got == want

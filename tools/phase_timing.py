@@ -13,21 +13,22 @@ for name in sys.argv[2:] or list(SH):
     qs = [torch.randint(-2**31, 2**31 - 1, (bits, N, K // 32), dtype=torch.int32, device=d) for _ in range(max(2, (600 << 20) // (bits * N * K // 8)))]
     lut = (torch.randn(N, 1 << bits, device=d) * 0.02).half()
     x = torch.randn(1, 1, K, device=d).half(); out = torch.empty(1, 1, N, dtype=torch.float16, device=d)
-    dbg = torch.zeros(64 + 128, dtype=torch.int64, device=d)
+    dbg = torch.zeros(128 + 256, dtype=torch.int64, device=d)
     for i, q in enumerate(qs):
         if i == len(qs) - 1:
             L.gq_debug_set_timing_buffer(dbg.data_ptr())
         L.gq_anyprec_gemv(x.data_ptr(), out.data_ptr(), q.data_ptr(), lut.data_ptr(), 1, N, K, bits, 0, None)
     torch.cuda.synchronize(); L.gq_debug_set_timing_buffer(None)
     raw = dbg.cpu().numpy()
-    t = raw[:64].reshape(8, 8)[:, [0, 6, 7, 1, 2, 3, 4, 5]]
-    t2 = raw[64:].reshape(8, 2, 8)[:, :, :5]
+    t = raw[:128].reshape(16, 8)[:, [0, 6, 7, 1, 2, 3, 4, 5]]
+    t2 = raw[128:].reshape(16, 2, 8)[:, :, :5]
     t0 = t[t > 0].min()
-    print(name, "cycles: [start, x landed (pro waves), phase A done, phase B done, after barrier B, main loop done, after barrier C, end]")
-    for w in range(8):
-        print("  wave", w, [int(v - t0) if v > 0 else None for v in t[w]])
+    print(name, "cycles: [start, raw x copied (before barrier 1), max/sum done (before barrier 2), image built, after barrier 3, main loop done, after barrier 4, end]")
+    for w in range(16):
+        if t[w].max() > 0:
+            print("  wave", w, [int(v - t0) if v > 0 else None for v in t[w]])
     print("  main-loop steps (wave, step): [step start, planes landed, PW built, MFMAs issued, item epilogue done]")
-    for w in range(8):
+    for w in range(16):
         for st in range(2):
             if t2[w, st].max() > 0:
                 print("   wave", w, "step", st, [(int(v) - int(t0)) if v > 0 else None for v in t2[w, st]])

@@ -110,3 +110,41 @@ def test_qtip_host_side():
     with pytest.raises(RuntimeError, match="float32"):
         f(torch.zeros(4096, 1, dtype=torch.float16), torch.zeros(1, dtype=torch.int32), torch.zeros(4096, 1, dtype=torch.float16),
           torch.zeros(1024, dtype=torch.float16))
+
+
+def test_anyprec_converter_fuses_like_the_reference():
+    """HF-layout multi-precision checkpoint -> gpt-fast fused layout (sqllm_llama_convert_fuse.py:35-118): key renames,
+    lut{b} -> lut, plane slicing, q/k/v and gate/up concatenation; the result loads strictly into the model."""
+    from guidedquant_amd.APLinear import APLinear
+    from guidedquant_amd.convert import convert_anyprec_fuse
+    from guidedquant_amd.model import ModelArgs, Transformer
+    cfg = ModelArgs(block_size=64, vocab_size=128, n_layer=2, n_head=4, dim=256, intermediate_size=512, n_local_heads=2,
+                    model_name="llama-test")
+    hd, kv, D, I = 64, 128, 256, 512
+    g = torch.Generator().manual_seed(0)
+    hf = {"model.embed_tokens.weight": torch.randn(128, D, generator=g).bfloat16(), "model.norm.weight": torch.ones(D).bfloat16(),
+          "lm_head.weight": torch.randn(128, D, generator=g).bfloat16()}
+    shapes = {"self_attn.q_proj": (D, D), "self_attn.k_proj": (kv, D), "self_attn.v_proj": (kv, D), "self_attn.o_proj": (D, D),
+              "mlp.gate_proj": (I, D), "mlp.up_proj": (I, D), "mlp.down_proj": (D, I)}
+    for i in range(2):
+        hf[f"model.layers.{i}.input_layernorm.weight"] = torch.ones(D).bfloat16()
+        hf[f"model.layers.{i}.post_attention_layernorm.weight"] = torch.ones(D).bfloat16()
+        for name, (n, k) in shapes.items():
+            hf[f"model.layers.{i}.{name}.qweight"] = torch.randint(-2**31, 2**31 - 1, (4, n, k // 32), dtype=torch.int32, generator=g)
+            for b in (2, 3, 4):
+                hf[f"model.layers.{i}.{name}.lut{b}"] = torch.randn(n, 2**b, generator=g).half()
+    out = convert_anyprec_fuse(hf, 3)
+    assert out["layers.1.attention.wqkv.qweight"].shape == (3, D + 2 * kv, D // 32)
+    assert torch.equal(out["layers.1.attention.wqkv.qweight"][:, D:D + kv], hf["model.layers.1.self_attn.k_proj.qweight"][:3])
+    assert torch.equal(out["layers.0.feed_forward.w1w3.lut"][I:], hf["model.layers.0.mlp.up_proj.lut3"])
+    assert out["layers.0.attention.wo.lut"].shape == (D, 8) and out["tok_embeddings.weight"].dtype == torch.float16
+    assert not any("lut2" in k or "lut4" in k or "q_proj" in k or "gate_proj" in k for k in out)
+    m = Transformer(torch.float16, cfg, linear_class=APLinear, linear_kwargs=dict(bitwidth=3, device="cpu"))
+    m.load_state_dict(out, strict=True)
+
+
+def test_qtip_converter_renames():
+    from guidedquant_amd.convert import convert_qtip_no_fuse
+    out = convert_qtip_no_fuse({"model.layers.0.self_attn.q_proj.trellis": torch.zeros(1), "model.layers.0.mlp.down_proj.SU": torch.zeros(1),
+                                "lm_head.weight": torch.zeros(1), "model.embed_tokens.weight": torch.zeros(1)})
+    assert set(out) == {"layers.0.attention.wq.trellis", "layers.0.feed_forward.w2.SU", "output.weight", "tok_embeddings.weight"}

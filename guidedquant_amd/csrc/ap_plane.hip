@@ -1,12 +1,15 @@
 // ap_plane.hip -- "fast mode" Any-Precision GEMV for gfx950: binary bit-plane GEMVs on the matrix cores.
 //
 // See plane_core.h for the algorithm.  What runs where:
-//   HBM    : the stored bit-planes, 128 contiguous bytes per row per plane per 1024-weight chunk
-//            (lane (row r, k-block kb) loads 32 B; 4 lanes of a row cover one cache line), register ring of D chunks.
+//   HBM    : the stored bit-planes, whole 128-byte lines (one row x one plane x one 1024-weight chunk), fetched by
+//            direct-to-LDS loads (buffer_load_dwordx4 ... lds) that every wave issues for ALL of its steps (up to
+//            its LDS ring depth) in its first instructions: the block's share of the matrix is in flight before
+//            the activation prologue starts, and the matrix cores chase the stream.
 //   VALU   : one v_and_b32 per 4 weights per plane-subset (bits -> bf8 {0, 2^e}); ANDs of planes for the subsets.
 //   MFMA   : v_mfma_scale_f32_16x16x128_f8f6f4 (A = bf8 bit patterns, scale cancels 2^e; B = 4 bf8 pieces of x in
 //            columns 0..3, per-32-element block scale), fp32 accumulate: 8 MFMAs per (chunk, plane-subset).
-//   LDS    : the B image (activation pieces, 4*K bytes) built once per block, partial sums of K-split items.
+//   LDS    : per-wave rings of A tiles (plane_core.h atile_unit swizzle), the B image (activation pieces, 4*K bytes)
+//            built once per block, partial sums of K-split items.
 // Epilogue : y = coef[0] * sum(x) + sum_S coef[S] * T[S]  (Moebius coefficients of the row's LUT), fp32 -> fp16.
 //
 // This path is NOT bit-identical to the reference's fp16-accumulated kernel (anyprec.cu:372-542): it is closer
@@ -37,6 +40,7 @@ struct PlaneArgs {
     u32 RGB;     // row groups (16 rows) per block
     u32 log2CS;  // a row group's chunks are split over 2^log2CS wave items
     u32 cpi;     // chunks per item
+    u32 S;       // LDS ring slots (steps) per wave
     float eps;
     unsigned long long *dbg;  // optional: per-wave phase timestamps of block 0 (tools/phase_timing.py)
 };
@@ -67,44 +71,69 @@ __device__ __forceinline__ float wave_reduce(float v) {
     return v;
 }
 
-template <int PRO>
-__device__ __forceinline__ float load_x(const uint16_t *x, const uint16_t *normw, u32 K, u32 e, float nscale) {
-    if constexpr (PRO == PRO_RMSNORM) {
-        // (x.float() * rsqrt(mean(x^2)+eps)).half() * w   -- inference/model.py:281-292, both fp16 roundings kept
-        _Float16 a = (_Float16)(h2f(x[e]) * nscale);
-        _Float16 r = a * __builtin_bit_cast(_Float16, normw[e]);
-        return (float)r;
-    } else if constexpr (PRO == PRO_SILUMUL) {
-        // F.silu(gate) * up on fp16 tensors -- inference/model.py:266
-        float g = h2f(x[e]);
-        _Float16 s = (_Float16)(g / (1.0f + __expf(-g)));
-        _Float16 r = s * __builtin_bit_cast(_Float16, x[K + e]);
-        return (float)r;
-    } else {
-        return h2f(x[e]);
+
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2v u2h2(u32 u) { return __builtin_bit_cast(h2v, u); }
+__device__ __forceinline__ u32 h22u(h2v h) { return __builtin_bit_cast(u32, h); }
+
+// --- hand-scheduled vector memory.  The compiler's waitcnt pass treats an LDS-DMA load as "may alias every later
+// LDS access" and drains vmcnt before the first ds_read / barrier, which would serialise the prologue behind the
+// whole plane stream.  So the plane loads and the activation loads that must overtake them are issued from inline
+// asm (invisible to that pass) and waited for with explicit s_waitcnt vmcnt(n) (vector memory returns in order).
+__device__ __forceinline__ void dma16(u32x4 rsrc, u32 lds_base, u32 voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(lds_base), "v"(voff), "s"(rsrc)
+                 : "memory");  // m0 is not otherwise used in this kernel (no compiler-generated LDS-DMA / movrel)
+}
+__device__ __forceinline__ u32 bload32(u32x4 rsrc, u32 voff) {
+    u32 r;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most n * LPS vector-memory instructions of this wave are outstanding (n uniform, 0..4)
+template <int LPS>
+__device__ __forceinline__ void wait_vm_steps(u32 n) {
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<LPS>(); break;
+        case 2: wait_vm<2 * LPS>(); break;
+        case 3: wait_vm<3 * LPS>(); break;
+        default: wait_vm<4 * LPS>(); break;
     }
 }
+// data dependence of asm-loaded registers on the preceding s_waitcnt (volatile asm statements keep their order)
+__device__ __forceinline__ void tie4(u32 (&r)[4]) { asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])); }
 
-template <int BITS, int D, int PRO>
+__device__ __forceinline__ u32x4 make_rsrc(const void *p, u32 bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return (u32x4){(u32)a, (u32)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};  // raw buffer: stride 0, num_records = bytes
+}
+
+template <int BITS, int PRO>
 __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneArgs a) {
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u;
+    constexpr u32 NI = 2048u / T;   // prologue passes: K <= 16384 -> at most 2048 (chunk, virtual lane, weight pair) items
+    constexpr u32 LPS = 2u * BITS;  // direct-to-LDS loads per step
+    constexpr u32 SLOT = 2048u * BITS;
+    constexpr u32 OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     Geom G;
     G.init(a.K);
-    const u32 T = blockDim.x, tid = threadIdx.x;
-    const u32 W = T >> 6;
+    const u32 tid = threadIdx.x;
     const u32 w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 l = tid & 63u;
-    unsigned char *bimg = smem;                            // [chunk][s][kb][piece][32]
-    unsigned char *bscale = bimg + G.nchunks * 4096u;      // u32 [chunk][blk]: E8M0 scale of the hardware scale block (64 B per chunk reserved)
-    unsigned char *zero32 = bscale + G.nchunks * 64u;      // 32 zero bytes
-    uint16_t *xs = reinterpret_cast<uint16_t *>(zero32 + 32 + 64 * 4);  // fp16 copy of the (transformed) activations
-    uint16_t *aux = xs + G.K;  // RMSNorm weight / up vector (prologue modes only)
-    float *red = reinterpret_cast<float *>(zero32 + 32);   // 64 floats
-    float *part = reinterpret_cast<float *>(xs + (PRO == PRO_NONE ? G.K : 2u * G.K));  // [RGB << log2CS][NP1][4 piece columns][16 rows]
-
-    const u32 CS = 1u << a.log2CS, cpi = a.cpi;
+    const u32 CS = 1u << a.log2CS, cpi = a.cpi, S = a.S;
     const u32 nIt = a.RGB * CS;  // wave items of this block
+    // LDS: [A rings: W * S slots][B image: nchunks * 4096][zero32][red: 64 floats][part: nIt * NP1 * 16 floats]
+    unsigned char *ring = smem + (size_t)w * S * SLOT;
+    unsigned char *bimg = smem + (size_t)W * S * SLOT;
+    unsigned char *zero32 = bimg + G.nchunks * 4096u;
+    float *red = reinterpret_cast<float *>(zero32 + 64);
+    float *part = red + 64;
     const u32 rg0 = blockIdx.x * a.RGB;
     const u32 m = blockIdx.y;
     const u32 r = l & 15u, kb = l >> 4;
@@ -113,256 +142,255 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     };
     stamp(0);
 
-    // ---------------------------------------------------------------- plane ring (register ring of D chunk steps)
-    constexpr u32 OOB = 0x80000000u;
-    const u32 plane_bytes = a.N * G.wpr * 4u;
-    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw, 0, (int)(plane_bytes * (u32)BITS), 0x00020000);
-    u32x4 P[D][BITS][2];
-    const u32 wi = (w + W - (W > 1 ? W / 2u : 0u)) % W;  // item slot of this wave: upper-half (loader-first) waves come first
-    u32 iq_item = wi, iq_c = 0;
-    auto issue = [&](int d) {
-        const u32 chunk = (iq_item & (CS - 1u)) * cpi + iq_c;
-        const u32 row = (rg0 + (iq_item >> a.log2CS)) * 16u + r;
-        const bool ok = iq_item < nIt && chunk < G.nchunks && row < a.N && 8u * kb < G.tpw(chunk);
-        const u32 off = (row * G.wpr + 32u * chunk + 8u * kb) * 4u;
+    // ---------------------------------------------------------------- 1. activation loads (must land first)
+    // item = (chunk, virtual lane t, weight pair jp): the two adjacent weights j = 2jp, 2jp+1 of the 4 bytes c of t
+    const u32x4 rsx = make_rsrc(a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
+    const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
+    u32 xr[NI][4], ar[NI][4];
 #pragma unroll
-        for (int p = 0; p < BITS; p++) {
-            P[d][p][0] = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? off + (u32)p * plane_bytes : OOB, 0, 2);
-            P[d][p][1] = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? off + (u32)p * plane_bytes + 16u : OOB, 0, 2);
+    for (u32 n = 0; n < NI; n++) {
+        const u32 it = tid + n * T;
+        const u32 t = it & 31u, jp = (it >> 5) & 3u, chunk = it >> 7;
+        const u32 tp = G.tpw(chunk);
+        const bool ok = chunk < G.nchunks && t < tp;
+#pragma unroll
+        for (u32 c = 0; c < 4; c++) {
+            const u32 e = 1024u * chunk + 8u * tp * c + 8u * t + 2u * jp;
+            xr[n][c] = bload32(rsx, ok ? 2u * e : OOB);
+            if constexpr (PRO == PRO_RMSNORM) ar[n][c] = bload32(rsa, ok ? 2u * e : OOB);
+            if constexpr (PRO == PRO_SILUMUL) ar[n][c] = bload32(rsx, ok ? 2u * (G.K + e) : OOB);
+        }
+    }
+
+    // ---------------------------------------------------------------- 2. the whole plane stream of this wave
+    // steps of wave w: item i = w + n*W (n = 0, 1, ..), chunks c = 0..cpi-1 of the item; step q uses ring slot q % S
+    const u32 items_w = nIt > w ? (nIt - w + W - 1u) / W : 0u;
+    const u32 my_steps = items_w * cpi;
+    const u32 plane_bytes = a.N * G.wpr * 4u;
+    const u32x4 rq = make_rsrc(a.qw, plane_bytes * (u32)BITS);
+    const u32 ring_lds = (u32)(uintptr_t)ring;
+    u32 iq_item = w, iq_c = 0, iq_slot = 0;
+    auto issue = [&]() {
+        const u32 chunk = (iq_item & (CS - 1u)) * cpi + iq_c;
+        const u32 rgi = rg0 + (iq_item >> a.log2CS);
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+            u32 rr, seg;
+            atile_src(h, l, rr, seg);
+            const u32 row = rgi * 16u + rr;
+            const bool ok = chunk < G.nchunks && row < a.N && 4u * seg < G.tpw(chunk);
+            const u32 off = (row * G.wpr + 32u * chunk + 4u * seg) * 4u;
+#pragma unroll
+            for (u32 p = 0; p < (u32)BITS; p++)
+                dma16(rq, ring_lds + iq_slot * SLOT + (p * 2u + h) * 1024u, ok ? off + p * plane_bytes : OOB);
         }
         if (++iq_c == cpi) {
             iq_c = 0;
             iq_item += W;
         }
+        if (++iq_slot == S) iq_slot = 0;
     };
-
-    // Vector-memory results return in order, so a wave that issues its plane loads first cannot see its
-    // activation loads until all of those landed.  Split roles: the upper half of the waves starts streaming
-    // planes at t = 0 and goes straight to the barrier; the lower half builds the activation image, then streams.
-    const u32 WP = W > 1 ? W / 2u : 1u;  // prologue waves
-    const u32 TP = WP * 64u;
-    const bool pro_wave = w < WP;
-    if (!pro_wave) {
+    // The activation loads must be back before the plane stream starts: once every CU has its share of the matrix
+    // in flight, the L2 / fabric queues are thousands of lines deep and a late L2 hit waits behind them (measured:
+    // activations land after 4000-9000 cycles when the plane loads are issued first or right behind them, ~900 alone).
+    wait_vm<0>();
 #pragma unroll
-        for (int d = 0; d < D; d++) issue(d);
+    for (u32 n = 0; n < NI; n++) {
+        tie4(xr[n]);
+        if constexpr (PRO != PRO_NONE) tie4(ar[n]);
     }
-
-    // ---------------------------------------------------------------- prologue: activation pieces -> LDS image
-    // Phase A (prologue waves): x -> (optional RMSNorm / SiLU*up, reference rounding points) -> fp16 copy in LDS,
-    //          plus max|x| and sum(x).   Phase B (all waves): split into 4 exact bf8 pieces of x * 2^(15-e_max)
-    //          and scatter them into the MFMA B image.
-    const uint16_t *x = a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K);
-    // step 0 (prologue waves): raw copy global -> LDS (the only vector-memory traffic of the prologue)
-    if (pro_wave) {
-        for (u32 g = tid; g < G.K / 8u; g += TP) {
-            *reinterpret_cast<uint4 *>(xs + 8u * g) = *reinterpret_cast<const uint4 *>(x + 8u * g);
-            if constexpr (PRO == PRO_RMSNORM) *reinterpret_cast<uint4 *>(aux + 8u * g) = *reinterpret_cast<const uint4 *>(a.normw + 8u * g);
-            if constexpr (PRO == PRO_SILUMUL) *reinterpret_cast<uint4 *>(aux + 8u * g) = *reinterpret_cast<const uint4 *>(x + G.K + 8u * g);
-        }
-        if (tid < 8) reinterpret_cast<u32 *>(zero32)[tid] = 0u;
-    }
+    const u32 init_steps = my_steps < S ? my_steps : S;
+    for (u32 q = 0; q < init_steps; q++) issue();
+    if (tid < 8) reinterpret_cast<u32 *>(zero32)[tid] = 0u;
     stamp(6);
-    __syncthreads();
-    // step 1 (all waves): optional RMSNorm / SiLU*up with the reference's fp16 rounding points, max|x|, sum(x)
-    float nscale = 0.f;
-    if constexpr (PRO == PRO_RMSNORM) {
-        float ss = 0.f;
-        for (u32 g = tid; g < G.K / 8u; g += T) {
-            const uint4 v4 = *reinterpret_cast<const uint4 *>(xs + 8u * g);
-            const u32 ww[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float p = h2f(ww[k] & 0xFFFF), q = h2f(ww[k] >> 16);
-                ss += p * p;
-                ss += q * q;
-            }
-        }
-        ss = wave_reduce<false>(ss);
-        if (l == 63) red[32 + w] = ss;
-        __syncthreads();
-        float tot = 0.f;
-        for (u32 i = 0; i < W; i++) tot += red[32 + i];
-        nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
-    }
+
+    // ---------------------------------------------------------------- 3. statistics -> one barrier
+    // RMSNorm: sum x^2 and max |x * w| (bounds the normalised maximum); otherwise max |x'| of the transformed vector
+    float nscale = 0.f, xmax = 0.f;
     {
-        float xsum = 0.f, mx = 0.f;
-        for (u32 g = tid; g < G.K / 8u; g += T) {
-            const uint4 v4 = *reinterpret_cast<const uint4 *>(xs + 8u * g);
-            u32 ww[4] = {v4.x, v4.y, v4.z, v4.w};
-            if constexpr (PRO != PRO_NONE) {
-                const uint4 a4 = *reinterpret_cast<const uint4 *>(aux + 8u * g);
-                const u32 aw[4] = {a4.x, a4.y, a4.z, a4.w};
+        float ss = 0.f, mx = 0.f;
+        u32 mxi = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    _Float16 h[2];
+        for (u32 n = 0; n < NI; n++)
 #pragma unroll
-                    for (int hh = 0; hh < 2; hh++) {
-                        const uint16_t hx = (uint16_t)(ww[k] >> (16 * hh)), ha = (uint16_t)(aw[k] >> (16 * hh));
-                        if constexpr (PRO == PRO_RMSNORM) {
-                            // (x.float() * rsqrt(mean(x^2)+eps)).half() * w  -- inference/model.py:281-292
-                            h[hh] = (_Float16)(h2f(hx) * nscale) * __builtin_bit_cast(_Float16, ha);
-                        } else {
-                            // F.silu(gate) * up on fp16 tensors -- inference/model.py:266
-                            const float gv = h2f(hx);
-                            h[hh] = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, ha);
+            for (u32 c = 0; c < 4; c++) {
+                if constexpr (PRO == PRO_RMSNORM) {
+                    const float p = h2f(xr[n][c] & 0xFFFF), q = h2f(xr[n][c] >> 16);
+                    ss += p * p;
+                    ss += q * q;
+                    mx = fmaxf(mx, fmaxf(fabsf(p * h2f(ar[n][c] & 0xFFFF)), fabsf(q * h2f(ar[n][c] >> 16))));
+                } else {
+                    if constexpr (PRO == PRO_SILUMUL) {
+                        // F.silu(gate) * up on fp16 tensors -- inference/model.py:266
+                        _Float16 hh[2];
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const float gv = h2f((uint16_t)(xr[n][c] >> (16 * k)));
+                            hh[k] = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, (uint16_t)(ar[n][c] >> (16 * k)));
                         }
+                        xr[n][c] = (u32)__builtin_bit_cast(uint16_t, hh[0]) | ((u32)__builtin_bit_cast(uint16_t, hh[1]) << 16);
                     }
-                    ww[k] = (u32)__builtin_bit_cast(uint16_t, h[0]) | ((u32)__builtin_bit_cast(uint16_t, h[1]) << 16);
+                    // |fp16| bit patterns order like unsigned integers
+                    const u32 ab = xr[n][c] & 0x7FFF7FFFu;
+                    mxi = max(mxi, max(ab & 0xFFFFu, ab >> 16));
                 }
-                *reinterpret_cast<uint4 *>(xs + 8u * g) = make_uint4(ww[0], ww[1], ww[2], ww[3]);
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float p = h2f(ww[k] & 0xFFFF), q = h2f(ww[k] >> 16);
-                xsum += p;
-                xsum += q;
-                mx = fmaxf(mx, fmaxf(fabsf(p), fabsf(q)));
-            }
-        }
-        xsum = wave_reduce<false>(xsum);
+        if constexpr (PRO != PRO_RMSNORM) mx = h2f((uint16_t)mxi);
         mx = wave_reduce<true>(mx);
+        if constexpr (PRO == PRO_RMSNORM) ss = wave_reduce<false>(ss);
         if (l == 63) {
-            red[w] = xsum;
-            red[16 + w] = mx;
+            red[w] = mx;
+            if constexpr (PRO == PRO_RMSNORM) red[16 + w] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 i = 0; i < W; i++) xmax = fmaxf(xmax, red[i]);
+        if constexpr (PRO == PRO_RMSNORM) {
+            float tot = 0.f;
+#pragma unroll
+            for (u32 i = 0; i < W; i++) tot += red[16 + i];
+            nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
+            xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
         }
     }
     stamp(7);
-    __syncthreads();
-    float X = 0.f, xmax = 0.f;
-    for (u32 i = 0; i < W; i++) {
-        X += red[i];
-        xmax = fmaxf(xmax, red[16 + i]);
-    }
-    // one power-of-two scale for the whole vector: |x| * 2^(15-eb) < 2^15 (bf8 has 32 binades below that)
-    const int eb = xmax > 0.f ? (int)((__builtin_bit_cast(u32, xmax) >> 23) & 0xFFu) - 126 : 15;
-    const float sc = __builtin_bit_cast(float, (u32)(15 - eb + 127) << 23);
-    const int sb = 127 + eb - 15;  // E8M0 scale of every B block
-    // Phase B: item = (chunk, t, j pair): the 4 bytes c of two adjacent weights -> 2 x 4 image words
-    for (u32 it = tid; it < G.nchunks * 128u; it += T) {
-        const u32 t = it & 31u, jp = (it >> 5) & 3u, chunk = it >> 7;  // 32 consecutive lanes = the 32 virtual lanes
-        const u32 tp = G.tpw(chunk), kbi = t >> 3, v = t & 7u;
-        float xe[4][2];
+
+    // ---------------------------------------------------------------- 4. transform, scale, split, scatter
+    const int ksh = piece_shift(xmax);
+    const int sb = 127 - ksh;  // E8M0 scale of every B block
+    {
+        const uint16_t k16 = pow2_f16(ksh);
+        const h2v kk = u2h2((u32)k16 * 0x10001u), one2 = u2h2(0x3C003C00u);
+        float xsum = 0.f;
 #pragma unroll
-        for (u32 c = 0; c < 4; c++) {
-            const u32 e = 1024u * chunk + 8u * tp * c + 8u * t + 2u * jp;
-            const u32 rw = t < tp ? *reinterpret_cast<const u32 *>(xs + e) : 0u;
-            xe[c][0] = h2f((uint16_t)(rw & 0xFFFF)) * sc;
-            xe[c][1] = h2f((uint16_t)(rw >> 16)) * sc;
-        }
+        for (u32 n = 0; n < NI; n++) {
+            const u32 it = tid + n * T;
+            const u32 t = it & 31u, jp = (it >> 5) & 3u, chunk = it >> 7;
+            if (chunk >= G.nchunks) continue;
+            const u32 kbi = t >> 3, v = t & 7u;
+            u32 P[4][4];  // [piece][c]
 #pragma unroll
-        for (u32 jj = 0; jj < 2; jj++) {
-            const u32 s = 7u - (2u * jp + jj);
-            float q0 = xe[0][jj], q1 = xe[1][jj], q2 = xe[2][jj], q3 = xe[3][jj];
+            for (u32 c = 0; c < 4; c++) {
+                u32 xw = xr[n][c];
+                if constexpr (PRO == PRO_RMSNORM) {
+                    // (x.float() * rsqrt(mean(x^2)+eps)).half() * w  -- inference/model.py:281-292, both fp16 roundings kept
+                    const _Float16 h0 = (_Float16)(h2f(xw & 0xFFFF) * nscale), h1 = (_Float16)(h2f(xw >> 16) * nscale);
+                    xw = h22u((h2v){h0, h1} * u2h2(ar[n][c]));
+                }
+                xsum = __builtin_amdgcn_fdot2(u2h2(xw), one2, xsum, false);
+                h2v rem = u2h2(xw) * kk;
 #pragma unroll
-            for (u32 p = 0; p < 4; p++) {
-                // bytes B = 0..3 hold c = 3..0
-                int wd = __builtin_amdgcn_cvt_pk_bf8_f32(q3, q2, 0, false);
-                wd = __builtin_amdgcn_cvt_pk_bf8_f32(q1, q0, wd, true);
-                *reinterpret_cast<int *>(bimg + bimg_off(chunk, s, kbi, p) + 4u * v) = wd;
-                if (p < 3) {
-                    q3 -= __builtin_amdgcn_cvt_f32_bf8(wd, 0);
-                    q2 -= __builtin_amdgcn_cvt_f32_bf8(wd, 1);
-                    q1 -= __builtin_amdgcn_cvt_f32_bf8(wd, 2);
-                    q0 -= __builtin_amdgcn_cvt_f32_bf8(wd, 3);
+                for (u32 p = 0; p < 4; p++) {
+                    P[p][c] = h22u(rem) & 0xFF00FF00u;
+                    if (p < 3) rem = rem - u2h2(P[p][c]);
                 }
             }
-        }
-    }
-    if (pro_wave) {
 #pragma unroll
-        for (int d = 0; d < D; d++) issue(d);
+            for (u32 p = 0; p < 4; p++) {
+                // image bytes B = 0..3 hold c = 3..0; the bf8 of weight 2jp is byte 1 of P, of weight 2jp+1 byte 3
+                const u32 hi = __builtin_amdgcn_perm(P[p][3], P[p][2], 0x03070105u);
+                const u32 lo = __builtin_amdgcn_perm(P[p][1], P[p][0], 0x03070105u);
+                const u32 w0 = __builtin_amdgcn_perm(lo, hi, 0x05040100u), w1 = __builtin_amdgcn_perm(lo, hi, 0x07060302u);
+                *reinterpret_cast<u32 *>(bimg + bimg_off(chunk, 7u - 2u * jp, kbi, p) + 4u * v) = w0;
+                *reinterpret_cast<u32 *>(bimg + bimg_off(chunk, 6u - 2u * jp, kbi, p) + 4u * v) = w1;
+            }
+        }
+        xsum = wave_reduce<false>(xsum);
+        if (l == 63) red[32 + w] = xsum;
     }
     stamp(1);
     __syncthreads();
     stamp(2);
+    float X = 0.f;
+#pragma unroll
+    for (u32 i = 0; i < W; i++) X += red[32 + i];
 
-    // ---------------------------------------------------------------- main loop: (item, chunk) steps of this wave
-    const u32 items_w = nIt > wi ? (nIt - wi + W - 1u) / W : 0u;
-    const u32 my_steps = items_w * cpi;
+    // ---------------------------------------------------------------- 5. main loop: the steps of this wave
     const u32 col = l & 15u;
     const bool bcol = col < 4u;
+    const u32 offA0 = atile_unit(r, 2u * kb) * 16u, offA1 = atile_unit(r, 2u * kb + 1u) * 16u;
     v4f acc[NP1];
 #pragma unroll
     for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
-    u32 cq_item = wi, cq_c = 0;
-
-    for (u32 q = 0; q < my_steps; q += D) {
+    u32 cq_item = w, cq_c = 0, cq_slot = 0;
+    for (u32 q = 0; q < my_steps; q++) {
+        const u32 chunk = (cq_item & (CS - 1u)) * cpi + cq_c;
+        const u32 after = my_steps - 1u - q;
+        wait_vm_steps<LPS>(after < S - 1u ? after : S - 1u);
+        u32 Wd[BITS][8];
+        {
+            const unsigned char *slot = ring + cq_slot * SLOT;
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            if (q + (u32)d < my_steps) {
-                const u32 chunk = (cq_item & (CS - 1u)) * cpi + cq_c;
-                auto stamp2 = [&](int i) {
-                    if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0 && q + (u32)d < 2u)
-                        a.dbg[64u + w * 16u + (q + (u32)d) * 8u + (u32)i] = __builtin_readcyclecounter();
-                };
-                stamp2(0);
-                u32 Wd[BITS][8];
+            for (int p = 0; p < BITS; p++) {
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA0);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA1);
+                Wd[p][0] = a0.x, Wd[p][1] = a0.y, Wd[p][2] = a0.z, Wd[p][3] = a0.w;
+                Wd[p][4] = a1.x, Wd[p][5] = a1.y, Wd[p][6] = a1.z, Wd[p][7] = a1.w;
+            }
+        }
+        if (q + S < my_steps) {
+            // refill this slot with the step S ahead: the ds_reads above must have returned first
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue();
+        }
+        if (++cq_slot == S) cq_slot = 0;
+        if (chunk < G.nchunks) {
+            // plane-subset words: code bit i lives in plane BITS-1-i
+            u32 PW[NP1][8];
 #pragma unroll
-                for (int p = 0; p < BITS; p++)
+            for (int cm = 1; cm < NP; cm++) {
+                const int low = cm & -cm, i0 = __builtin_ctz(cm), rest = cm ^ low;
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        Wd[p][4 * h + 0] = P[d][p][h].x;
-                        Wd[p][4 * h + 1] = P[d][p][h].y;
-                        Wd[p][4 * h + 2] = P[d][p][h].z;
-                        Wd[p][4 * h + 3] = P[d][p][h].w;
-                    }
-                issue(d);
-                if (a.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                stamp2(1);
-                if (chunk < G.nchunks) {
-                    // plane-subset words: code bit i lives in plane BITS-1-i
-                    u32 PW[NP1][8];
+                for (int v = 0; v < 8; v++)
+                    PW[cm - 1][v] = rest ? (PW[rest - 1][v] & Wd[BITS - 1 - i0][v]) : Wd[BITS - 1 - i0][v];
+            }
+            // B operand (activation pieces) double-buffered over the bit position s
+            const unsigned char *bbase = bcol ? bimg + bimg_off(chunk, 0u, kb, col) : zero32;
+            const u32 bstep = bcol ? 512u : 0u;  // bimg_off(.., s+1, ..) - bimg_off(.., s, ..) = 4 pieces * 4 kb * 32 B
+            uint4 bn0 = *reinterpret_cast<const uint4 *>(bbase);
+            uint4 bn1 = *reinterpret_cast<const uint4 *>(bbase + 16);
 #pragma unroll
-                    for (int cm = 1; cm < NP; cm++) {
-                        const int low = cm & -cm, i0 = __builtin_ctz(cm), rest = cm ^ low;
-#pragma unroll
-                        for (int v = 0; v < 8; v++)
-                            PW[cm - 1][v] = rest ? (PW[rest - 1][v] & Wd[BITS - 1 - i0][v]) : Wd[BITS - 1 - i0][v];
-                    }
-                    stamp2(2);
-                    // B operand (activation pieces) double-buffered over the bit position s
-                    const unsigned char *bbase = bcol ? bimg + bimg_off(chunk, 0u, kb, col) : zero32;
-                    const u32 bstep = bcol ? 512u : 0u;  // bimg_off(.., s+1, ..) - bimg_off(.., s, ..) = 4 pieces * 4 kb * 32 B
-                    uint4 bn0 = *reinterpret_cast<const uint4 *>(bbase);
-                    uint4 bn1 = *reinterpret_cast<const uint4 *>(bbase + 16);
-#pragma unroll
-                    for (int s = 0; s < 8; s++) {
-                        const uint4 b0 = bn0, b1 = bn1;
-                        if (s < 7) {
-                            bn0 = *reinterpret_cast<const uint4 *>(bbase + (u32)(s + 1) * bstep);
-                            bn1 = *reinterpret_cast<const uint4 *>(bbase + (u32)(s + 1) * bstep + 16);
-                        }
-                        v8i Bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-#pragma unroll
-                        for (int cm = 1; cm < NP; cm++) {
-                            v8i Av;
-#pragma unroll
-                            for (int v = 0; v < 8; v++) Av[v] = (int)extract(PW[cm - 1][v], s);
-                            acc[cm - 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Av, Bv, acc[cm - 1], 1, 1, 0, scale_byte(s), 0, sb);
-                        }
-                    }
+            for (int s = 0; s < 8; s++) {
+                const uint4 b0 = bn0, b1 = bn1;
+                if (s < 7) {
+                    bn0 = *reinterpret_cast<const uint4 *>(bbase + (u32)(s + 1) * bstep);
+                    bn1 = *reinterpret_cast<const uint4 *>(bbase + (u32)(s + 1) * bstep + 16);
                 }
-                stamp2(3);
-                if (++cq_c == cpi) {
-                    // item done: add the 4 piece columns, park the 16 x NP1 sums in LDS
+                v8i Bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
 #pragma unroll
-                    for (int cm = 0; cm < NP1; cm++) {
-                        // part[item][plane][piece column][row]: lane (col, kb) owns rows 4kb..4kb+3 of its column
-                        if (bcol) *reinterpret_cast<v4f *>(part + (((size_t)cq_item * NP1 + cm) * 4u + col) * 16u + 4u * kb) = acc[cm];
-                        acc[cm] = (v4f){0.f, 0.f, 0.f, 0.f};
-                    }
-                    cq_c = 0;
-                    cq_item += W;
-                    stamp2(4);
+                for (int cm = 1; cm < NP; cm++) {
+                    v8i Av;
+#pragma unroll
+                    for (int v = 0; v < 8; v++) Av[v] = (int)extract(PW[cm - 1][v], s);
+                    acc[cm - 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Av, Bv, acc[cm - 1], 1, 1, 0, scale_byte(s), 0, sb);
                 }
             }
+        }
+        if (++cq_c == cpi) {
+            // item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
+#pragma unroll
+            for (int cm = 0; cm < NP1; cm++) {
+                v4f v = acc[cm];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float f = v[k];
+                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
+                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
+                    v[k] = f;
+                }
+                // part[item][subset][row]: lane (col 0, kb) owns rows 4kb..4kb+3
+                if (col == 0u) *reinterpret_cast<v4f *>(part + ((size_t)cq_item * NP1 + cm) * 16u + 4u * kb) = v;
+                acc[cm] = (v4f){0.f, 0.f, 0.f, 0.f};
+            }
+            cq_c = 0;
+            cq_item += W;
         }
     }
     stamp(3);
     __syncthreads();
     stamp(4);
 
-    // ---------------------------------------------------------------- epilogue: coefficients x plane sums
+    // ---------------------------------------------------------------- 6. epilogue: coefficients x plane sums
     for (u32 i = tid; i < a.RGB * 16u; i += T) {
         const u32 rgl = i >> 4, rr = i & 15u;
         const u32 row = (rg0 + rgl) * 16u + rr;
@@ -375,10 +403,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
 #pragma unroll
         for (int cm = 1; cm < NP; cm++) {
             float tsum = 0.f;
-            for (u32 cs = 0; cs < CS; cs++)
-#pragma unroll
-                for (u32 pc = 0; pc < 4; pc++)
-                    tsum += part[((((size_t)((rgl << a.log2CS) + cs)) * NP1 + (cm - 1)) * 4u + pc) * 16u + rr];
+            for (u32 cs = 0; cs < CS; cs++) tsum += part[(((size_t)((rgl << a.log2CS) + cs)) * NP1 + (cm - 1)) * 16u + rr];
             y += f[cm] * tsum;
         }
         _Float16 yh = (_Float16)y;
@@ -389,8 +414,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
 }
 
 struct PlaneCfg {
-    u32 grid, T, RGB, log2CS, cpi;
-    int D;
+    u32 grid, T, RGB, log2CS, cpi, S;
     size_t smem;
 };
 
@@ -412,38 +436,42 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     const u32 nchunks = K / 1024u + ((K % 1024u) ? 1u : 0u);
     const u32 RGt = (N + 15u) / 16u;
     const u32 ncu = (u32)cus();
-    // split K of a row group over 2^log2CS wave items until there are ~1.5 items per SIMD
+    const u32 W = bits == 2 ? 16u : 8u;
+    c.T = 64u * W;
+    // one block per CU when the matrix is big enough
+    u32 rgb = (RGt + ncu - 1u) / ncu;
+    if (rgb < 1) rgb = 1;
+    c.RGB = rgb;
+    c.grid = (RGt + rgb - 1u) / rgb;
+    // split K of a row group over 2^log2CS wave items until the block has at least one item per wave
     u32 lcs = 0;
-    const u32 want = (u32)gq_env_int("GQ_PL_ITEMS", (int)(ncu * 24u));
-    while ((RGt << lcs) < want && (2u << lcs) <= nchunks) lcs++;
+    while ((rgb << lcs) < W && (2u << lcs) <= nchunks) lcs++;
     const int envcs = gq_env_int("GQ_PL_LOG2CS", -1);
     if (envcs >= 0 && (1u << envcs) <= nchunks) lcs = (u32)envcs;
     c.log2CS = lcs;
     c.cpi = (nchunks + (1u << lcs) - 1u) >> lcs;
-    const u32 Wmax = bits == 2 ? 16u : 8u;
-    u32 W = (u32)gq_env_int("GQ_PL_WAVES", (int)Wmax);
-    if (W < 2 || W > Wmax) W = Wmax;
-    c.T = 64u * W;
-    // row groups per block: one block per CU when the matrix is big enough, never more items than ~2 per wave
-    u32 rgb = (RGt + ncu - 1u) / ncu;
-    const u32 envbpc = (u32)gq_env_int("GQ_PL_BPC", 1);
-    if (envbpc > 1) rgb = (RGt + ncu * envbpc - 1u) / (ncu * envbpc);
-    if (rgb < 1) rgb = 1;
-    c.RGB = rgb;
-    c.grid = (RGt + rgb - 1u) / rgb;
-    int d = gq_env_int("GQ_PL_D", 0);
-    if (d < 1 || d > 2) d = 1;
-    c.D = d;
+    // ring depth: as many steps per wave as the wave has / as fit next to the B image (<= 4: vmcnt immediates)
+    const u32 nIt = rgb << lcs;
+    const u32 steps_w = ((nIt + W - 1u) / W) * c.cpi;
     const u32 np1 = (1u << bits) - 1u;
-    c.smem = (size_t)nchunks * 4096u + nchunks * 64u + 32u + 64u * 4u + (size_t)K * 4u + (size_t)(rgb << lcs) * 16u * np1 * 4u * 4u;
-    return c.smem <= 160u * 1024u;
+    const size_t fixed = (size_t)nchunks * 4096u + 64u + 64u * 4u + (size_t)nIt * np1 * 16u * 4u;
+    const size_t slot = 2048u * (size_t)bits, lds = 160u * 1024u;
+    if (fixed + W * slot > lds) return false;
+    u32 S = (u32)((lds - fixed) / (W * slot));
+    if (S > 4u) S = 4u;
+    if (S > steps_w) S = steps_w;
+    const int envs = gq_env_int("GQ_PL_S", 0);
+    if (envs >= 1 && (u32)envs < S) S = (u32)envs;
+    c.S = S;
+    c.smem = fixed + (size_t)W * S * slot;
+    return true;
 }
 
-template <int BITS, int D, int PRO>
+template <int BITS, int PRO>
 int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = ap_plane_kernel<BITS, D, PRO>;
-    if (c.smem > 48u * 1024u && !attr_set) {
+    auto kern = ap_plane_kernel<BITS, PRO>;
+    if (!attr_set) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(160u * 1024u)));
         attr_set = true;
@@ -454,26 +482,12 @@ int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t 
     return GQ_OK;
 }
 
-template <int BITS, int PRO>
-int launch_plane_d(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
-    if constexpr (BITS == 4) {
-        return launch_plane_inst<BITS, 1, PRO>(a, c, M, s);
-    } else if constexpr (BITS == 3) {
-        return launch_plane_inst<BITS, 1, PRO>(a, c, M, s);
-    } else {
-        switch (c.D) {
-            case 1: return launch_plane_inst<BITS, 1, PRO>(a, c, M, s);
-            default: return launch_plane_inst<BITS, 2, PRO>(a, c, M, s);
-        }
-    }
-}
-
 template <int BITS>
 int launch_plane(const PlaneArgs &a, const PlaneCfg &c, u32 M, int pro, hipStream_t s) {
     switch (pro) {
-        case PRO_RMSNORM: return launch_plane_d<BITS, PRO_RMSNORM>(a, c, M, s);
-        case PRO_SILUMUL: return launch_plane_d<BITS, PRO_SILUMUL>(a, c, M, s);
-        default: return launch_plane_d<BITS, PRO_NONE>(a, c, M, s);
+        case PRO_RMSNORM: return launch_plane_inst<BITS, PRO_RMSNORM>(a, c, M, s);
+        case PRO_SILUMUL: return launch_plane_inst<BITS, PRO_SILUMUL>(a, c, M, s);
+        default: return launch_plane_inst<BITS, PRO_NONE>(a, c, M, s);
     }
 }
 
@@ -503,6 +517,7 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
     a.RGB = c.RGB;
     a.log2CS = c.log2CS;
     a.cpi = c.cpi;
+    a.S = c.S;
     a.eps = eps;
     a.dbg = g_dbg;
     switch (bits) {

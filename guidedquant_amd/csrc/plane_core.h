@@ -94,6 +94,37 @@ GQP_HD void locate_x(const Geom &G, u32 e, u32 &chunk, u32 &s, u32 &kb, u32 &v, 
     B = 3u - c;
 }
 
+
+// ---- A tile in LDS.  One step (16 rows x one 1024-weight chunk) of one plane is 16 lines of 128 B = 128 units of
+// 16 B, deposited by two direct-to-LDS loads (buffer_load_dwordx4 ... lds: LDS address = base + 16 * lane, so the
+// only freedom is WHICH global 16 B each lane fetches).  Instruction h (0/1) carries rows 8h..8h+7, lane = 8*a + b:
+//     row = 8*h + rr,  rr = a ^ h,  segment (16 B of the line) = b ^ rr
+// -> every instruction reads 8 whole 128-byte lines from HBM, and the MFMA lanes (row r = 0..15, fixed segment) of a
+// ds_read_b128 pass hit 16 distinct 16-byte bank groups (unit mod 16 = 8*((rr&1)^h) + (seg^rr)).
+GQP_HD u32 atile_unit(u32 r, u32 seg) {
+    const u32 h = r >> 3, rr = r & 7u;
+    return 64u * h + 8u * (rr ^ h) + (seg ^ rr);
+}
+GQP_HD void atile_src(u32 h, u32 lane, u32 &r, u32 &seg) {
+    const u32 a = lane >> 3, b = lane & 7u, rr = a ^ h;
+    r = 8u * h + rr;
+    seg = b ^ rr;
+}
+
+// ---- activation pieces.  bf8 (e5m2) is fp16 with the low significand byte cut off, so an fp16 value splits EXACTLY
+// into 4 bf8 pieces by truncate-and-subtract in fp16 arithmetic: p = h & 0xFF00, h -= p (exact), 4 times (3 significand
+// bits each, 12 >= 11).  The vector is first multiplied by 2^k (fp16, exact unless it underflows) so that
+// max|x| * 2^k is in [2^14, 2^15): pieces of every element within 2^-17 of the maximum stay bf8 NORMALS (the matrix
+// cores are inexact on fp8 denormals).  k is clamped to what fp16 can hold as a factor.
+GQP_HD int piece_shift(float xmax) {  // xmax >= 0 (an upper bound of max|x| is fine)
+    u32 u;
+    memcpy(&u, &xmax, 4);
+    const int eb = xmax > 0.f ? (int)((u >> 23) & 0xFFu) - 126 : 15;  // xmax < 2^eb
+    int k = 15 - eb;
+    return k > 15 ? 15 : (k < -14 ? -14 : k);
+}
+GQP_HD uint16_t pow2_f16(int k) { return (uint16_t)((k + 15) << 10); }  // -14 <= k <= 15
+
 // e5m2 ("bf8") software conversions (host emulation and documentation of what the hardware cvt does)
 GQP_HD float bf8_to_f32(uint8_t b) {
     const int sg = b >> 7, e = (b >> 2) & 31, m = b & 3;

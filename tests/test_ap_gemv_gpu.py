@@ -1,6 +1,8 @@
 """GPU parity: the HIP Any-Precision GEMV / dequant, called through the C ABI (ctypes -> libgq_hip.so) behind the
 reference's `ap_gemv` module surface, against the CPU oracle.  The bar is BIT-EXACT fp16 (the kernel reproduces
 the reference's fp16 accumulation order), so the north-star tolerance (1e-3 rel-fp16) is met with zero error."""
+import os
+
 import numpy as np
 import pytest
 
@@ -19,11 +21,20 @@ def _exact_mode():
     _lib.check(_lib.lib().gq_set_ap_mode(1), "gq_set_ap_mode")
     yield
     _lib.lib().gq_set_ap_mode(-1)
+    for k in ("GQ_PL_MIN_MWEIGHTS", "GQ_PL_MAX_BITS"):
+        os.environ.pop(k, None)
+    _lib.lib().gq_reset_env_cache()
 
 
-def _fast():
+def _fast(force_plane=True):
+    """Fast mode.  By default the dispatcher sends only the shapes on which the plane-MFMA kernel wins to it
+    (2-bit, >= 32 M weights); the parity tests of that kernel lift the thresholds so that every shape runs on it."""
     from guidedquant_amd import _lib
     _lib.check(_lib.lib().gq_set_ap_mode(0), "gq_set_ap_mode")
+    if force_plane:
+        os.environ["GQ_PL_MIN_MWEIGHTS"] = "0"
+        os.environ["GQ_PL_MAX_BITS"] = "4"
+        _lib.lib().gq_reset_env_cache()
 
 
 def _check_fast(got, x, q, lut, bits, oracle, rows=None):
@@ -35,14 +46,14 @@ def _check_fast(got, x, q, lut, bits, oracle, rows=None):
                     |got - ref| <= |fp16(exact) - ref| + 2 ulp + 1e-5 * sum|w||x|, and normwise
                     ||got - ref|| <= 1.05 * ||fp16(exact) - ref|| (+eps): all of the distance to the reference is
                     the reference's own fp16 accumulation error (anyprec.cu:495-512);
-      (c) shapes the fast path does not serve (K % 256 != 0 or K > 24576) fall back to the exact kernels: bit-identical."""
+      (c) shapes the fast path does not serve (K % 256 != 0 or K > 16384) fall back to the exact kernels: bit-identical."""
     if rows is not None:
         q = np.ascontiguousarray(q[:, rows, :])
         lut = lut[rows]
         got = got[rows]
     K = q.shape[2] * 32
     ref16h = oracle.ap_gemv_f16(x, q, lut, bits)[0]
-    if K % 256 or K > 24576:
+    if K % 256 or K > 16384:
         assert np.array_equal(got.view(np.uint16), ref16h.view(np.uint16))
         return
     y64 = oracle.ap_gemv_f64(x, q, lut, bits)[0]
@@ -143,7 +154,6 @@ def test_fast_path_equals_generic_path_on_device(bits):
     lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
     x = rng.normal(0, 1, K).astype(np.float16)
     fast = _run_gemv(x, q, lut, bits)
-    import os
     os.environ["GQ_AP_FORCE_GENERIC"] = "1"
     _lib.lib().gq_reset_env_cache()
     try:
@@ -289,3 +299,22 @@ def test_fast_mode_tiny_and_huge_activations(oracle):
     _check_fast(got, x, q, lut, bits, oracle)
     x = np.zeros(K, dtype=np.float16)
     assert (_run_gemv(x, q, lut, bits)[0] == 0).all()
+
+
+def test_default_dispatch_is_hybrid(oracle):
+    """Default fast mode without lifted thresholds: a small matrix is served by the exact-order kernel (bit-identical
+    to the reference order), the 8B gate/up matrix by the plane-MFMA kernel (fp32-class accuracy)."""
+    from guidedquant_amd import pack
+    rng = np.random.default_rng(21)
+    _fast(force_plane=False)
+    for N, K, plane in ((4096, 4096, False), (28672, 4096, True)):
+        q = pack.random_planes(N, K, 2, seed=N)
+        lut = np.sort(rng.normal(0, 0.02, (N, 4)).astype(np.float16), axis=1)
+        x = rng.normal(0, 1, K).astype(np.float16)
+        got = _run_gemv(x, q, lut, 2)[0]
+        rows = np.unique(rng.integers(0, N, 96))
+        if plane:
+            _check_fast(got, x, q, lut, 2, oracle, rows=rows)
+        else:
+            want = oracle.ap_gemv_f16(x, np.ascontiguousarray(q[:, rows, :]), lut[rows], 2)[0]
+            assert np.array_equal(got[rows].view(np.uint16), want.view(np.uint16))

@@ -3,6 +3,7 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from guidedquant_amd import _lib
+os.environ.setdefault('GQ_PL_MIN_MWEIGHTS', '0')
 L = _lib.lib(); L.gq_set_ap_mode(0)
 L.gq_debug_set_timing_buffer.argtypes = [ctypes.c_void_p]
 d = torch.device("cuda:0")
@@ -21,14 +22,8 @@ for name in sys.argv[2:] or list(SH):
     torch.cuda.synchronize(); L.gq_debug_set_timing_buffer(None)
     raw = dbg.cpu().numpy()
     t = raw[:128].reshape(16, 8)[:, [0, 6, 7, 1, 2, 3, 4, 5]]
-    t2 = raw[128:].reshape(16, 2, 8)[:, :, :5]
     t0 = t[t > 0].min()
-    print(name, "cycles: [start, raw x copied (before barrier 1), max/sum done (before barrier 2), image built, after barrier 3, main loop done, after barrier 4, end]")
+    print(name, "cycles: [start, x landed (planes issued), stats done, image built, after image barrier, main loop done, after barrier, end]")
     for w in range(16):
         if t[w].max() > 0:
             print("  wave", w, [int(v - t0) if v > 0 else None for v in t[w]])
-    print("  main-loop steps (wave, step): [step start, planes landed, PW built, MFMAs issued, item epilogue done]")
-    for w in range(16):
-        for st in range(2):
-            if t2[w, st].max() > 0:
-                print("   wave", w, "step", st, [(int(v) - int(t0)) if v > 0 else None for v in t2[w, st]])

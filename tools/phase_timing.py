@@ -27,3 +27,8 @@ for name in sys.argv[2:] or list(SH):
     for w in range(16):
         if t[w].max() > 0:
             print("  wave", w, [int(v - t0) if v > 0 else None for v in t[w]])
+    t2 = raw[128:].reshape(16, 16)
+    print("  extra stamps (consumer: per step [wait start, tile ready], item end; producer: tile publishes)")
+    for w in range(16):
+        if t2[w].max() > 0:
+            print("  wave", w, [int(v - t0) for v in t2[w] if v > 0])

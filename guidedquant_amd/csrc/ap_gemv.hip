@@ -523,7 +523,7 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     // fast mode serves the shapes on which the plane-MFMA kernel beats the exact kernel (measured):
     // 2-bit matrices of >= GQ_PL_MIN_MWEIGHTS million weights (w1w3, w2 of the 8B / 70B models); everything else runs
     // the exact kernels, whose results are bit-identical to the reference
-    const uint64_t min_w = (uint64_t)gq_env_int("GQ_PL_MIN_MWEIGHTS", 32) * 1000000ull;
+    const uint64_t min_w = (uint64_t)gq_env_int("GQ_PL_MIN_MWEIGHTS", 20) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 2);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {
         int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, s);

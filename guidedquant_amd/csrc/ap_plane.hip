@@ -26,6 +26,7 @@ using namespace gqp;
 namespace {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -41,7 +42,8 @@ struct PlaneArgs {
     u32 log2CS;  // a row group's chunks are split over 2^log2CS wave items
     u32 cpi;     // chunks per item
     u32 S;       // LDS ring slots (steps) per wave
-    u32 xflags;  // experiments (GQ_PL_XFLAGS): 1 = no MFMA work, 2 = no plane stream, 4 = no prologue image
+    u32 xflags;  // ablation experiments (GQ_PL_XFLAGS): 1 no MFMA work, 2 no steps at all, 8 no activation loads, 16 no LUT, 32 empty kernel,
+                 // 256 late waves request only their first item up front, 1024 no plane loads (the MFMA phase runs on stale LDS)
     float eps;
     unsigned long long *dbg;  // optional: per-wave phase timestamps of block 0 (tools/phase_timing.py)
 };
@@ -77,6 +79,18 @@ typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2v u2h2(u32 u) { return __builtin_bit_cast(h2v, u); }
 __device__ __forceinline__ u32 h22u(h2v h) { return __builtin_bit_cast(u32, h); }
 
+// The scaled MFMA with A = FP4 (4 registers), B = BF8, accumulating IN PLACE.  Through the builtin the register
+// allocator lets the accumulators wander (vDst != SrcC, overlapping freed operand registers), and every MFMA then waits
+// for the previous one to retire (s_nop 5..6 plus the hardware interlock) -- the matrix pipe runs at half rate.
+// Hazards the compiler can not see inside the asm: the A registers were just written by VALU (2 wait states, the
+// s_nop below); a VALU read of the accumulator needs the MFMA retired (mfma_drain before the item's reduction).
+__device__ __forceinline__ void mfma_f4_bf8(v4f &acc, v4i a, v8i b, u32 scale_a, u32 scale_b) {
+    asm("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:1"
+        : "+v"(acc)
+        : "v"(a), "v"(b), "v"(scale_a), "v"(scale_b));
+}
+__device__ __forceinline__ void mfma_drain(v4f &acc) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc)); }
+
 // --- hand-scheduled vector memory.  The compiler's waitcnt pass treats an LDS-DMA load as "may alias every later
 // LDS access" and drains vmcnt before the first ds_read / barrier, which would serialise the prologue behind the
 // whole plane stream.  So the plane loads and the activation loads that must overtake them are issued from inline
@@ -97,6 +111,11 @@ __device__ __forceinline__ u32 bload32(u32x4 rsrc, u32 voff) {
 __device__ __forceinline__ u32 bload32s(u32x4 rsrc, u32 voff, u32 soff) {
     u32 r;
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return r;
+}
+__device__ __forceinline__ u32 bload16s(u32x4 rsrc, u32 voff, u32 soff) {  // zero-extended 16-bit load
+    u32 r;
+    asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     return r;
 }
 template <int N>
@@ -122,32 +141,31 @@ __device__ __forceinline__ u32x4 make_rsrc(const void *p, u32 bytes) {
     return (u32x4){(u32)a, (u32)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};  // raw buffer: stride 0, num_records = bytes
 }
 
-// software barrier among the consumer waves (the producer waves may be stalled in the vector-memory issue queue
-// for microseconds, so s_barrier is only used once, at the very start of the kernel)
-__device__ __forceinline__ void arrive_and_wait(u32 *ctr, u32 target, u32 lane) {
+// software barrier among a subset of the waves (LDS counter): waves that may sit in the vector-memory issue queue
+// (issuing blocks once the CU's memory pipe is full) must not hold up a hardware barrier
+__device__ __forceinline__ void arrive(u32 *ctr, u32 lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wait_count(const u32 *ctr, u32 target) {
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void spin_nonzero(const u32 *flag) {
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
-// Roles.  A block is W waves: NC consumers (activation prologue, MFMA, epilogue) and NPR = W / 4 producers (one per
-// SIMD) that do nothing but issue the direct-to-LDS plane loads in consumption order and publish "tile ready"
-// flags.  Work unit ("step") = 16 rows x one 1024-weight chunk x all planes; an item = cpi consecutive chunks of a
-// row group, accumulated in registers by one consumer.  Sequence number of a step:
-//     seq = (round * cpi + c) * NC + k      consumer k, its round-th item (item = round * NC + k), chunk c of the item
-// Producer p owns seq = p (mod NPR); tile seq lives in ring slot seq % R.
+// Work unit ("step") = 16 rows x one 1024-weight chunk x all planes = one A tile of BITS * 2 KiB; an item = cpi
+// consecutive chunks of a row group, accumulated in registers by one wave.  Every wave streams its own tiles
+// (direct-to-LDS loads into a private ring of S slots, own vmcnt) and multiplies them; what differs is the start:
+//   early waves (first half, launched first): activation loads -> statistics -> B image.  They request their tiles
+//                only when the image is built, so they never sit in a full memory issue queue before that.
+//   late waves : request their first item at t = 0 (right behind the activation loads of the early waves) and may
+//                block in the issue queue; they only wait for the image, through an LDS counter.
+// Items: i < L (= W - E late waves) -> the first item of late wave E + i; i >= L -> wave (i - L) mod W.
 template <int BITS, int PRO, int NI>
 __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneArgs a) {
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
-    constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u, NPR = W / 4u, NC = W - NPR, TC = NC * 64u;
-    // NI prologue passes over the (chunk, virtual lane, weight pair) items: pass n gives wave w the chunk (w >> 1) + n * TC / 128
-    static_assert(TC % 128u == 0, "a wave's prologue items must share one chunk");
-    constexpr u32 LPS = 2u * BITS;              // direct-to-LDS loads per step
+    constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u, E = W / 2u, L = W - E;  // early / late waves
+    // NI prologue passes over the (chunk, virtual lane, weight pair) items: pass n gives early wave w the chunk (w >> 1) + n * E / 2
+    constexpr u32 LPS = 2u * BITS;  // direct-to-LDS loads per step
     constexpr u32 SLOT = 2048u * BITS;
     constexpr u32 OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -156,21 +174,18 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     const u32 tid = threadIdx.x;
     const u32 w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 l = tid & 63u;
-    const u32 CS = 1u << a.log2CS, cpi = a.cpi, R = a.S;
+    const u32 CS = 1u << a.log2CS, cpi = a.cpi, S = a.S;
     const u32 nIt = a.RGB * CS;  // items of this block
-    const u32 rounds = (nIt + NC - 1u) / NC;
-    const u32 nseq = rounds * cpi * NC;
-    // LDS: [A ring: R slots][LUT rows of the block][B image: nchunks * 4096][zero32 (64 B)][red: 64 floats][ctr: 4][ready: nseq][done: nseq][part]
-    unsigned char *ring = smem;
-    const u32 lut_bytes = (a.RGB * 16u * (u32)NP * 2u + 1023u) & ~1023u;
-    const u32 *lutl = reinterpret_cast<const u32 *>(smem + (size_t)R * SLOT);  // fp16 [RGB * 16][NP], fetched by producer 0
-    unsigned char *bimg = smem + (size_t)R * SLOT + lut_bytes;
+    // LDS: [A rings: W x S slots][LUT rows of the block][B image: nchunks * 4096][zero32 (64 B)][red: 60 floats, ctr: 4][part]
+    unsigned char *ring = smem + (size_t)w * S * SLOT;
+    const u32 lut_bytes = (a.RGB * 16u * (u32)NP * 2u + LPS * 1024u - 1u) / (LPS * 1024u) * (LPS * 1024u);  // whole pseudo steps
+    unsigned char *lutb = smem + (size_t)W * S * SLOT;
+    const u32 *lutl = reinterpret_cast<const u32 *>(lutb);  // fp16 [RGB * 16][NP]
+    unsigned char *bimg = lutb + lut_bytes;
     unsigned char *zero32 = bimg + G.nchunks * 4096u;
     float *red = reinterpret_cast<float *>(zero32 + 64);
-    u32 *ctr = reinterpret_cast<u32 *>(red + 64);
-    u32 *ready = ctr + 4;
-    u32 *done = ready + nseq;
-    float *part = reinterpret_cast<float *>(done + nseq);  // [item][subset][16 rows]
+    u32 *ctr = reinterpret_cast<u32 *>(red + 60);
+    float *part = red + 64;  // [item][subset][16 rows]
     const u32 rg0 = blockIdx.x * a.RGB;
     const u32 m = blockIdx.y;
     auto stamp = [&](int i) {
@@ -178,47 +193,51 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     };
     stamp(0);
     if (a.xflags & 32u) return;
-    // waves 0..NC-1 are the consumers; the producers are the last waves of the block: they are launched ~500 cycles
-    // after wave 0, by when the consumers' activation loads are in the memory pipe ahead of the plane stream
-    const bool producer = w >= NC;
-    const u32 k = w, ctid = tid;
+    const bool early = w < E;
 
-    // ---------------------------------------------------------------- producer state (plane stream)
-    // this producer's steps in consumption order: seq = (rd * cpi + c) * NC + kc with kc = w (mod NPR); NC % NPR == 0
-    static_assert(NC % NPR == 0, "every producer serves a fixed set of consumers");
-    struct It {
-        u32 rd, c, kk;
-    };
-    constexpr u32 KPP = NC / NPR;
-    const u32 pi = w - NC;  // producer index
-    auto it_seq = [&](const It &i) { return (i.rd * cpi + i.c) * NC + pi + NPR * i.kk; };
-    auto it_valid = [&](const It &i, u32 &item, u32 &chunk) {
-        item = i.rd * NC + pi + NPR * i.kk;
-        chunk = (item & (CS - 1u)) * cpi + i.c;
-        return item < nIt && chunk < G.nchunks;
-    };
-    auto it_next = [&](It &i) {
-        if (++i.kk == KPP) {
-            i.kk = 0;
-            if (++i.c == cpi) {
-                i.c = 0;
-                i.rd++;
+    // ---------------------------------------------------------------- 0. activation loads, then the first tiles
+    // prologue item = (chunk, virtual lane t, nibble bit b): the weights j = 7 - b and j = 3 - b (plane bits b and b + 4 of
+    // every byte) of the 4 bytes c of lane t -- the 8 activations that meet the two image words of (t, b)
+    u32 xr[NI][4], ar[NI][4], xh[NI][4], ah[NI][4];
+    const u32 pt = l & 31u, pb = ((w & 1u) << 1) | (l >> 5);  // the same for every pass (E * 64 is a multiple of 128)
+    if (early) {
+        const u32x4 rsx = make_rsrc(a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
+        const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
+#pragma unroll
+        for (u32 n = 0; n < (u32)NI; n++) {
+            const u32 chunk = (w >> 1) + n * (E / 2u);  // wave-uniform
+            const u32 tp = G.tpw(chunk);
+            const bool ok = chunk < G.nchunks && pt < tp && !(a.xflags & 8u);
+            const u32 vlo = ok ? 16u * pt + 2u * (7u - pb) : OOB, vhi = ok ? 16u * pt + 2u * (3u - pb) : OOB;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 soff = 2048u * chunk + 16u * tp * c;  // element 1024*chunk + 8*tp*c (+ 8t + j per lane)
+                xr[n][c] = bload16s(rsx, vlo, soff);
+                xh[n][c] = bload16s(rsx, vhi, soff);
+                if constexpr (PRO == PRO_RMSNORM) {
+                    ar[n][c] = bload16s(rsa, vlo, soff);
+                    ah[n][c] = bload16s(rsa, vhi, soff);
+                }
+                if constexpr (PRO == PRO_SILUMUL) {
+                    ar[n][c] = bload16s(rsx, vlo, soff + 2u * G.K);
+                    ah[n][c] = bload16s(rsx, vhi, soff + 2u * G.K);
+                }
             }
         }
-    };
-    auto it_skip = [&](It &i) {  // advance to the next valid step (or the end: rd == rounds)
-        u32 item, chunk;
-        while (i.rd < rounds && !it_valid(i, item, chunk)) it_next(i);
-    };
-    It iss{0, 0, 0}, pub{0, 0, 0};
-    u32 issued = 0, published = 0;
+    }
+    // plane stream of this wave: its items in order (late wave: item w - E first), cpi steps each, ring slot = step % S
+    const u32 first_late = (!early && w - E < nIt) ? 1u : 0u;
+    const u32 items_w = first_late + (nIt > L + w ? (nIt - L - w + W - 1u) / W : 0u);
+    const u32 my_steps = (a.xflags & 2u) ? 0u : items_w * cpi;
+    auto item_after = [&](u32 item) { return item < L ? L + w : item + W; };  // the wave's next item
+    const u32 item0 = first_late ? w - E : L + w;
     const u32 plane_bytes = a.N * G.wpr * 4u;
     const u32x4 rq = make_rsrc(a.qw, plane_bytes * (u32)BITS);
     const u32 ring_lds = (u32)(uintptr_t)ring;
     // Per-lane part of a tile address is constant (atile_src); the tile part is wave-uniform and goes into the
     // scalar offset.  No per-lane validity: rows >= N and the words of a short tail chunk beyond the row fetch
     // in-range garbage (or zeros past the end of the tensor) that only ever meets zero activation pieces /
-    // rows that are never stored.
+    // rows that are never stored.  Steps whose chunk does not exist are skipped by issue and use alike.
     u32 lane_off[2];
     {
         u32 lr, lseg;
@@ -227,114 +246,72 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         atile_src(1u, l, lr, lseg);
         lane_off[1] = (lr * G.wpr + 4u * lseg) * 4u;
     }
-    auto issue_step = [&]() {  // the step at `iss`
-        u32 item, chunk;
-        it_valid(iss, item, chunk);
-        const u32 seq = it_seq(iss);
-        const u32 rgi = rg0 + (item >> a.log2CS);
-        const u32 slot_lds = ring_lds + (R == nseq ? seq : seq % R) * SLOT;
-        const u32 tile_off = (rgi * 16u * G.wpr + 32u * chunk) * 4u;
+    u32 iq_item = item0, iq_c = 0, iq_slot = 0, iq_n = 0;  // next step to request
+    auto issue = [&]() {
+        if (a.xflags & 1024u) {  // experiment: no plane loads at all (the MFMA phase runs on whatever is in LDS)
+            iq_n++;
+            return;
+        }
+        const u32 chunk = (iq_item & (CS - 1u)) * cpi + iq_c;
+        const u32 rgi = rg0 + (iq_item >> a.log2CS);
+        const u32 slot_lds = ring_lds + iq_slot * SLOT;
+        const u32 tile_off = (rgi * 16u * G.wpr + 32u * (chunk < G.nchunks ? chunk : 0u)) * 4u;
 #pragma unroll
         for (u32 p = 0; p < (u32)BITS; p++)
 #pragma unroll
             for (u32 h = 0; h < 2; h++) dma16s(rq, slot_lds + (p * 2u + h) * 1024u, lane_off[h], tile_off + p * plane_bytes);
-        issued++;
-        it_next(iss);
-        it_skip(iss);
+        if (++iq_c == cpi) {
+            iq_c = 0;
+            iq_item = item_after(iq_item);
+        }
+        if (++iq_slot == S) iq_slot = 0;
+        iq_n++;
     };
-
-    // ---------------------------------------------------------------- 0. first loads, flag init, the only barrier
-    // prologue item = (chunk, virtual lane t, weight pair jp): the weights j = 2jp, 2jp+1 of the 4 bytes c of lane t
-    u32 xr[NI][4], ar[NI][4];
-    const u32 pt = l & 31u, pjp = ((k & 1u) << 1) | (l >> 5);  // the same for every pass (TC is a multiple of 128)
-    if (producer) {
-        if (!(a.xflags & 2u)) {
-            __builtin_amdgcn_s_setprio(3);  // the stream must not wait for issue slots behind the MFMA waves of this SIMD
-            if (pi == 0 && !(a.xflags & 16u)) {
-                // the LUT rows of the block, ahead of this producer's first tile: loads return in order, so they are in
-                // LDS before tile seq 0 is published, long before the epilogue reads them
-                const u32x4 rl = make_rsrc(a.lut, a.N * (u32)NP * 2u);
-                const u32 lut_lds = ring_lds + R * SLOT;
-                for (u32 o = 0; o < lut_bytes; o += 1024u) dma16(rl, lut_lds + o, rg0 * 16u * (u32)NP * 2u + o + 16u * l);
-            }
-            it_skip(iss);
-            it_skip(pub);
-        }
-    } else {
-        const u32x4 rsx = make_rsrc(a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
-        const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
-#pragma unroll
-        for (u32 n = 0; n < (u32)NI; n++) {
-            const u32 chunk = (k >> 1) + n * (TC / 128u);  // wave-uniform
-            const u32 tp = G.tpw(chunk);
-            const u32 voff = (chunk < G.nchunks && pt < tp && !(a.xflags & 8u)) ? 16u * pt + 4u * pjp : OOB;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 soff = 2048u * chunk + 16u * tp * c;  // element 1024*chunk + 8*tp*c (+ 8t + 2jp per lane)
-                xr[n][c] = bload32s(rsx, voff, soff);
-                if constexpr (PRO == PRO_RMSNORM) ar[n][c] = bload32s(rsa, voff, soff);
-                if constexpr (PRO == PRO_SILUMUL) ar[n][c] = bload32s(rsx, voff, soff + 2u * G.K);
-            }
-        }
-    }
-    for (u32 i = tid; i < 4u + 2u * nseq; i += T) ctr[i] = 0u;
+    // The CU's vector-memory pipe serves requests in order across waves: an activation load (an L2 hit) queued behind
+    // another wave's plane loads waits for HBM (measured: 5000 cycles instead of 1200).  So every activation load of
+    // the block is issued before the first plane load; this barrier (the LDS counters are zero behind it) costs the
+    // launch skew of the last wave, ~800 cycles.
+    if (tid < 4) ctr[tid] = 0u;
     if (tid < 16) reinterpret_cast<u32 *>(zero32)[tid] = 0u;
-    // The only hardware barrier of the kernel, as early as possible: behind it the flags are zero and every activation
-    // load is in the memory pipe ahead of the plane stream.  (Later a producer may sit in the memory issue queue
-    // for microseconds -- issuing blocks once the queues are full -- so it can not take part in barriers.)
     __syncthreads();
-
-    if (producer) {
-        if (a.xflags & 2u) return;
-        // ------------------------------------------------------------ producer: publish what lands, stream the rest
-        auto publish = [&]() {  // tiles are published in issue order
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (l == 0) __hip_atomic_store(ready + it_seq(pub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            it_next(pub);
-            it_skip(pub);
-            published++;
-        };
-        // vector-memory operations of this wave still in flight (IB_STS.VM_CNT, bits 3:0 and 23:22): loads return in
-        // order, so everything but the youngest ceil(vmcnt / LPS) steps has landed in LDS
-        auto publish_landed = [&]() {
-            const u32 sts = __builtin_amdgcn_s_getreg(7 | (0 << 6) | (31 << 11));
-            const u32 vm = (sts & 0xFu) | ((sts >> 18) & 0x30u);
-            const u32 inflight = (vm + LPS - 1u) / LPS;
-            while (issued - published > inflight) publish();
-        };
-        while (iss.rd < rounds) {
-            const u32 seq = it_seq(iss);
-            if (seq >= R) {
-                // ring slot still held by its consumer: keep publishing what lands while waiting for the release
-                while (__hip_atomic_load(done + (seq - R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
-                    publish_landed();
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            issue_step();
-            publish_landed();
+    // The LUT rows of the block ride in the queue of the last wave as nlut pseudo steps of exactly LPS loads each
+    // (padded with out-of-range loads), behind its first item: loads return in order, so its vmcnt bookkeeping stays in
+    // units of steps, and the LUT is in LDS once it has seen its last tile.
+    const u32 nlut = (w == W - 1u && !(a.xflags & 16u)) ? lut_bytes / (LPS * 1024u) : 0u;
+    u32 lut_after = 0;  // pseudo steps queued behind the steps issued so far
+    if (!early) {
+        // late wave: first item now (this may block in the issue queue: nothing else to do before the image is built)
+        while (iq_n < my_steps && iq_n < S && (!(a.xflags & 256u) || iq_n < cpi * first_late)) issue();
+        if (nlut) {
+            const u32x4 rl = make_rsrc(a.lut, a.N * (u32)NP * 2u);
+            const u32 want = a.RGB * 16u * (u32)NP * 2u;
+            for (u32 o = 0; o < lut_bytes; o += 1024u)
+                dma16(rl, (u32)(uintptr_t)lutb + o, o + 16u * l < want ? rg0 * 16u * (u32)NP * 2u + o + 16u * l : OOB);
+            lut_after = nlut;
         }
-        while (published < issued) {
-            publish_landed();
-            if (published < issued) __builtin_amdgcn_s_sleep(1);
-        }
-        stamp(3);
-        return;
     }
+    const u32 lut_from = iq_n;  // the pseudo steps sit behind steps 0 .. lut_from-1
+    stamp(6);
 
-    // ================================================================ consumers
-    if (a.xflags & 64u) return;
-    const u32 r = l & 15u, kb = l >> 4;
-    wait_vm<0>();
+    float X = 0.f;
+    int sb = 127;
+    if (early) {
+    wait_vm<0>();  // the activation loads (an early wave has nothing else in flight)
 #pragma unroll
     for (u32 n = 0; n < (u32)NI; n++) {
         tie4(xr[n]);
-        if constexpr (PRO != PRO_NONE) tie4(ar[n]);
+        tie4(xh[n]);
+        if constexpr (PRO != PRO_NONE) {
+            tie4(ar[n]);
+            tie4(ah[n]);
+        }
+#pragma unroll
+        for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
+            xr[n][c] |= xh[n][c] << 16;
+            if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
+        }
     }
-    stamp(6);
-
-    // ---------------------------------------------------------------- 1. statistics -> one consumer barrier
+    // ---------------------------------------------------------------- 1. statistics -> barrier
     // RMSNorm: sum x^2 and max |x * w| (bounds the normalised maximum); otherwise max |x'| of the transformed vector
     float nscale = 0.f, xmax = 0.f;
     {
@@ -369,16 +346,17 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         mx = wave_reduce<true>(mx);
         if constexpr (PRO == PRO_RMSNORM) ss = wave_reduce<false>(ss);
         if (l == 63) {
-            red[k] = mx;
-            if constexpr (PRO == PRO_RMSNORM) red[16 + k] = ss;
+            red[w] = mx;
+            if constexpr (PRO == PRO_RMSNORM) red[16 + w] = ss;
         }
-        arrive_and_wait(ctr + 0, NC, l);
+        arrive(ctr + 0, l);
+        wait_count(ctr + 0, E);
 #pragma unroll
-        for (u32 i = 0; i < NC; i++) xmax = fmaxf(xmax, red[i]);
+        for (u32 i = 0; i < E; i++) xmax = fmaxf(xmax, red[i]);
         if constexpr (PRO == PRO_RMSNORM) {
             float tot = 0.f;
 #pragma unroll
-            for (u32 i = 0; i < NC; i++) tot += red[16 + i];
+            for (u32 i = 0; i < E; i++) tot += red[16 + i];
             nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
             xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
         }
@@ -387,16 +365,15 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
 
     // ---------------------------------------------------------------- 2. transform, scale, split, scatter
     const int ksh = piece_shift(xmax);
-    const int sb = 127 - ksh;  // E8M0 scale of every B block
     {
         const uint16_t k16 = pow2_f16(ksh);
         const h2v kk = u2h2((u32)k16 * 0x10001u), one2 = u2h2(0x3C003C00u);
         float xsum = 0.f;
 #pragma unroll
         for (u32 n = 0; n < (u32)NI; n++) {
-            const u32 chunk = (k >> 1) + n * (TC / 128u);
+            const u32 chunk = (w >> 1) + n * (E / 2u);
             if (chunk >= G.nchunks) continue;
-            const u32 t = pt, jp = pjp, kbi = t >> 3, v = t & 7u;
+            const u32 t = pt, g = t >> 3, hh = (t >> 2) & 1u, vA = t & 3u;
             u32 P[4][4];  // [piece][c]
 #pragma unroll
             for (u32 c = 0; c < 4; c++) {
@@ -414,59 +391,63 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
                     if (p < 3) rem = rem - u2h2(P[p][c]);
                 }
             }
+            unsigned char *img = bimg + bimg4_off(chunk, pb, hh, 0u) + 32u * g + 8u * vA;
 #pragma unroll
             for (u32 p = 0; p < 4; p++) {
-                // image bytes B = 0..3 hold c = 3..0; the bf8 of weight 2jp is byte 1 of P, of weight 2jp+1 byte 3
-                const u32 hi = __builtin_amdgcn_perm(P[p][3], P[p][2], 0x03070105u);
-                const u32 lo = __builtin_amdgcn_perm(P[p][1], P[p][0], 0x03070105u);
-                const u32 w0 = __builtin_amdgcn_perm(lo, hi, 0x05040100u), w1 = __builtin_amdgcn_perm(lo, hi, 0x07060302u);
-                *reinterpret_cast<u32 *>(bimg + bimg_off(chunk, 7u - 2u * jp, kbi, p) + 4u * v) = w0;
-                *reinterpret_cast<u32 *>(bimg + bimg_off(chunk, 6u - 2u * jp, kbi, p) + 4u * v) = w1;
+                // k = 32g + 8v + i, nibble i = 2 (3 - c) + (s >> 2): bytes (i = 0..3) = c3.j(7-b), c3.j(3-b), c2.j(7-b), c2.j(3-b);
+                // the bf8 of weight 7 - b is byte 1 of P (low half), of weight 3 - b byte 3 (high half)
+                *reinterpret_cast<u32 *>(img + p * 128u) = __builtin_amdgcn_perm(P[p][2], P[p][3], 0x07050301u);
+                *reinterpret_cast<u32 *>(img + p * 128u + 4u) = __builtin_amdgcn_perm(P[p][0], P[p][1], 0x07050301u);
             }
         }
         xsum = wave_reduce<false>(xsum);
-        if (l == 63) red[32 + k] = xsum;
+        if (l == 63) {
+            red[32 + w] = xsum;
+            if (w == 0) red[48] = __builtin_bit_cast(float, (u32)(127 - ksh));  // E8M0 scale of every B block, for the late waves
+        }
     }
     stamp(1);
-    arrive_and_wait(ctr + 1, NC, l);
+    arrive(ctr + 1, l);
+    }  // early
+    wait_count(ctr + 1, E);  // the B image is complete
     stamp(2);
-    float X = 0.f;
 #pragma unroll
-    for (u32 i = 0; i < NC; i++) X += red[32 + i];
+    for (u32 i = 0; i < E; i++) X += red[32 + i];
+    sb = (int)__builtin_bit_cast(u32, red[48]);
 
-    // ---------------------------------------------------------------- 3. main loop: the steps of this consumer
+    // ---------------------------------------------------------------- 3. main loop: the steps of this wave
+    // the rest of the ring is requested now: the first tiles of the block have (mostly) landed, the queues have room
+    while (iq_n < my_steps && iq_n < S) issue();
+    const u32 r = l & 15u, kb = l >> 4;
     const u32 col = l & 15u;
     const bool bcol = col < 4u;
     const u32 offA0 = atile_unit(r, 2u * kb) * 16u, offA1 = atile_unit(r, 2u * kb + 1u) * 16u;
     v4f acc[NP1];
 #pragma unroll
     for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
-    u32 seq = k, slot_i = k;  // slot_i = seq % R, tracked without a division (R >= NC)
-    for (u32 item = k; item < nIt; item += NC) {
-        for (u32 c = 0; c < cpi; c++, seq += NC, slot_i = slot_i + NC >= R ? slot_i + NC - R : slot_i + NC) {
-            const u32 chunk = (item & (CS - 1u)) * cpi + c;
-            if (chunk >= G.nchunks) continue;
-            if (!(a.xflags & 2u)) spin_nonzero(ready + seq);
-            u32 Wd[BITS][8];
-            {
-                const unsigned char *slot = ring + slot_i * SLOT;
+    u32 cq_item = item0, cq_c = 0, cq_slot = 0;
+    for (u32 q = 0; q < my_steps; q++) {
+        const u32 chunk = (cq_item & (CS - 1u)) * cpi + cq_c;
+        const u32 after = iq_n - 1u - q + (q < lut_from ? lut_after : 0u);  // (pseudo) steps requested behind this one
+        wait_vm_steps<LPS>(after);
+        u32 Wd[BITS][8];
+        {
+            const unsigned char *slot = ring + cq_slot * SLOT;
 #pragma unroll
-                for (int p = 0; p < BITS; p++) {
-                    const uint4 a0 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA0);
-                    const uint4 a1 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA1);
-                    Wd[p][0] = a0.x, Wd[p][1] = a0.y, Wd[p][2] = a0.z, Wd[p][3] = a0.w;
-                    Wd[p][4] = a1.x, Wd[p][5] = a1.y, Wd[p][6] = a1.z, Wd[p][7] = a1.w;
-                }
+            for (int p = 0; p < BITS; p++) {
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA0);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA1);
+                Wd[p][0] = a0.x, Wd[p][1] = a0.y, Wd[p][2] = a0.z, Wd[p][3] = a0.w;
+                Wd[p][4] = a1.x, Wd[p][5] = a1.y, Wd[p][6] = a1.z, Wd[p][7] = a1.w;
             }
-            if (R < nseq) {
-                // the tile is in registers: hand the ring slot back to the producer
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (l == 0) __hip_atomic_store(done + seq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (a.xflags & 1u) {
-                acc[0][0] += __builtin_bit_cast(float, Wd[0][0] ^ Wd[BITS - 1][7]);
-                continue;
-            }
+        }
+        if (iq_n < my_steps) {
+            // refill this slot with the step S ahead: the ds_reads above must have returned first
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue();
+        }
+        if (++cq_slot == S) cq_slot = 0;
+        if (chunk < G.nchunks && !(a.xflags & 1u)) {
             // plane-subset words: code bit i lives in plane BITS-1-i
             u32 PW[NP1][8];
 #pragma unroll
@@ -476,55 +457,64 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
                 for (int v = 0; v < 8; v++)
                     PW[cm - 1][v] = rest ? (PW[rest - 1][v] & Wd[BITS - 1 - i0][v]) : Wd[BITS - 1 - i0][v];
             }
-            // B operand (activation pieces) double-buffered over the bit position s
-            const unsigned char *bbase = bcol ? bimg + bimg_off(chunk, 0u, kb, col) : zero32;
-            const u32 bstep = bcol ? 512u : 0u;  // bimg_off(.., s+1, ..) - bimg_off(.., s, ..) = 4 pieces * 4 kb * 32 B
+            // B operand (activation pieces) double-buffered over the 8 (nibble bit b, word half h) MFMAs per subset
+            const unsigned char *bbase = bcol ? bimg + bimg4_off(chunk, 0u, 0u, col) + 16u * kb : zero32;
+            const u32 bstep = bcol ? 512u : 0u, bhalf = bcol ? 64u : 0u;  // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
             uint4 bn0 = *reinterpret_cast<const uint4 *>(bbase);
-            uint4 bn1 = *reinterpret_cast<const uint4 *>(bbase + 16);
+            uint4 bn1 = *reinterpret_cast<const uint4 *>(bbase + bhalf);
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
+            for (int bh = 0; bh < 8; bh++) {
+                const int nb = bh >> 1, hh = bh & 1;
                 const uint4 b0 = bn0, b1 = bn1;
-                if (s < 7) {
-                    bn0 = *reinterpret_cast<const uint4 *>(bbase + (u32)(s + 1) * bstep);
-                    bn1 = *reinterpret_cast<const uint4 *>(bbase + (u32)(s + 1) * bstep + 16);
+                if (bh < 7) {
+                    bn0 = *reinterpret_cast<const uint4 *>(bbase + (u32)(bh + 1) * bstep);
+                    bn1 = *reinterpret_cast<const uint4 *>(bbase + (u32)(bh + 1) * bstep + bhalf);
                 }
-                // keep the loads of s + 1 ahead of the MFMAs of s (the scheduler otherwise sinks them behind the
+                // keep the loads of the next MFMA group ahead of this one (the scheduler otherwise sinks them behind the
                 // MFMAs into a single B buffer and exposes the LDS latency 8 times per step)
                 __builtin_amdgcn_sched_barrier(0);
                 v8i Bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
 #pragma unroll
                 for (int cm = 1; cm < NP; cm++) {
-                    v8i Av;
+                    v4i A4;  // FP4 operand: 4 registers (the upper half of the builtin's vector is ignored for cbsz = 4)
 #pragma unroll
-                    for (int v = 0; v < 8; v++) Av[v] = (int)extract(PW[cm - 1][v], s);
-                    acc[cm - 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Av, Bv, acc[cm - 1], 1, 1, 0, scale_byte(s), 0, sb);
+                    for (int v = 0; v < 4; v++) A4[v] = (int)extract4(PW[cm - 1][4 * hh + v], nb);
+                    mfma_f4_bf8(acc[cm - 1], A4, Bv, (u32)scale_byte4(nb), (u32)sb);
                 }
             }
+        } else if (a.xflags & 1u) {
+            acc[0][0] += __builtin_bit_cast(float, Wd[0][0] ^ Wd[BITS - 1][7]);
         }
-        // item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
+        if (++cq_c == cpi) {
+            // item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
 #pragma unroll
-        for (int cm = 0; cm < NP1; cm++) {
-            v4f v = acc[cm];
+            for (int cm = 0; cm < NP1; cm++) {
+                mfma_drain(acc[cm]);
+                v4f v = acc[cm];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float f = v[q];
-                f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
-                f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
-                v[q] = f;
+                for (int q4 = 0; q4 < 4; q4++) {
+                    float f = v[q4];
+                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
+                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
+                    v[q4] = f;
+                }
+                // part[item][subset][row]: lane (col 0, kb) owns rows 4kb..4kb+3
+                if (col == 0u) *reinterpret_cast<v4f *>(part + ((size_t)cq_item * NP1 + cm) * 16u + 4u * kb) = v;
+                acc[cm] = (v4f){0.f, 0.f, 0.f, 0.f};
             }
-            // part[item][subset][row]: lane (col 0, kb) owns rows 4kb..4kb+3
-            if (col == 0u) *reinterpret_cast<v4f *>(part + ((size_t)item * NP1 + cm) * 16u + 4u * kb) = v;
-            acc[cm] = (v4f){0.f, 0.f, 0.f, 0.f};
+            cq_c = 0;
+            cq_item = item_after(cq_item);
         }
     }
+    wait_vm<0>();  // (the LUT loads of the last wave when it had no tile)
     stamp(3);
-    arrive_and_wait(ctr + 2, NC, l);
+    __syncthreads();
     stamp(4);
 
     // ---------------------------------------------------------------- 4. epilogue: coefficients x plane sums
     // lane = (output row, Moebius index c): term c = coef[c] * (c == 0 ? sum(x) : T[c]); the NP terms of a row sit in
     // NP adjacent lanes and are added by a fixed DPP tree (deterministic order)
-    for (u32 e = ctid; e < a.RGB * 16u * (u32)NP; e += TC) {
+    for (u32 e = tid; e < a.RGB * 16u * (u32)NP; e += T) {
         const u32 i = e / (u32)NP, c = e % (u32)NP;
         const u32 rgl = i >> 4, rr = i & 15u;
         const u32 row = (rg0 + rgl) * 16u + rr;
@@ -560,7 +550,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
 }
 
 struct PlaneCfg {
-    u32 grid, T, RGB, log2CS, cpi, S, NI;
+    u32 grid, T, RGB, log2CS, cpi, S, NI, E;
     size_t smem;
 };
 
@@ -582,37 +572,41 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     const u32 nchunks = K / 1024u + ((K % 1024u) ? 1u : 0u);
     const u32 RGt = (N + 15u) / 16u;
     const u32 ncu = (u32)cus();
-    const u32 W = bits == 2 ? 16u : 8u, NC = W - W / 4u;
+    const u32 W = bits == 2 ? 16u : 8u;
     c.T = 64u * W;
     // one block per CU when the matrix is big enough
     u32 rgb = (RGt + ncu - 1u) / ncu;
     if (rgb < 1) rgb = 1;
     c.RGB = rgb;
     c.grid = (RGt + rgb - 1u) / rgb;
-    // split K of a row group over 2^log2CS items until the block has at least two items per consumer wave
+    // split K of a row group over 2^log2CS items until the block has ~1.5 items per wave
     u32 lcs = 0;
-    while ((rgb << lcs) < 2u * NC && (2u << lcs) <= nchunks) lcs++;
+    while (2u * (rgb << lcs) < 3u * W && (2u << lcs) <= nchunks) lcs++;
     const int envcs = gq_env_int("GQ_PL_LOG2CS", -1);
     if (envcs >= 0 && (1u << envcs) <= nchunks) lcs = (u32)envcs;
     c.log2CS = lcs;
     c.cpi = (nchunks + (1u << lcs) - 1u) >> lcs;
     const u32 nIt = rgb << lcs;
-    const u32 nseq = ((nIt + NC - 1u) / NC) * c.cpi * NC;
-    if (nseq > 2048u) return false;
-    // ring: the whole share of the block when it fits next to the B image, else as many slots as fit
+    const u32 steps_w = ((nIt + W - 1u) / W) * c.cpi;
+    // per-wave ring: as many tiles as the wave has / as fit next to the B image (<= 4: vmcnt immediates)
     const u32 np1 = (1u << bits) - 1u;
-    const size_t lutb = ((size_t)rgb * 16u * (np1 + 1u) * 2u + 1023u) & ~(size_t)1023u;
-    const size_t fixed = lutb + (size_t)nchunks * 4096u + 64u + 64u * 4u + 16u + 8u * (size_t)nseq + (size_t)nIt * np1 * 16u * 4u;
+    const size_t lps_bytes = 2048u * (size_t)bits;  // LPS loads of 1 KiB
+    const size_t lutb = ((size_t)rgb * 16u * (np1 + 1u) * 2u + lps_bytes - 1u) / lps_bytes * lps_bytes;
+    const size_t fixed = lutb + (size_t)nchunks * 4096u + 64u + 64u * 4u + (size_t)nIt * np1 * 16u * 4u;
     const size_t slot = 2048u * (size_t)bits, lds = 160u * 1024u;
-    if (fixed + slot > lds) return false;
-    u32 R = (u32)((lds - fixed) / slot);
-    if (R > nseq) R = nseq;
-    if (R < (nseq < NC ? nseq : NC)) return false;  // at least one tile per consumer wave
+    if (fixed + W * slot > lds) return false;
+    u32 S = (u32)((lds - fixed) / (W * slot));
+    const u32 nlut = (u32)(lutb / lps_bytes);
+    if (nlut > 3u) return false;
+    if (S > 5u - nlut - 1u) S = 5u - nlut - 1u;  // <= 4 steps behind the awaited one (vmcnt immediates)
+    if (S > steps_w) S = steps_w;
     const int envs = gq_env_int("GQ_PL_S", 0);
-    if (envs >= 1 && (u32)envs < R) R = (u32)envs;
-    c.S = R;
-    c.NI = (nchunks * 128u + NC * 64u - 1u) / (NC * 64u);  // prologue passes
-    c.smem = fixed + (size_t)R * slot;
+    if (envs >= 1 && (u32)envs < S) S = (u32)envs;
+    c.S = S;
+    const u32 E = W / 2u;  // early waves (activation prologue); more of them was measured slower for every shape
+    c.E = E;
+    c.NI = (nchunks * 128u + E * 64u - 1u) / (E * 64u);  // prologue passes
+    c.smem = fixed + (size_t)W * S * slot;
     return true;
 }
 
@@ -633,12 +627,13 @@ int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t 
 
 template <int BITS, int PRO>
 int launch_plane_ni(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
-    constexpr u32 NIMAX = BITS == 2 ? 3u : 6u;  // 2048 items over 768 / 384 consumer lanes
-    if (c.NI > NIMAX) return GQ_ENOTSUP;
+    // K <= 16384 -> at most 2048 items over 512 / 256 lanes
     if (c.NI <= 1) return launch_plane_inst<BITS, PRO, 1>(a, c, M, s);
     if (c.NI == 2) return launch_plane_inst<BITS, PRO, 2>(a, c, M, s);
-    if (c.NI == 3) return launch_plane_inst<BITS, PRO, 3>(a, c, M, s);
-    if constexpr (BITS != 2) return launch_plane_inst<BITS, PRO, 6>(a, c, M, s);
+    if (c.NI <= 4) return launch_plane_inst<BITS, PRO, 4>(a, c, M, s);
+    if constexpr (BITS != 2) {
+        if (c.NI <= 8) return launch_plane_inst<BITS, PRO, 8>(a, c, M, s);
+    }
     return GQ_ENOTSUP;
 }
 

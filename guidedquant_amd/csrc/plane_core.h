@@ -95,6 +95,40 @@ GQP_HD void locate_x(const Geom &G, u32 e, u32 &chunk, u32 &s, u32 &kb, u32 &v, 
 }
 
 
+// ---- FP4 A operand (v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = 4, blgp = 1: A = e2m1 nibbles, B = bf8 bytes).
+// Measured (tools/ubench/fp4_probe.hip): single-bit nibble patterns 0x1 / 0x2 / 0x4 are 0.5 / 1 / 2 (0x8 is -0);
+// A element (lane group g = lane / 16, VGPR v = 0..3, nibble i) is k = 32 g + 8 v + i; the bf8 B operand keeps
+// k = 64 (v / 4) + 16 kb + 4 (v % 4) + byte.  The mixed MFMA costs the same matrix-pipe time as bf8 x bf8 but its A
+// operand is 4 registers for the same 32 weights per lane: half the v_and_b32 per weight.
+//   nibble bit b = 0..2:  w & (0x11111111 << b);     b = 3 (the sign position): (w >> 1) & 0x44444444
+GQP_HD u32 extract4(u32 w, int b) { return b == 3 ? ((w >> 1) & 0x44444444u) : (w & (0x11111111u << b)); }
+// E8M0 scale byte cancelling the pattern value (0.5, 1, 2, 2)
+GQP_HD int scale_byte4(int b) { return b == 0 ? 128 : (b == 1 ? 127 : 126); }
+// Lane (row r, group g) holds the plane words wd = 0..7 of virtual lanes t = 8 g + wd.  MFMA (b, h) takes the words
+// 4 h + v (v = 0..3) masked at nibble bit b: nibble i of word wd is plane bit 4 i + b = byte B = i / 2 (c = 3 - B),
+// bit s = 4 (i & 1) + b of that byte, i.e. weight j = 7 - s of virtual lane t.
+// B image: [chunk][b][h][piece][k = 0..127] bytes, k = 32 g + 8 v + i; lane (col = piece, kb) of the MFMA reads the 16
+// bytes at 16 kb and the 16 bytes at 64 + 16 kb.
+GQP_HD u32 bimg4_off(u32 chunk, u32 b, u32 h, u32 piece) { return chunk * 4096u + (((b * 2u + h) * 4u + piece) << 7); }
+// activation e -> chunk, b, h, k  (inverse of the above)
+GQP_HD void locate_x4(const Geom &G, u32 e, u32 &chunk, u32 &b, u32 &h, u32 &k) {
+    u32 r, tp;
+    if (e < 1024u * G.nfull) {
+        chunk = e / 1024u;
+        r = e % 1024u;
+        tp = 32u;
+    } else {
+        chunk = G.nfull;
+        r = e - 1024u * G.nfull;
+        tp = G.eff;
+    }
+    const u32 c = r / (8u * tp), t = (r % (8u * tp)) / 8u, j = r % 8u, s = 7u - j;
+    b = s & 3u;
+    h = (t >> 2) & 1u;
+    const u32 g = t >> 3, v = t & 3u, i = 2u * (3u - c) + (s >> 2);
+    k = 32u * g + 8u * v + i;
+}
+
 // ---- A tile in LDS.  One step (16 rows x one 1024-weight chunk) of one plane is 16 lines of 128 B = 128 units of
 // 16 B, deposited by two direct-to-LDS loads (buffer_load_dwordx4 ... lds: LDS address = base + 16 * lane, so the
 // only freedom is WHICH global 16 B each lane fetches).  Instruction h (0/1) carries rows 8h..8h+7, lane = 8*a + b:

@@ -1,0 +1,34 @@
+// for an A one-hot (lane la, VGPR va, nibble ia) find every B single byte (lane lb, VGPR vb, byte bb) with a nonzero product
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ void k(float *out, int la, int va, int ia) {
+    const int q = blockIdx.x, lb = q >> 5, vb = (q >> 2) & 7, bb = q & 3;
+    const int l = threadIdx.x;
+    v8i a = {0, 0, 0, 0, 0, 0, 0, 0}, b = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        if (l == la && v == va) a[v] = 2 << (4 * ia);
+        if (l == lb && v == vb) b[v] = 0x3C << (8 * bb);
+    }
+    v4f c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 1, 0, 127, 0, 127);
+    float s = fabsf(c[0]) + fabsf(c[1]) + fabsf(c[2]) + fabsf(c[3]);
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if (l == 0) out[q] = s;
+}
+int main() {
+    float *d, h[2048];
+    hipMalloc(&d, 2048 * 4);
+    for (int la : {0, 16, 17, 32, 48})
+        for (int va : {0, 3})
+            for (int ia : {0, 5}) {
+                hipLaunchKernelGGL(k, dim3(2048), dim3(64), 0, 0, d, la, va, ia);
+                hipMemcpy(h, d, 2048 * 4, hipMemcpyDeviceToHost);
+                printf("A(lane %d, vgpr %d, nibble %d) matches B:", la, va, ia);
+                for (int q = 0; q < 2048; q++) if (h[q] != 0.f) printf(" (lane %d = col %d kb %d, vgpr %d, byte %d)=%g", q >> 5, (q >> 5) & 15, q >> 9, (q >> 2) & 7, q & 3, h[q]);
+                printf("\n");
+            }
+    return 0;
+}

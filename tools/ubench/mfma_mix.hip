@@ -44,8 +44,21 @@ __global__ void k(float *out, const int *src, int iters) {
                 int4 x0 = p[0], x1 = p[1];
                 b = (v8i){x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             }
+            if (MODE == 6) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) a0[i] = w[i] & (0x11111111 << (j & 3));
+            }
             v8i &aa = (MODE == 2 && (j & 1)) ? a1 : a0;
-            acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 1, 1, 0, 141, 0, 127);
+            if (MODE == 5 || MODE == 6)  // fp4 x fp4
+                acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 4, 4, 0, 141, 0, 127);
+            else if (MODE == 7)  // fp4 A x bf8 B
+                acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 4, 1, 0, 141, 0, 127);
+            else if (MODE == 8)  // fp6 x fp6
+                acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 2, 2, 0, 141, 0, 127);
+            else if (MODE == 9)  // fp4 A x fp6 B
+                acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 4, 2, 0, 141, 0, 127);
+            else
+                acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 1, 1, 0, 141, 0, 127);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = w[i] * 3 + 1;
@@ -58,7 +71,7 @@ __global__ void k(float *out, const int *src, int iters) {
 template <int MODE, int NACC>
 void run(const char *name, float *out, int *src) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int wps : {1, 2, 3}) {
+    for (int wps : {1, 3, 4}) {
         int iters = 2000;
         hipLaunchKernelGGL((k<MODE, NACC>), dim3(256), dim3(256 * wps), 0, 0, out, src, 10);
         CHECK(hipDeviceSynchronize());
@@ -81,5 +94,10 @@ int main() {
     run<2, 3>("8 v_and -> A (alternating reg sets) + MFMA", out, src);
     run<3, 3>("4 v_and + MFMA", out, src);
     run<4, 3>("8 v_and + B from LDS + MFMA", out, src);
+    run<5, 3>("fp4 x fp4 MFMA only", out, src);
+    run<6, 3>("fp4 x fp4, 4 v_and -> A + MFMA", out, src);
+    run<7, 3>("fp4 A x bf8 B MFMA only", out, src);
+    run<8, 3>("fp6 x fp6 MFMA only", out, src);
+    run<9, 3>("fp4 A x fp6 B MFMA only", out, src);
     return 0;
 }

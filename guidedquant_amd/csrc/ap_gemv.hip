@@ -266,7 +266,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
     for (u32 rl2 = tid >> 5; rl2 < SPB * RS; rl2 += T >> 5) {
         const u32 row = row0 + rl2;
         uint16_t y = reduce_row(G, sv + (size_t)rl2 * svrow, t, 0u, G.nchunks);
-        if (t == 0 && row < a.N) {
+        if (a.epilogue & GQ_EPI_SILU_PAIRS) {
+            // rows (2i, 2i+1) = (gate_i, up_i) sit in the two halves of the wave: F.silu(gate) * up on fp16 values
+            // (inference/model.py:266), written to out[i]
+            const uint16_t yo = (uint16_t)__shfl_xor((int)y, 32);
+            if (t == 0 && !(tid & 32u) && row + 1u < a.N) {
+                const float gv = (float)__builtin_bit_cast(_Float16, y);
+                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, yo);
+                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
+            }
+        } else if (t == 0 && row < a.N) {
             if (a.resid) y = h_add(a.resid[(size_t)m * a.N + row], y);
             a.out[(size_t)m * a.N + row] = y;
         }
@@ -501,7 +510,7 @@ int launch_generic(const ApArgs &a, u32 M, hipStream_t s) {
 }  // namespace
 
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
-                      int bits, const void *normw, float eps, const void *resid, int pro, hipStream_t stream);
+                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream);
 
 namespace {
 
@@ -526,12 +535,13 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     const uint64_t min_w = (uint64_t)gq_env_int("GQ_PL_MIN_MWEIGHTS", 20) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 2);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {
-        int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, s);
+        int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s);
         if (rc != GQ_ENOTSUP) return rc;
     }
     const uint64_t qbytes = (uint64_t)bits * a.N * (a.K / 8u);
     if (!force_generic && bits <= 4 && qbytes < 0x7FFFFFFFull && pick_quad_cfg(a.N, a.K, bits, c) &&
-        (((uintptr_t)a.qw | (uintptr_t)a.x | (uintptr_t)a.normw) & 15u) == 0 && ((uintptr_t)a.lut & 15u) == 0) {
+        (((uintptr_t)a.qw | (uintptr_t)a.x | (uintptr_t)a.normw) & 15u) == 0 && ((uintptr_t)a.lut & 15u) == 0 &&
+        !((a.epilogue & GQ_EPI_SILU_PAIRS) && ((c.SPB * c.RS) & 1u))) {
         a.RS = c.RS;
         a.SPB = c.SPB;
         switch (bits) {
@@ -540,8 +550,8 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
             default: return launch_quad<4>(a, c, M, pro, s);
         }
     }
-    if (pro != PRO_NONE)
-        return gq_fail(GQ_ENOTSUP, "fused prologue needs bits in 2..4, K % 128 == 0 and 16-byte aligned buffers.");
+    if (pro != PRO_NONE || (a.epilogue & GQ_EPI_SILU_PAIRS))
+        return gq_fail(GQ_ENOTSUP, "fused prologue / pair epilogue needs bits in 2..4, K % 128 == 0 and 16-byte aligned buffers.");
     if ((uintptr_t)a.x & 15u) return gq_fail(GQ_EINVAL, "input must be 16-byte aligned.");
     switch (bits) {
         case 2: return launch_generic<2>(a, M, s);
@@ -592,6 +602,8 @@ extern "C" int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *q
     a.epilogue = epilogue;
     if ((epilogue & GQ_EPI_RESIDUAL) && !residual) return gq_fail(GQ_EINVAL, "RESIDUAL epilogue needs a residual pointer.");
     if ((epilogue & GQ_PRO_SILU_MUL) && norm_weight) return gq_fail(GQ_EINVAL, "RMSNorm and SiLU-mul prologues are exclusive.");
+    if ((epilogue & GQ_EPI_SILU_PAIRS) && ((epilogue & GQ_EPI_RESIDUAL) || (N & 1u)))
+        return gq_fail(GQ_EINVAL, "SILU_PAIRS epilogue needs an even N and excludes the residual epilogue.");
     return ap_gemv_dispatch(a, 1, bits, (hipStream_t)stream);
 }
 

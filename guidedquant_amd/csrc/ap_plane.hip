@@ -42,6 +42,7 @@ struct PlaneArgs {
     u32 log2CS;  // a row group's chunks are split over 2^log2CS wave items
     u32 cpi;     // chunks per item
     u32 S;       // LDS ring slots (steps) per wave
+    u32 pairs;   // GQ_EPI_SILU_PAIRS: rows are (gate, up) pairs, out[i] = silu(y[2i]) * y[2i+1]
     u32 xflags;  // ablation experiments (GQ_PL_XFLAGS): 1 no MFMA work, 2 no steps at all, 8 no activation loads, 16 no LUT, 32 empty kernel,
                  // 256 late waves request only their first item up front, 1024 no plane loads (the MFMA phase runs on stale LDS)
     float eps;
@@ -540,8 +541,16 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x4E, 0xF, 0xF, false));
         if constexpr (NP >= 8) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x141, 0xF, 0xF, false));
         if constexpr (NP >= 16) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x140, 0xF, 0xF, false));
-        if (c == 0u && row < a.N) {
-            _Float16 yh = (_Float16)y;
+        _Float16 yh = (_Float16)y;
+        if (a.pairs) {
+            // the partner row of the pair sits NP lanes away: F.silu(gate) * up on fp16 values -- inference/model.py:266
+            const _Float16 yo = __builtin_bit_cast(_Float16, (uint16_t)__shfl_xor((int)__builtin_bit_cast(uint16_t, yh), NP));
+            if (c == 0u && !(rr & 1u) && row + 1u < a.N) {
+                const float gv = (float)yh;
+                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * yo;
+                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
+            }
+        } else if (c == 0u && row < a.N) {
             if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[(size_t)m * a.N + row]) + yh;
             a.out[(size_t)m * a.N + row] = __builtin_bit_cast(uint16_t, yh);
         }
@@ -653,7 +662,7 @@ extern "C" void gq_debug_set_timing_buffer(void *p) { g_dbg = (unsigned long lon
 
 // returns GQ_ENOTSUP when the shape is not served by this path (caller falls back to the exact kernels)
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
-                      int bits, const void *normw, float eps, const void *resid, int pro, hipStream_t stream) {
+                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
     if (bits < 2 || bits > 4) return GQ_ENOTSUP;
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
@@ -673,6 +682,7 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
     a.log2CS = c.log2CS;
     a.cpi = c.cpi;
     a.S = c.S;
+    a.pairs = pairs ? 1u : 0u;
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);
     a.eps = eps;
     a.dbg = g_dbg;

@@ -20,6 +20,7 @@ Model table: the reference's entries (model.py:53-61) plus Llama-3.2-1B-Instruct
 BASELINE.json's configs name and the reference table lacks.
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -295,6 +296,15 @@ class Transformer(nn.Module):
                 x=torch.zeros(c.dim, **f16), h=torch.zeros(c.dim, **f16), y=torch.zeros(c.dim, **f16),
                 qkv=torch.zeros((c.n_head + 2 * c.n_local_heads) * c.head_dim, **f16),
                 gu=torch.zeros(2 * c.intermediate_size, **f16), logits=torch.zeros(1, 1, c.vocab_size, **f16))
+            # Gate/up pairing (GQ_EPI_SILU_PAIRS): a row-interleaved copy (gate_0, up_0, gate_1, up_1, ..) of every fused
+            # w1w3 tensor lets the w1w3 GEMV write silu(gate) * up directly (model.py:266 of the reference), so w2 reads a
+            # plain vector.  The module buffers keep the reference layout [w1; w3] (state-dict contract, prefill path).
+            self._native["pairs"] = None
+            if os.environ.get("GQ_NATIVE_PAIRS", "1") != "0":
+                inter = c.intermediate_size
+                perm = torch.stack((torch.arange(inter, device=dev), torch.arange(inter, 2 * inter, device=dev)), dim=1).reshape(-1)
+                self._native["pairs"] = [(b.feed_forward.w1w3.qweight[:b.feed_forward.w1w3.bitwidth, perm, :].contiguous(),
+                                          b.feed_forward.w1w3.lut[perm].contiguous()) for b in self.layers]
         return self._native
 
     def native_embed(self, tok: Tensor, x: Tensor):
@@ -308,11 +318,11 @@ class Transformer(nn.Module):
         st = _lib.current_stream_ptr()
         c = self.config
         b = self._native_state()
-        h, y, qkv, gu = b["h"], b["y"], b["qkv"], b["gu"]
+        h, y, qkv, gu, pairs = b["h"], b["y"], b["qkv"], b["gu"], b["pairs"]
         ck = _lib.check
         scale = 1.0 / math.sqrt(c.head_dim)
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2  # bytes per batch slot
-        for blk in self.layers[l0:l1]:
+        for li, blk in enumerate(self.layers[l0:l1]):
             at, ff = blk.attention, blk.feed_forward
             ck(L.gq_anyprec_gemv_fused(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
                                        at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
@@ -322,6 +332,14 @@ class Transformer(nn.Module):
                                 y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, st), "attn")
             ck(L.gq_anyprec_gemv_fused(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
                                        at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, st), "wo")
+            if pairs is not None:
+                pq, pl = pairs[l0 + li]
+                ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), pq.data_ptr(), pl.data_ptr(), 2 * c.intermediate_size, c.dim,
+                                           ff.w1w3.bitwidth, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 4, st),
+                   "w1w3")
+                ck(L.gq_anyprec_gemv_fused(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,
+                                           c.intermediate_size, ff.w2.bitwidth, None, 0.0, h.data_ptr(), 1, st), "w2")
+                continue
             ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(),
                                        2 * c.intermediate_size, c.dim, ff.w1w3.bitwidth,
                                        blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 0, st), "w1w3")

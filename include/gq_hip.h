@@ -35,6 +35,8 @@ extern "C" {
 #define GQ_EPI_NONE 0u
 #define GQ_EPI_RESIDUAL 1u  /* out[n] = residual[n] + y[n]          (fp16 add) */
 #define GQ_PRO_SILU_MUL 2u  /* prologue: x holds 2K values (gate|up), the GEMV input is silu(x[0:K]) * x[K:2K] */
+#define GQ_EPI_SILU_PAIRS 4u /* epilogue: the rows are (gate_i, up_i) pairs (row 2i, row 2i+1); out has N/2 elements,
+                              * out[i] = silu(y[2i]) * y[2i+1] with the reference's fp16 rounding points */
 
 int gq_version(void);
 const char *gq_last_error(void);
@@ -110,6 +112,9 @@ int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale
  *   norm_weight  fp16 [K] or NULL (no RMSNorm);  eps used when norm_weight != NULL
  *   flags        GQ_EPI_RESIDUAL: out[n] = residual[n] + y[n]
  *                GQ_PRO_SILU_MUL: x is fp16 [2K]; the GEMV input is silu(x[0:K]) * x[K:2K]
+ *                GQ_EPI_SILU_PAIRS: qweight / lut rows are interleaved gate/up pairs (the caller permuted the fused
+ *                                 [w1; w3] tensor, model.py:259-266): out fp16 [N/2], out[i] = silu(y[2i]) * y[2i+1];
+ *                                 exclusive with GQ_EPI_RESIDUAL; N even
  */
 int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
                           uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,

@@ -5,6 +5,8 @@ The quantized GEMVs are bit-identical in both paths (exact mode); the tolerance 
 arithmetic, reduction order of the norms and the dense lm_head accumulation order."""
 import math
 
+import numpy as np
+
 import pytest
 
 torch = pytest.importorskip("torch")
@@ -227,3 +229,39 @@ def test_pipelined_decoder_native_single_rank():
     m2 = _tiny_model(2)
     ref = generate(m2, torch.tensor([1], dtype=torch.int32, device=d), 10, use_graph=False, temperature=0.0, top_k=32)
     assert out[0].tolist() == ref[0, 1:].tolist()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("N,K", [(28672, 4096), (2048, 1024)])
+def test_silu_pairs_epilogue_matches_separate_ops(mode, N, K):
+    """GQ_EPI_SILU_PAIRS on a row-interleaved (gate_i, up_i) tensor == the plain GEMV of the [gate; up] tensor followed
+    by F.silu(gate) * up on fp16 tensors (inference/model.py:266), in both arithmetic modes."""
+    import ctypes
+    from guidedquant_amd import _lib, pack
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    rng = np.random.default_rng(N + K)
+    q = pack.random_planes(N, K, 2, seed=N + 1)
+    lut = np.sort(rng.normal(0, 0.02, (N, 4)).astype(np.float16), axis=1)
+    x = torch.from_numpy(rng.normal(0, 1, K).astype(np.float16)).to(d)
+    qt, lt = torch.from_numpy(q).to(d), torch.from_numpy(lut).to(d)
+    half = N // 2
+    perm = torch.stack((torch.arange(half, device=d), torch.arange(half, N, device=d)), dim=1).reshape(-1)
+    qp, lp = qt[:, perm, :].contiguous(), lt[perm].contiguous()
+    _lib.check(L.gq_set_ap_mode(mode), "mode")
+    try:
+        y = torch.empty(N, dtype=torch.float16, device=d)
+        _lib.check(L.gq_anyprec_gemv_fused(x.data_ptr(), y.data_ptr(), qt.data_ptr(), lt.data_ptr(), N, K, 2, None, 0.0, None, 0, None), "plain")
+        o = torch.full((half,), float("nan"), dtype=torch.float16, device=d)
+        _lib.check(L.gq_anyprec_gemv_fused(x.data_ptr(), o.data_ptr(), qp.data_ptr(), lp.data_ptr(), N, K, 2, None, 0.0, None, 4, None), "pairs")
+        torch.cuda.synchronize()
+    finally:
+        L.gq_set_ap_mode(-1)
+    want = torch.nn.functional.silu(y[:half]) * y[half:]
+    # same fp16 rounding points; the only freedom is the last bit of exp()
+    diff = (o.float() - want.float()).abs()
+    tol = 2.0 ** -10 * want.float().abs() + 1e-7
+    assert bool((diff <= tol).all()), float((diff / (want.float().abs() + 1e-6)).max())
+    assert float((o != want).float().mean()) < 0.02
+    # validation
+    assert L.gq_anyprec_gemv_fused(x.data_ptr(), o.data_ptr(), qp.data_ptr(), lp.data_ptr(), N, K, 2, None, 0.0, y.data_ptr(), 5, None) != 0

@@ -151,8 +151,15 @@ def main():
     t_kernel_us = e0.elapsed_time(e1) * 1e3 / (reps * cfg.n_layer)
     bytes_launch = b_ap(args.bits, 2 * I, D)
     achieved = bytes_launch / t_kernel_us / 1e3  # GB/s
+    # HBM bytes per launch from the PMC counters: measured offline (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes, tools/prof_bench.sh) for exactly this kernel and shape, committed under profiles/ with its correction
+    traffic = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_w1w3_traffic.json")
+    if args.bits == 2 and cfg.dim == 4096 and I == 14336 and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "AP-GEMV w1w3 28672x4096",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": "AP-GEMV w1w3 28672x4096",
                 "avg_launch_us": round(t_kernel_us, 3), "algorithmic_bytes_per_launch": bytes_launch}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0 only, bounded sample)

@@ -126,3 +126,44 @@ extern "C" int gq_emul_plane_gemv(const uint16_t *x, const uint32_t *qw, const u
     }
     return 0;
 }
+
+// A-tile swizzle properties: (1) atile_src and atile_unit are inverse bijections over the 128 units of a tile;
+// (2) every instruction fetches 8 whole 128-byte lines; (3) the 16 lanes of a ds_read_b128 pass (rows 0..15, one
+// segment) hit 16 distinct 16-byte bank groups.  Returns 0 when all hold, else a code naming the violated property.
+extern "C" int gq_emul_atile_check() {
+    bool seen[128] = {};
+    for (u32 h = 0; h < 2; h++) {
+        int rows_seen[16] = {};
+        for (u32 lane = 0; lane < 64; lane++) {
+            u32 r, seg;
+            atile_src(h, lane, r, seg);
+            if (r >= 16 || seg >= 8 || (r >> 3) != h) return 1;
+            const u32 u = atile_unit(r, seg);
+            if (u != 64 * h + lane || seen[u]) return 2;
+            seen[u] = true;
+            rows_seen[r] |= 1 << seg;
+        }
+        for (u32 r = 8 * h; r < 8 * h + 8; r++)
+            if (rows_seen[r] != 0xFF) return 3;  // the 8 segments of each of the 8 rows: whole lines
+    }
+    for (u32 seg = 0; seg < 8; seg++) {
+        int groups = 0;
+        for (u32 r = 0; r < 16; r++) groups |= 1 << (atile_unit(r, seg) & 15u);
+        if (groups != 0xFFFF) return 4;
+    }
+    // FP4 masks: the four nibble bits cover every plane bit exactly once, pattern values times the scale are 1
+    for (u32 bit = 0; bit < 32; bit++) {
+        int hits = 0;
+        for (int b = 0; b < 4; b++) {
+            const u32 a = extract4(1u << bit, b);
+            if (!a) continue;
+            hits++;
+            u32 nib = 0;
+            for (u32 i = 0; i < 8; i++)
+                if ((a >> (4 * i)) & 15u) nib = (a >> (4 * i)) & 15u;
+            if (fp4_val(nib) * ldexpf(1.0f, scale_byte4(b) - 127) != 1.0f) return 5;
+        }
+        if (hits != 1) return 6;
+    }
+    return 0;
+}

@@ -108,3 +108,12 @@ def test_plane_decomposition_algorithm(plane_emul, oracle, bits, K):
     W = oracle.ap_dequant(q, lut, bits).astype(np.float64)
     scale = np.abs(W) @ np.abs(x.astype(np.float64))
     assert (np.abs(got - y64) <= 2e-6 * scale).all(), (np.abs(got - y64) / scale).max()
+
+
+def test_plane_tile_swizzle_and_fp4_masks(plane_emul):
+    """direct-to-LDS tile layout: lane <-> (row, segment) is a bijection, every load instruction covers whole 128-byte
+    lines, the MFMA lanes' 16-byte reads are bank-conflict free; the 4 nibble masks partition the plane bits and the
+    scale operand cancels every single-bit FP4 pattern exactly"""
+    import ctypes
+    L = ctypes.CDLL(PSO)
+    assert L.gq_emul_atile_check() == 0

@@ -42,6 +42,7 @@ struct PlaneArgs {
     u32 log2CS;  // a row group's chunks are split over 2^log2CS wave items
     u32 cpi;     // chunks per item
     u32 S;       // LDS ring slots (steps) per wave
+    u32 rawx;    // the activations are staged through LDS (coalesced 16-byte loads into the early waves' still unused ring slots)
     u32 pairs;   // GQ_EPI_SILU_PAIRS: rows are (gate, up) pairs, out[i] = silu(y[2i]) * y[2i+1]
     u32 xflags;  // ablation experiments (GQ_PL_XFLAGS): 1 no MFMA work, 2 no steps at all, 8 no activation loads, 16 no LUT, 32 empty kernel,
                  // 256 late waves request only their first item up front, 1024 no plane loads (the MFMA phase runs on stale LDS)
@@ -119,6 +120,12 @@ __device__ __forceinline__ u32 bload16s(u32x4 rsrc, u32 voff, u32 soff) {  // ze
     asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     return r;
 }
+__device__ __forceinline__ u32x4 bload128(u32x4 rsrc, u32 voff, u32 soff) {
+    u32x4 r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return r;
+}
+__device__ __forceinline__ void tie128(u32x4 &r) { asm volatile("" : "+v"(r)); }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -199,29 +206,45 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     // ---------------------------------------------------------------- 0. activation loads, then the first tiles
     // prologue item = (chunk, virtual lane t, nibble bit b): the weights j = 7 - b and j = 3 - b (plane bits b and b + 4 of
     // every byte) of the 4 bytes c of lane t -- the 8 activations that meet the two image words of (t, b)
+    // Two ways to get them: (rawx) coalesced 16-byte loads, staged through LDS in the early waves' ring slots (free until
+    // the image is built), one extra early-wave barrier -- every line of x is requested once per CU; or, when the ring is
+    // too small for the copy, 16-bit loads straight into the item layout (each line requested up to 9 times: measured 7300
+    // cycles instead of ~1500 until the K = 14336 vector has landed).
     u32 xr[NI][4], ar[NI][4], xh[NI][4], ah[NI][4];
+    u32x4 rawv[NI], rawa[NI];
     const u32 pt = l & 31u, pb = ((w & 1u) << 1) | (l >> 5);  // the same for every pass (E * 64 is a multiple of 128)
     if (early) {
         const u32x4 rsx = make_rsrc(a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
         const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
+        if (a.rawx) {
 #pragma unroll
-        for (u32 n = 0; n < (u32)NI; n++) {
-            const u32 chunk = (w >> 1) + n * (E / 2u);  // wave-uniform
-            const u32 tp = G.tpw(chunk);
-            const bool ok = chunk < G.nchunks && pt < tp && !(a.xflags & 8u);
-            const u32 vlo = ok ? 16u * pt + 2u * (7u - pb) : OOB, vhi = ok ? 16u * pt + 2u * (3u - pb) : OOB;
+            for (u32 n = 0; n < (u32)NI; n++) {
+                const u32 idx = tid + n * (E * 64u);  // 16-byte unit of the vector
+                const u32 voff = (idx < G.K / 8u && !(a.xflags & 8u)) ? 16u * idx : OOB;
+                rawv[n] = bload128(rsx, voff, 0u);
+                if constexpr (PRO == PRO_RMSNORM) rawa[n] = bload128(rsa, voff, 0u);
+                if constexpr (PRO == PRO_SILUMUL) rawa[n] = bload128(rsx, voff, 2u * G.K);
+            }
+        } else {
 #pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 soff = 2048u * chunk + 16u * tp * c;  // element 1024*chunk + 8*tp*c (+ 8t + j per lane)
-                xr[n][c] = bload16s(rsx, vlo, soff);
-                xh[n][c] = bload16s(rsx, vhi, soff);
-                if constexpr (PRO == PRO_RMSNORM) {
-                    ar[n][c] = bload16s(rsa, vlo, soff);
-                    ah[n][c] = bload16s(rsa, vhi, soff);
-                }
-                if constexpr (PRO == PRO_SILUMUL) {
-                    ar[n][c] = bload16s(rsx, vlo, soff + 2u * G.K);
-                    ah[n][c] = bload16s(rsx, vhi, soff + 2u * G.K);
+            for (u32 n = 0; n < (u32)NI; n++) {
+                const u32 chunk = (w >> 1) + n * (E / 2u);  // wave-uniform
+                const u32 tp = G.tpw(chunk);
+                const bool ok = chunk < G.nchunks && pt < tp && !(a.xflags & 8u);
+                const u32 vlo = ok ? 16u * pt + 2u * (7u - pb) : OOB, vhi = ok ? 16u * pt + 2u * (3u - pb) : OOB;
+#pragma unroll
+                for (u32 c = 0; c < 4; c++) {
+                    const u32 soff = 2048u * chunk + 16u * tp * c;  // element 1024*chunk + 8*tp*c (+ 8t + j per lane)
+                    xr[n][c] = bload16s(rsx, vlo, soff);
+                    xh[n][c] = bload16s(rsx, vhi, soff);
+                    if constexpr (PRO == PRO_RMSNORM) {
+                        ar[n][c] = bload16s(rsa, vlo, soff);
+                        ah[n][c] = bload16s(rsa, vhi, soff);
+                    }
+                    if constexpr (PRO == PRO_SILUMUL) {
+                        ar[n][c] = bload16s(rsx, vlo, soff + 2u * G.K);
+                        ah[n][c] = bload16s(rsx, vhi, soff + 2u * G.K);
+                    }
                 }
             }
         }
@@ -298,18 +321,49 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     int sb = 127;
     if (early) {
     wait_vm<0>();  // the activation loads (an early wave has nothing else in flight)
+    if (a.rawx) {
+        unsigned char *raw = smem;  // the early waves' ring slots
 #pragma unroll
-    for (u32 n = 0; n < (u32)NI; n++) {
-        tie4(xr[n]);
-        tie4(xh[n]);
-        if constexpr (PRO != PRO_NONE) {
-            tie4(ar[n]);
-            tie4(ah[n]);
+        for (u32 n = 0; n < (u32)NI; n++) {
+            tie128(rawv[n]);
+            const u32 idx = tid + n * (E * 64u);
+            if (idx < G.K / 8u) {
+                *reinterpret_cast<u32x4 *>(raw + 16u * idx) = rawv[n];
+                if constexpr (PRO != PRO_NONE) {
+                    tie128(rawa[n]);
+                    *reinterpret_cast<u32x4 *>(raw + 2u * G.K + 16u * idx) = rawa[n];
+                }
+            }
         }
+        arrive(ctr + 2, l);
+        wait_count(ctr + 2, E);
+        const uint16_t *rx = reinterpret_cast<const uint16_t *>(raw), *ra = rx + G.K;
 #pragma unroll
-        for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
-            xr[n][c] |= xh[n][c] << 16;
-            if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
+        for (u32 n = 0; n < (u32)NI; n++) {
+            const u32 chunk = (w >> 1) + n * (E / 2u);
+            const u32 tp = G.tpw(chunk);
+            const bool ok = chunk < G.nchunks && pt < tp;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
+                const u32 e = 1024u * chunk + 8u * tp * c + 8u * pt + 3u - pb;
+                xr[n][c] = ok ? ((u32)rx[e + 4u] | ((u32)rx[e] << 16)) : 0u;
+                if constexpr (PRO != PRO_NONE) ar[n][c] = ok ? ((u32)ra[e + 4u] | ((u32)ra[e] << 16)) : 0u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (u32 n = 0; n < (u32)NI; n++) {
+            tie4(xr[n]);
+            tie4(xh[n]);
+            if constexpr (PRO != PRO_NONE) {
+                tie4(ar[n]);
+                tie4(ah[n]);
+            }
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
+                xr[n][c] |= xh[n][c] << 16;
+                if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
+            }
         }
     }
     // ---------------------------------------------------------------- 1. statistics -> barrier
@@ -683,6 +737,10 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
     a.cpi = c.cpi;
     a.S = c.S;
     a.pairs = pairs ? 1u : 0u;
+    {
+        const size_t need = (size_t)K * 2u * (pro == PRO_NONE ? 1u : 2u), have = (size_t)(c.T / 128u) * c.S * 2048u * (size_t)bits;
+        a.rawx = (need <= have && gq_env_int("GQ_PL_RAWX", 1)) ? 1u : 0u;
+    }
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);
     a.eps = eps;
     a.dbg = g_dbg;

@@ -40,7 +40,7 @@ template <>
 __device__ __forceinline__ u32 unit_of<4>(const u32 (&d)[4], u32 j) { return d[j]; }
 
 template <int R>
-__global__ void __launch_bounds__(512) qtip_matvec_kernel(float *out, const u32 *comp, const uint16_t *x, const uint16_t *tlut,
+__global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32 *comp, const uint16_t *x, const uint16_t *tlut,
                                                           u32 M, u32 K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32 *tl = reinterpret_cast<u32 *>(smem);                    // [512] half2 codebook
@@ -56,28 +56,46 @@ __global__ void __launch_bounds__(512) qtip_matvec_kernel(float *out, const u32 
     const u32 nK2 = K / 32u;
     const unsigned char *band = reinterpret_cast<const unsigned char *>(comp) + (size_t)M2 * nK2 * 128u * R;
     float acc0 = 0.f, acc1 = 0.f;        // rows a and a + 8 of tile row 2*M2 + a4
-    for (u32 K2 = w; K2 < nK2; K2 += W) {
-        u32 d[R];
-        const u32 *row = reinterpret_cast<const u32 *>(band + (size_t)K2 * 128u * R + (size_t)s * 4u * R);
+    // The stream of a wave is a chain of 4R-byte-per-lane loads: with one load in flight per wave a CU has 4 KiB
+    // outstanding and the kernel is latency-bound (measured 0.35 TB/s).  PF tile blocks are requested ahead.
+    constexpr u32 PF = 8;
+    u32 dq[PF][R];
+    auto fetch = [&](u32 slot, u32 K2) {
+        if (K2 < nK2) {
+            const u32 *row = reinterpret_cast<const u32 *>(band + (size_t)K2 * 128u * R + (size_t)s * 4u * R);
 #pragma unroll
-        for (int i = 0; i < R; i++) d[i] = __builtin_nontemporal_load(row + i);
+            for (int i = 0; i < R; i++) dq[slot][i] = __builtin_nontemporal_load(row + i);
+        }
+    };
 #pragma unroll
-        for (u32 a3 = 0; a3 < 2; a3++) {
-            const u32 u = unit_of<R>(d, 2u * a3 + a4);
-            const u32 un = (u32)__shfl((int)u, (int)((l & 32u) | ((s + 1u) & 31u)), 64);
-            const u64 comb = ((u64)u << (8 * R)) | (u64)un;
-            const uint16_t *xk = xs + 32u * K2 + 16u * a3 + 2u * b;
-            const u32 x0 = *reinterpret_cast<const u32 *>(xk), x1 = *reinterpret_cast<const u32 *>(xk + 8);
+    for (u32 p = 0; p < PF; p++) fetch(p, w + p * W);
+    for (u32 K2b = w; K2b < nK2; K2b += W * PF) {
 #pragma unroll
-            for (u32 i = 0; i < 4; i++) {
-                const u32 st = (u32)(comb >> (16 * R - 2 * R * i - 16)) & 0xFFFFu;
-                const u32 idx = st * (st + 1u);
-                const u32 w2 = tl[(idx >> 6) & 0x1FFu] ^ (idx & 0x8000u);
-                const u32 xv = (i & 2u) ? x1 : x0;  // cc = i / 2
-                if (i & 1u)                        // d = i % 2
-                    acc1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, w2), __builtin_bit_cast(h16x2, xv), acc1, false);
-                else
-                    acc0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, w2), __builtin_bit_cast(h16x2, xv), acc0, false);
+        for (u32 p = 0; p < PF; p++) {
+            const u32 K2 = K2b + p * W;
+            if (K2 >= nK2) break;
+            u32 d[R];
+#pragma unroll
+            for (int i = 0; i < R; i++) d[i] = dq[p][i];
+            fetch(p, K2 + W * PF);
+#pragma unroll
+            for (u32 a3 = 0; a3 < 2; a3++) {
+                const u32 u = unit_of<R>(d, 2u * a3 + a4);
+                const u32 un = (u32)__shfl((int)u, (int)((l & 32u) | ((s + 1u) & 31u)), 64);
+                const u64 comb = ((u64)u << (8 * R)) | (u64)un;
+                const uint16_t *xk = xs + 32u * K2 + 16u * a3 + 2u * b;
+                const u32 x0 = *reinterpret_cast<const u32 *>(xk), x1 = *reinterpret_cast<const u32 *>(xk + 8);
+#pragma unroll
+                for (u32 i = 0; i < 4; i++) {
+                    const u32 st = (u32)(comb >> (16 * R - 2 * R * i - 16)) & 0xFFFFu;
+                    const u32 idx = st * (st + 1u);
+                    const u32 w2 = tl[(idx >> 6) & 0x1FFu] ^ (idx & 0x8000u);
+                    const u32 xv = (i & 2u) ? x1 : x0;  // cc = i / 2
+                    if (i & 1u)                        // d = i % 2
+                        acc1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, w2), __builtin_bit_cast(h16x2, xv), acc1, false);
+                    else
+                        acc0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, w2), __builtin_bit_cast(h16x2, xv), acc0, false);
+                }
             }
         }
     }
@@ -128,6 +146,8 @@ extern "C" int gq_qtip_matvec(float *out, const uint32_t *compressed, const void
     if (((uintptr_t)x | (uintptr_t)compressed | (uintptr_t)codebook) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
     const u32 nK2 = K / 32u;
     u32 waves = nK2 >= 8u ? 8u : (nK2 >= 4u ? 4u : (nK2 >= 2u ? 2u : 1u));
+    // fewer 32-row bands than CUs (e.g. M = 4096: 128 blocks): 16 waves per band shorten the per-wave decode loop
+    if (nK2 >= 32u && M / 32u <= 256u) waves = 16u;
     const size_t smem = 2048u + (size_t)K * 2u + (size_t)waves * 32u * 4u;
     if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "K too large.");
     hipStream_t s = (hipStream_t)stream;

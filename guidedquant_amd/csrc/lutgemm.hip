@@ -3,8 +3,9 @@
 // The reference launches one block per 32-activation tile and atomically adds fp16 tile results into the output, in
 // an undefined order.  Here one block owns a slice of the outputs and walks the tiles in ASCENDING order (one valid
 // execution of the reference's atomics, and deterministic): per group of G tiles the 4 x 256 sign-sum tables of every
-// tile are built in LDS with the reference's fp16 operation order (lutgemm.cu:40-78), then every lane accumulates its
-// outputs tile by tile with the same fp16 multiply / add sequence (lutgemm.cu:94-145).  Weight words are read
+// tile are built in LDS with the reference's fp16 operation order (lutgemm.cu:40-78); the four waves of a block compute
+// the per-tile results of its 64 outputs in parallel (lutgemm.cu:94-145, same fp16 multiply / add sequence) and wave 0
+// adds them to the running sums in tile order.  Weight words are read
 // coalesced (consecutive outputs of one (tile, plane) are consecutive in memory).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,22 +18,44 @@ typedef _Float16 h16;
 __device__ __forceinline__ h16 u2h(uint16_t h) { return __builtin_bit_cast(h16, h); }
 __device__ __forceinline__ uint16_t h2u(h16 h) { return __builtin_bit_cast(uint16_t, h); }
 
-constexpr int G = 8;  // tiles per LDS round: 8 * 4 * 256 halves = 16 KiB
+constexpr int G = 16;   // tiles per LDS round: 16 * 4 * 256 halves = 32 KiB
+constexpr int OB = 64;  // outputs per block; the 4 waves of a block take the tiles of a round in an interleaved way
+constexpr int TPW = G / 4;  // tiles per wave per round
 
+template <int BITS>
 __global__ void __launch_bounds__(256) lutgemm_kernel(const uint16_t *x, uint16_t *out, const u32 *W, const uint16_t *alpha,
-                                                      const uint16_t *q_bias, u32 N, u32 K, int bits, u32 group_size) {
-    __shared__ uint16_t lut[G][4][256];
-    const u32 tid = threadIdx.x;
-    const u32 m = (blockIdx.x * 256u + tid);  // one output per lane
+                                                      const uint16_t *q_bias, u32 N, u32 K, u32 group_size) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t (*lut)[4][256] = reinterpret_cast<uint16_t (*)[4][256]>(smem);                          // [G][4][256]
+    uint16_t (*obuf)[G][OB] = reinterpret_cast<uint16_t (*)[G][OB]>(smem + G * 4 * 256 * 2);        // [2][G][OB]
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem + G * 4 * 256 * 2 + 2 * G * OB * 2);           // [K]
+    const u32 tid = threadIdx.x, q = tid >> 6, mo = tid & 63u;
+    const u32 m = blockIdx.x * OB + mo;  // the output of this lane (all 4 waves of the block share the 64 outputs)
     const bool ok = m < N;
-    h16 acc = ok ? u2h(out[m]) : (h16)0;
+    for (u32 i = tid; i < K / 2u; i += 256u) reinterpret_cast<u32 *>(xs)[i] = reinterpret_cast<const u32 *>(x)[i];
+    h16 acc = (ok && q == 0) ? u2h(out[m]) : (h16)0;
     const u32 ntiles = K / 32u;
-    for (u32 kt0 = 0; kt0 < ntiles; kt0 += G) {
+    u32 par = 0;
+    __syncthreads();
+    for (u32 kt0 = 0; kt0 < ntiles; kt0 += G, par ^= 1u) {
+        // the weight words / scales of this wave's tiles are requested first: their latency overlaps the table build
+        u32 wq[TPW][BITS];
+        uint16_t al[TPW], qb[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; j++) {
+            const u32 kt = kt0 + q + 4u * (u32)j;
+            const bool v = ok && kt < ntiles;
+            const u32 g = v ? (kt * 32u) / group_size : 0u;
+#pragma unroll
+            for (int b = 0; b < BITS; b++) wq[j][b] = v ? W[((size_t)kt * BITS + b) * N + m] : 0u;
+            al[j] = v ? alpha[(size_t)g * BITS * N + m] : (uint16_t)0;
+            qb[j] = v ? q_bias[(size_t)g * N + m] : (uint16_t)0;
+        }
         // build: thread -> (tile gi, table y, v < 64) for 4 passes, then the two doubling steps
         for (u32 e = tid; e < (u32)G * 4u * 64u; e += 256u) {
             const u32 v = e & 63u, y = (e >> 6) & 3u, gi = e >> 8;
             if (kt0 + gi < ntiles) {
-                const uint16_t *xi = x + 32u * (kt0 + gi) + 8u * y;
+                const uint16_t *xi = xs + 32u * (kt0 + gi) + 8u * y;
                 h16 a = (h16)0;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -49,29 +72,33 @@ __global__ void __launch_bounds__(256) lutgemm_kernel(const uint16_t *x, uint16_
             }
         }
         __syncthreads();
-        if (ok) {
-            for (u32 gi = 0; gi < (u32)G && kt0 + gi < ntiles; gi++) {
-                const u32 kt = kt0 + gi;
-                const u32 g = (kt * 32u) / group_size;
-                h16 all = (h16)0;
+        // per-tile results: wave q takes tiles gi = q, q + 4, .. of the round (independent of the running sum)
 #pragma unroll
-                for (int y = 0; y < 4; y++) all = all + u2h(lut[gi][y][255]);
-                h16 o = (h16)0 + u2h(q_bias[(size_t)g * N + m]) * all;
-                h16 a = u2h(alpha[(size_t)g * bits * N + m]);
-                for (int b = 0; b < bits; b++) {
-                    const u32 w = W[((size_t)kt * bits + b) * N + m];
-                    h16 t = (h16)0;
+        for (int j = 0; j < TPW; j++) {
+            const u32 gi = q + 4u * (u32)j;
+            if (kt0 + gi >= ntiles) break;
+            h16 all = (h16)0;
 #pragma unroll
-                    for (int y = 0; y < 4; y++) t = t + u2h(lut[gi][y][(w >> (8 * y)) & 255u]);
-                    o = o + a * t;
-                    a = a * (h16)2.0f;
-                }
-                acc = acc + o;
+            for (int y = 0; y < 4; y++) all = all + u2h(lut[gi][y][255]);
+            h16 o = (h16)0 + u2h(qb[j]) * all;
+            h16 a = u2h(al[j]);
+#pragma unroll
+            for (int b = 0; b < BITS; b++) {
+                const u32 w = wq[j][b];
+                h16 t = (h16)0;
+#pragma unroll
+                for (int y = 0; y < 4; y++) t = t + u2h(lut[gi][y][(w >> (8 * y)) & 255u]);
+                o = o + a * t;
+                a = a * (h16)2.0f;
             }
+            obuf[par][gi][mo] = h2u(o);
         }
         __syncthreads();
+        // ascending-tile chain of the fp16 adds (the reference's atomicAdd sequence in tile order)
+        if (q == 0)
+            for (u32 gi = 0; gi < (u32)G && kt0 + gi < ntiles; gi++) acc = acc + u2h(obuf[par][gi][mo]);
     }
-    if (ok) out[m] = h2u(acc);
+    if (ok && q == 0) out[m] = h2u(acc);
 }
 }  // namespace
 
@@ -82,8 +109,26 @@ extern "C" int gq_lutgemm_gemv(const void *x, void *out, const uint32_t *qweight
     if (K == 0 || K % 32u || N == 0) return gq_fail(GQ_EINVAL, "need N > 0 and K a positive multiple of 32.");
     if (group_size <= 0 || K % (uint32_t)group_size || (uint32_t)group_size % 32u)
         return gq_fail(GQ_EINVAL, "group_size must be a multiple of 32 that divides input_feat.");
-    hipLaunchKernelGGL(lutgemm_kernel, dim3((N + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x,
-                       (uint16_t *)out, qweight, (const uint16_t *)alpha, (const uint16_t *)q_bias, N, K, bits, (u32)group_size);
+    const size_t smem = (size_t)G * 4 * 256 * 2 + 2 * (size_t)G * OB * 2 + (size_t)K * 2u;
+    if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "input_feat too large for the LDS activation copy.");
+    if (((uintptr_t)x) & 3u) return gq_fail(GQ_EINVAL, "input must be 4-byte aligned.");
+    const dim3 grid((N + (u32)OB - 1u) / (u32)OB), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define GQ_LG_CASE(B)                                                                                                    \
+    case B: {                                                                                                            \
+        static bool set = false;                                                                                         \
+        if (!set) {                                                                                                      \
+            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lutgemm_kernel<B>),                         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            set = true;                                                                                                  \
+        }                                                                                                                \
+        hipLaunchKernelGGL(lutgemm_kernel<B>, grid, block, smem, st, (const uint16_t *)x, (uint16_t *)out, qweight,      \
+                           (const uint16_t *)alpha, (const uint16_t *)q_bias, N, K, (u32)group_size);                    \
+    } break;
+    switch (bits) {
+        GQ_LG_CASE(1) GQ_LG_CASE(2) GQ_LG_CASE(3) GQ_LG_CASE(4) GQ_LG_CASE(5) GQ_LG_CASE(6) GQ_LG_CASE(7) GQ_LG_CASE(8)
+    }
+#undef GQ_LG_CASE
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

@@ -182,6 +182,13 @@ def random_init_(model: Transformer, seed: int = 0, lut_std: float = 0.02, cheap
             mod.qweight.copy_(torch.randint(-2**31, 2**31 - 1, mod.qweight.shape, dtype=torch.int32, device=dev, generator=gd))
             mod.alpha.copy_((torch.rand(mod.alpha.shape, device=dev, generator=gd) * lut_std).to(mod.alpha.dtype))
             mod.q_bias.copy_((torch.randn(mod.q_bias.shape, device=dev, generator=gd) * lut_std).to(mod.q_bias.dtype))
+        elif type(mod).__name__ == "QuantizedLinear":
+            # QTIP: random trellis words, a smooth symmetric codebook, sign vectors
+            mod.trellis.copy_(torch.randint(-2**15, 2**15 - 1, mod.trellis.shape, dtype=torch.int16, device=dev, generator=gd))
+            if mod.tlut is not None:
+                mod.tlut.data.copy_((torch.randn(mod.tlut.shape, device=dev, generator=gd) * 0.5).to(mod.tlut.dtype))
+            mod.SU.copy_((torch.randint(0, 2, mod.SU.shape, device=dev, generator=gd) * 2 - 1).to(mod.SU.dtype))
+            mod.SV.copy_((torch.randint(0, 2, mod.SV.shape, device=dev, generator=gd) * 2 - 1).to(mod.SV.dtype) * lut_std)
         elif isinstance(mod, nn.Linear):
             mod.weight.data.copy_((torch.randn(mod.weight.shape, device=dev, generator=gd) * 0.02).to(mod.weight.dtype))
         elif isinstance(mod, nn.Embedding):
@@ -201,17 +208,30 @@ def load_model(model_name, device, backend, bitwidth, random_init=True, checkpoi
         linear_kwargs["bitwidth"] = bitwidth
         linear_kwargs["group_size"] = -1
         linear_kwargs["device"] = device
+    elif backend == "qtip":
+        # generate.py:210-221: the QTIP hyper-parameters come from the checkpoint's config.json ("quip_params"); the
+        # linears are not fused (generate.py:232) and the state dict is loaded non-strictly (generate.py:238)
+        from .qtip import QuantizedLinear
+        import json
+        import os
+        quip = dict(td_x=16, td_y=16, L=16, K=bitwidth, V=2, tlut_bits=9, decode_mode="quantlut_sym")
+        if checkpoint_path is not None and os.path.exists(os.path.join(checkpoint_path, "config.json")):
+            with open(os.path.join(checkpoint_path, "config.json"), "r") as f:
+                quip.update({k: v for k, v in json.load(f)["quip_params"].items() if k in quip})
+        linear_class = QuantizedLinear
+        linear_kwargs.update(quip)
+        linear_kwargs["device"] = device
     elif backend is None:
         linear_class = nn.Linear
         assert bitwidth == 16
     else:
-        raise ValueError(f"unknown backend {backend!r} (ap | lutgemm | None)")
+        raise ValueError(f"unknown backend {backend!r} (ap | lutgemm | qtip | None)")
     model = Transformer.from_name(name=model_name, dtype=dtype, linear_class=linear_class, linear_kwargs=linear_kwargs,
-                                  halve_layers=halve_layers, fuse_linears=True)
+                                  halve_layers=halve_layers, fuse_linears=(backend != "qtip"))
     if not random_init:
         import os
         checkpoint = torch.load(os.path.join(checkpoint_path, "converted_pytorch_model.bin"), mmap=True, weights_only=True)
-        model.load_state_dict(checkpoint, assign=True, strict=True)
+        model.load_state_dict(checkpoint, assign=True, strict=(backend != "qtip"))
     model = model.to(device=device, dtype=dtype)
     if random_init:
         random_init_(model)

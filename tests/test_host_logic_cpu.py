@@ -148,3 +148,21 @@ def test_qtip_converter_renames():
     out = convert_qtip_no_fuse({"model.layers.0.self_attn.q_proj.trellis": torch.zeros(1), "model.layers.0.mlp.down_proj.SU": torch.zeros(1),
                                 "lm_head.weight": torch.zeros(1), "model.embed_tokens.weight": torch.zeros(1)})
     assert set(out) == {"layers.0.attention.wq.trellis", "layers.0.feed_forward.w2.SU", "output.weight", "tok_embeddings.weight"}
+
+
+def test_load_model_qtip_backend_builds_unfused_tree():
+    """generate.py:210-238 -- backend 'qtip': QuantizedLinear with the quip_params, separate wq/wk/wv and w1/w3 modules"""
+    from guidedquant_amd import model as gm
+    from guidedquant_amd.generate import load_model
+    from guidedquant_amd.qtip import QuantizedLinear
+    gm.transformer_configs["qtip-test"] = dict(model_name="llama-qtip-test", block_size=64, vocab_size=128, n_layer=1, n_head=4, dim=256, intermediate_size=512,
+                                               n_local_heads=2)
+    try:
+        m = load_model("qtip-test", "cpu", "qtip", 2, random_init=True)
+    finally:
+        del gm.transformer_configs["qtip-test"]
+    att, ff = m.layers[0].attention, m.layers[0].feed_forward
+    assert not hasattr(att, "wqkv") and isinstance(att.wq, QuantizedLinear) and isinstance(ff.w3, QuantizedLinear)
+    assert att.wk.out_features == 128 and ff.w2.in_features == 512 and att.wq.K == 2 and att.wq.decode_mode == "quantlut_sym"
+    assert att.wq.trellis.dtype == torch.int16 and att.wq.trellis.shape == (256 // 16 * (256 // 16), 16 * 16 * 2 // 16)
+    assert bool(att.wq.trellis.any()) and set(att.wq.SU.unique().tolist()) <= {-1.0, 1.0}

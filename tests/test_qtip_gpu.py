@@ -105,3 +105,25 @@ def test_quantized_linear_forward(oracle, R):
     zh = oracle.matmul_hadU(z.astype(np.float32)[None], None)[0].astype(np.float64)
     ref = zh * (SV.astype(np.float64) * 32)
     assert np.abs(y - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4
+
+
+def test_qtip_backend_model_decodes():
+    """generate.py --backend qtip: an unfused QuantizedLinear model (power-of-two dims: no Hadamard factor tables needed)
+    steps through the reference decode loop; every linear runs hadamard -> trellis matvec -> hadamard on the HIP ops."""
+    from guidedquant_amd import model as gm
+    from guidedquant_amd.generate import load_model, decode_one_token
+    gm.transformer_configs["qtip-gpu-test"] = dict(model_name="llama-qtip-gpu-test", block_size=128, vocab_size=512, n_layer=2,
+                                                   n_head=8, dim=1024, intermediate_size=2048, n_local_heads=4)
+    try:
+        m = load_model("qtip-gpu-test", "cuda:0", "qtip", 2, random_init=True)
+    finally:
+        del gm.transformer_configs["qtip-gpu-test"]
+    with torch.device("cuda:0"):
+        m.setup_caches(max_batch_size=1, max_seq_length=64)
+    tok = torch.tensor([[1]], dtype=torch.int32, device="cuda:0")
+    for pos in range(3):
+        with torch.no_grad():
+            nxt, probs = decode_one_token(m, tok, torch.tensor([pos], dtype=torch.int32, device="cuda:0"), temperature=0.0, top_k=32)
+        assert nxt.shape[-1] == 1 and 0 <= int(nxt.reshape(-1)[0]) < 512
+        assert bool(torch.isfinite(probs.float()).all())
+        tok = nxt.reshape(1, 1).to(torch.int32)

@@ -530,10 +530,12 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     QuadCfg c;
     const int pro = a.normw ? PRO_RMSNORM : ((a.epilogue & GQ_PRO_SILU_MUL) ? PRO_SILUMUL : PRO_NONE);
     // fast mode serves the shapes on which the plane-MFMA kernel beats the exact kernel (measured):
-    // 2-bit matrices of >= GQ_PL_MIN_MWEIGHTS million weights (w1w3, w2 of the 8B / 70B models); everything else runs
-    // the exact kernels, whose results are bit-identical to the reference
-    const uint64_t min_w = (uint64_t)gq_env_int("GQ_PL_MIN_MWEIGHTS", 20) * 1000000ull;
-    const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 2);
+    // 2-bit matrices of >= 20 M weights (wqkv, w1w3, w2 of the 8B / 70B models), 3- and 4-bit matrices of >= 32 M weights
+    // (w1w3, w2); everything else runs the exact kernels, whose results are bit-identical to the reference.
+    // GQ_PL_MIN_MWEIGHTS overrides the threshold for every bit width, GQ_PL_MAX_BITS the widest plane-served width.
+    const int env_min = gq_env_int("GQ_PL_MIN_MWEIGHTS", -1);
+    const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : (bits == 2 ? 20 : 32)) * 1000000ull;
+    const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {
         int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s);
         if (rc != GQ_ENOTSUP) return rc;

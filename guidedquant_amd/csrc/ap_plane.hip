@@ -81,17 +81,15 @@ typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2v u2h2(u32 u) { return __builtin_bit_cast(h2v, u); }
 __device__ __forceinline__ u32 h22u(h2v h) { return __builtin_bit_cast(u32, h); }
 
-// The scaled MFMA with A = FP4 (4 registers), B = BF8, accumulating IN PLACE.  Through the builtin the register
-// allocator lets the accumulators wander (vDst != SrcC, overlapping freed operand registers), and every MFMA then waits
-// for the previous one to retire (s_nop 5..6 plus the hardware interlock) -- the matrix pipe runs at half rate.
-// Hazards the compiler can not see inside the asm: the A registers were just written by VALU (2 wait states, the
-// s_nop below); a VALU read of the accumulator needs the MFMA retired (mfma_drain before the item's reduction).
-__device__ __forceinline__ void mfma_f4_bf8(v4f &acc, v4i a, v8i b, u32 scale_a, u32 scale_b) {
-    asm("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:1"
-        : "+v"(acc)
-        : "v"(a), "v"(b), "v"(scale_a), "v"(scale_b));
+// The scaled MFMA with A = FP4 (4 registers; the upper half of the builtin's 8-register vector is ignored for cbsz = 4),
+// B = BF8.  Through the BUILTIN, not inline asm: the compiler must see the instruction to insert the MFMA hazard wait
+// states.  An asm version with a tied accumulator was tried (the register allocator otherwise lets vDst != SrcC wander):
+// no faster, and unsafe -- the compiler copied accumulators between registers right behind an MFMA it could not see.
+__device__ __forceinline__ void mfma_f4_bf8(v4f &acc, v4i a, v8i b, int scale_a, int scale_b) {
+    const v8i a8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, -1, -1, -1, -1);
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b, acc, 4, 1, 0, scale_a, 0, scale_b);
 }
-__device__ __forceinline__ void mfma_drain(v4f &acc) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc)); }
+__device__ __forceinline__ void mfma_drain(v4f &) {}
 
 // --- hand-scheduled vector memory.  The compiler's waitcnt pass treats an LDS-DMA load as "may alias every later
 // LDS access" and drains vmcnt before the first ds_read / barrier, which would serialise the prologue behind the
@@ -503,15 +501,6 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         }
         if (++cq_slot == S) cq_slot = 0;
         if (chunk < G.nchunks && !(a.xflags & 1u)) {
-            // plane-subset words: code bit i lives in plane BITS-1-i
-            u32 PW[NP1][8];
-#pragma unroll
-            for (int cm = 1; cm < NP; cm++) {
-                const int low = cm & -cm, i0 = __builtin_ctz(cm), rest = cm ^ low;
-#pragma unroll
-                for (int v = 0; v < 8; v++)
-                    PW[cm - 1][v] = rest ? (PW[rest - 1][v] & Wd[BITS - 1 - i0][v]) : Wd[BITS - 1 - i0][v];
-            }
             // B operand (activation pieces) double-buffered over the 8 (nibble bit b, word half h) MFMAs per subset
             const unsigned char *bbase = bcol ? bimg + bimg4_off(chunk, 0u, 0u, col) + 16u * kb : zero32;
             const u32 bstep = bcol ? 512u : 0u, bhalf = bcol ? 64u : 0u;  // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
@@ -529,12 +518,39 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
                 // MFMAs into a single B buffer and exposes the LDS latency 8 times per step)
                 __builtin_amdgcn_sched_barrier(0);
                 v8i Bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+                // FP4 A operands of the 2^BITS - 1 plane subsets, built on the fly: the mask commutes with AND, so a subset's
+                // operand is the AND of its planes' masked words; a depth-first walk over the subset lattice keeps only one
+                // partial product per level alive (no register-resident AND words: 4-bit would need 120 of them).
+                // Plane p holds code bit BITS-1-p; subset index cm = OR of the code bits.
+                v4i Mp[BITS];
 #pragma unroll
-                for (int cm = 1; cm < NP; cm++) {
-                    v4i A4;  // FP4 operand: 4 registers (the upper half of the builtin's vector is ignored for cbsz = 4)
+                for (int p = 0; p < BITS; p++)
 #pragma unroll
-                    for (int v = 0; v < 4; v++) A4[v] = (int)extract4(PW[cm - 1][4 * hh + v], nb);
-                    mfma_f4_bf8(acc[cm - 1], A4, Bv, (u32)scale_byte4(nb), (u32)sb);
+                    for (int v = 0; v < 4; v++) Mp[p][v] = (int)extract4(Wd[p][4 * hh + v], nb);
+                const int sa = scale_byte4(nb);
+#pragma unroll
+                for (int p0 = 0; p0 < BITS; p0++) {
+                    const v4i A1 = Mp[p0];
+                    const int c1 = 1 << (BITS - 1 - p0);
+                    mfma_f4_bf8(acc[c1 - 1], A1, Bv, sa, sb);
+#pragma unroll
+                    for (int p1 = p0 + 1; p1 < BITS; p1++) {
+                        const v4i A2 = A1 & Mp[p1];
+                        const int c2 = c1 | (1 << (BITS - 1 - p1));
+                        mfma_f4_bf8(acc[c2 - 1], A2, Bv, sa, sb);
+#pragma unroll
+                        for (int p2 = p1 + 1; p2 < BITS; p2++) {
+                            const v4i A3 = A2 & Mp[p2];
+                            const int c3 = c2 | (1 << (BITS - 1 - p2));
+                            mfma_f4_bf8(acc[c3 - 1], A3, Bv, sa, sb);
+#pragma unroll
+                            for (int p3 = p2 + 1; p3 < BITS; p3++) {
+                                const v4i A4 = A3 & Mp[p3];
+                                const int c4 = c3 | (1 << (BITS - 1 - p3));
+                                mfma_f4_bf8(acc[c4 - 1], A4, Bv, sa, sb);
+                            }
+                        }
+                    }
                 }
             }
         } else if (a.xflags & 1u) {

@@ -1,16 +1,18 @@
 // ap_plane.hip -- "fast mode" Any-Precision GEMV for gfx950: binary bit-plane GEMVs on the matrix cores.
 //
-// See plane_core.h for the algorithm.  What runs where:
+// See plane_core.h for the algorithm and the measured hardware facts.  What runs where:
 //   HBM    : the stored bit-planes, whole 128-byte lines (one row x one plane x one 1024-weight chunk), fetched by
-//            direct-to-LDS loads (buffer_load_dwordx4 ... lds) that every wave issues for ALL of its steps (up to
-//            its LDS ring depth) in its first instructions: the block's share of the matrix is in flight before
-//            the activation prologue starts, and the matrix cores chase the stream.
-//   VALU   : one v_and_b32 per 4 weights per plane-subset (bits -> bf8 {0, 2^e}); ANDs of planes for the subsets.
-//   MFMA   : v_mfma_scale_f32_16x16x128_f8f6f4 (A = bf8 bit patterns, scale cancels 2^e; B = 4 bf8 pieces of x in
-//            columns 0..3, per-32-element block scale), fp32 accumulate: 8 MFMAs per (chunk, plane-subset).
+//            direct-to-LDS loads (buffer_load_dwordx4 ... lds) into per-wave rings of A tiles; the late half of the
+//            waves requests its tiles in its first instructions, the early half after it has built the B image.
+//   VALU   : one v_and_b32 per 8 weights per plane-subset (nibble bit -> FP4 {0, 0.5 / 1 / 2}); the operand of a subset
+//            is the AND of its planes' masked words (depth-first over the subset lattice).
+//   MFMA   : v_mfma_scale_f32_16x16x128_f8f6f4, A = FP4 single-bit patterns (4 registers, the E8M0 scale cancels the
+//            pattern value), B = 4 exact bf8 pieces of x * 2^k in columns 0..3, fp32 accumulate:
+//            8 MFMAs per (chunk, plane-subset).
 //   LDS    : per-wave rings of A tiles (plane_core.h atile_unit swizzle), the B image (activation pieces, 4*K bytes)
-//            built once per block, partial sums of K-split items.
-// Epilogue : y = coef[0] * sum(x) + sum_S coef[S] * T[S]  (Moebius coefficients of the row's LUT), fp32 -> fp16.
+//            built once per block, the LUT rows of the block, partial sums of K-split items.
+// Epilogue : y = coef[0] * sum(x) + sum_S coef[S] * T[S]  (Moebius coefficients of the row's LUT), fp32 -> fp16;
+//            optional residual add or SiLU(gate) * up over row pairs.
 //
 // This path is NOT bit-identical to the reference's fp16-accumulated kernel (anyprec.cu:372-542): it is closer
 // to the exact product than the reference is (products exact, fp32 accumulation).  The bit-exact path is
@@ -89,7 +91,6 @@ __device__ __forceinline__ void mfma_f4_bf8(v4f &acc, v4i a, v8i b, int scale_a,
     const v8i a8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, -1, -1, -1, -1);
     acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b, acc, 4, 1, 0, scale_a, 0, scale_b);
 }
-__device__ __forceinline__ void mfma_drain(v4f &) {}
 
 // --- hand-scheduled vector memory.  The compiler's waitcnt pass treats an LDS-DMA load as "may alias every later
 // LDS access" and drains vmcnt before the first ds_read / barrier, which would serialise the prologue behind the
@@ -102,16 +103,6 @@ __device__ __forceinline__ void dma16(u32x4 rsrc, u32 lds_base, u32 voff) {
 __device__ __forceinline__ void dma16s(u32x4 rsrc, u32 lds_base, u32 voff, u32 soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory");
-}
-__device__ __forceinline__ u32 bload32(u32x4 rsrc, u32 voff) {
-    u32 r;
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
-    return r;
-}
-__device__ __forceinline__ u32 bload32s(u32x4 rsrc, u32 voff, u32 soff) {
-    u32 r;
-    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-    return r;
 }
 __device__ __forceinline__ u32 bload16s(u32x4 rsrc, u32 voff, u32 soff) {  // zero-extended 16-bit load
     u32 r;
@@ -560,7 +551,6 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
             // item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
 #pragma unroll
             for (int cm = 0; cm < NP1; cm++) {
-                mfma_drain(acc[cm]);
                 v4f v = acc[cm];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {

@@ -7,18 +7,16 @@
 // i.e. 2^b - 1 BINARY GEMVs whose matrices are the stored bit-planes (and ANDs of them) -- exactly the bytes the
 // reference streams (any_precision/quantization/pack.py:101-109), never expanded to fp16 weights.
 //
-// On CDNA4 a binary plane becomes an MFMA operand with ONE v_and_b32 per 4 weights: (word & 0x04040404 << s)
-// is four bf8 (e5m2) values in {0, 2^e(s)}, a power of two that the block-scale operand of
-// v_mfma_scale_f32_16x16x128_f8f6f4 cancels for free.  The activations are split EXACTLY into 4 bf8 pieces
-// (x * 2^-g = p0 + p1 + p2 + p3, 3 significand bits each) that occupy 4 of the 16 MFMA columns, so the products
-// are exact and the sums are accumulated in fp32: the result is MORE accurate than the reference's fp16-accumulated
-// kernel (anyprec.cu:372-542), not bit-identical to it (that is what the "exact" mode in ap_gemv.hip is for).
+// On CDNA4 a binary plane becomes an MFMA operand with ONE v_and_b32 per 8 weights: (word & 0x11111111 << b) is eight
+// FP4 (e2m1) values in {0, 0.5 / 1 / 2}, a power of two that the scale operand of v_mfma_scale_f32_16x16x128_f8f6f4
+// cancels for free.  The activations are split EXACTLY into 4 bf8 pieces (x * 2^k = p0 + p1 + p2 + p3, 3 significand
+// bits each) that occupy 4 of the 16 MFMA columns, so the products are exact and the sums are accumulated in fp32: the
+// result is MORE accurate than the reference's fp16-accumulated kernel (anyprec.cu:372-542), not bit-identical to it
+// (that is what the "exact" mode in ap_gemv.hip is for).
 //
-// Layout of one MFMA (16 rows x 128 k): lane l -> row r = l & 15 of the row group, k-block kb = l >> 4;
-// the lane feeds 8 VGPRs = the SAME bit position s of its 8 consecutive plane words (32 bytes of the row's
-// 128-byte chunk line), so all 32 A elements of a lane share one scale.  VGPR v, byte B  <->  virtual lane
-// t = 8*kb + v of the chunk, byte c = 3 - B, weight j = 7 - s  <->  activation 1024*chunk + 8*tpw*c + 8*t + j
-// (anyprec.cu:498).  The B operand (activation pieces) is pre-arranged in LDS in that order.
+// Chunk geometry is the reference's (anyprec.cu:498): a 1024-weight chunk of a row is 32 plane words ("virtual lanes"
+// t = 0..31; a tail chunk has tpw = (K % 1024) / 32 of them); bit 8 (3 - c) + (7 - j) of word t is the weight of
+// activation 1024 * chunk + 8 * tpw * c + 8 * t + j   (byte c = 0..3, weight j = 0..7).
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -34,35 +32,6 @@ namespace gqp {
 
 typedef uint32_t u32;
 
-// bit position s (inside each byte of a plane word) -> how to turn it into bf8 values {0, 2^e}
-//   s = 0,1 : (w << 2) & (0x04040404 << s)      (avoids the e5m2 denormal patterns 0x01 / 0x02)
-//   s = 2..6:  w       & (0x01010101 << s)
-//   s = 7   : (w >> 1) & 0x40404040             (avoids the sign bit)
-GQP_HD u32 extract(u32 w, int s) {
-    if (s <= 1) return (w << 2) & (0x04040404u << s);
-    if (s == 7) return (w >> 1) & 0x40404040u;
-    return w & (0x01010101u << s);
-}
-// exponent e with pattern value = 2^e for the byte pattern produced by extract(., s)
-GQP_HD int pattern_exp(int s) {
-    const int pos = s <= 1 ? s + 2 : (s == 7 ? 6 : s);  // bit position of the pattern inside the byte
-    // e5m2: exponent field = bits 6..2, bias 15; a single exponent bit at position pos -> 2^(2^(pos-2) - 15)
-    return (1 << (pos - 2)) - 15;
-}
-// E8M0 scale byte cancelling the pattern value: 2^(byte - 127) = 2^-e
-GQP_HD int scale_byte(int s) { return 127 - pattern_exp(s); }
-
-// Hardware K order of v_mfma_scale_f32_16x16x128_f8f6f4 (measured, tools/ubench/opsel_probe.hip + one-hot sweep):
-//     k = 64*(v/4) + 16*kb + 4*(v%4) + byte,    v = VGPR 0..7 of the lane, kb = lane/16
-// and the E8M0 scale of the 32-element block b = k/32 is the one supplied by lane group kb == b.  So a scale block
-// is {kb in pair b&1} x {v in half b>>1}:
-GQP_HD u32 blk_of(u32 kb, u32 v) { return (kb >> 1) + 2u * (v >> 2); }
-
-// byte offset of the 32-byte B block of (chunk, s, kb, piece) in the LDS image; inside: 4*v + B.
-// kb is the fastest block index so that the 32 virtual lanes t = 8*kb + v of one (chunk, s, piece) are 128
-// contiguous bytes (conflict-free 4-byte LDS writes by 32 consecutive lanes)
-GQP_HD u32 bimg_off(u32 chunk, u32 s, u32 kb, u32 piece) { return ((((chunk * 8u + s) * 4u + piece) * 4u + kb) << 5); }
-
 struct Geom {
     u32 K, wpr, nfull, eff, nchunks;
     GQP_HD void init(u32 K_) {
@@ -74,25 +43,6 @@ struct Geom {
     }
     GQP_HD u32 tpw(u32 chunk) const { return chunk < nfull ? 32u : eff; }
 };
-
-// activation e (0 <= e < K) -> chunk, s, kb, v, B  (inverse of the mapping above)
-GQP_HD void locate_x(const Geom &G, u32 e, u32 &chunk, u32 &s, u32 &kb, u32 &v, u32 &B) {
-    u32 r, tp;
-    if (e < 1024u * G.nfull) {
-        chunk = e / 1024u;
-        r = e % 1024u;
-        tp = 32u;
-    } else {
-        chunk = G.nfull;
-        r = e - 1024u * G.nfull;
-        tp = G.eff;
-    }
-    const u32 c = r / (8u * tp), t = (r % (8u * tp)) / 8u, j = r % 8u;
-    s = 7u - j;
-    kb = t / 8u;
-    v = t % 8u;
-    B = 3u - c;
-}
 
 
 // ---- FP4 A operand (v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = 4, blgp = 1: A = e2m1 nibbles, B = bf8 bytes).

@@ -18,6 +18,20 @@ __global__ void __launch_bounds__(1024) flat(u32 *ctr, int iters, u32 base) {
         __syncthreads();
     }
 }
+// flat counter, relaxed atomics: one release fence before the arrive, relaxed polling, one acquire fence after
+__global__ void __launch_bounds__(1024) flat_relaxed(u32 *ctr, int iters, u32 base, int fences) {
+    for (int it = 0; it < iters; it++) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 target = base + (u32)(it + 1) * gridDim.x;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+            if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+}
 // two-level: blocks of the same XCD (blockIdx % 8) add to their XCD counter; the last arriver of an XCD adds to the top
 // counter; everyone polls the top counter
 __global__ void __launch_bounds__(1024) twolevel(u32 *ctr, int iters, u32 base) {
@@ -36,16 +50,18 @@ __global__ void __launch_bounds__(1024) twolevel(u32 *ctr, int iters, u32 base) 
 int main() {
     u32 *ctr; CHECK(hipMalloc(&ctr, 4096 * 4)); CHECK(hipMemset(ctr, 0, 4096 * 4));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 2; variant++) {
+    for (int variant = 0; variant < 4; variant++) {
         for (int iters : {1, 101}) {
             CHECK(hipMemset(ctr, 0, 4096 * 4));
             CHECK(hipDeviceSynchronize());
             CHECK(hipEventRecord(e0));
             if (variant == 0) hipLaunchKernelGGL(flat, dim3(256), dim3(1024), 0, 0, ctr, iters, 0u);
-            else hipLaunchKernelGGL(twolevel, dim3(256), dim3(1024), 0, 0, ctr, iters, 0u);
+            else if (variant == 1) hipLaunchKernelGGL(twolevel, dim3(256), dim3(1024), 0, 0, ctr, iters, 0u);
+            else hipLaunchKernelGGL(flat_relaxed, dim3(256), dim3(1024), 0, 0, ctr, iters, 0u, variant == 2 ? 1 : 0);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-            printf("%s: %d barriers: %.2f us total\n", variant ? "two-level" : "flat     ", iters, ms * 1e3);
+            const char *nm[4] = {"flat acq/rel", "two-level   ", "flat relaxed + fences", "flat relaxed, no fences"};
+            printf("%s: %d barriers: %.2f us total\n", nm[variant], iters, ms * 1e3);
         }
     }
     return 0;

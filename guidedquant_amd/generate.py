@@ -269,3 +269,90 @@ def benchmark_decode(model: Transformer, device, num_samples=5, max_new_tokens=1
     model_size, _ = _get_model_size(model)
     return dict(tokens_per_sec=float(np.mean(tps)), std=float(np.std(tps)), bandwidth_GBps=model_size * float(np.mean(tps)) / 1e9,
                 model_size=model_size)
+
+
+def main(prompt=None, num_samples=5, max_new_tokens=100, batch_size=1, top_k=200, temperature=0.8, compile=2,
+         compile_prefill=False, profile=None, device="cuda", model_name=None, backend=None, bitwidth=None,
+         checkpoint_path=None, config_path=None, dtype=None, print_result=False, random_init=False):
+    """generate.py:268-389 -- same arguments and printed report.  `compile` selects the decode driver: 0 = eager per-token
+    launches, >= 1 = the captured hipGraph of the decode step (the role torch.compile(mode='max-autotune') plays in the
+    reference).  A tokenizer is only needed for a text prompt / --print_result; without one the BOS id of the model
+    family is used (the reference's benchmark setting, prompt=None)."""
+    print(f"Using device={device}")
+    dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32, None: torch.float16}.get(dtype, dtype)
+    if batch_size != 1:
+        raise ValueError("only batch_size 1 is implemented (generate.py:165)")
+    t0 = time.time()
+    model = load_model(model_name, device, backend, bitwidth, random_init=random_init, checkpoint_path=checkpoint_path, dtype=dtype)
+    tokenizer = None
+    if prompt is not None or print_result:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(model_name)
+    if "cuda" in str(device):
+        torch.cuda.synchronize()
+    print(f"Time to load model: {time.time() - t0:.02f} seconds", flush=True)
+    if prompt is not None:
+        encoded = torch.tensor(tokenizer.encode(prompt), dtype=torch.int32, device=device)
+    else:
+        bos = tokenizer.bos_token_id if tokenizer is not None else (128000 if model.config.vocab_size > 100000 else 1)
+        encoded = torch.tensor([bos], dtype=torch.int32, device=device)
+    prompt_length = encoded.size(-1)
+    torch.manual_seed(1234)
+    model_size, params = _get_model_size(model)
+    model.setup_caches(1, prompt_length + max_new_tokens)
+    use_graph = bool(compile) and "cuda" in str(device)
+    graph = DecodeGraph(model, device, temperature=temperature, top_k=top_k) if use_graph else None
+    tps = []
+    for i in range(-1 if use_graph else 0, num_samples):
+        if "cuda" in str(device):
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        y = generate(model, encoded, max_new_tokens, use_graph=use_graph, graph=graph, temperature=temperature, top_k=top_k)
+        if "cuda" in str(device):
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t1
+        if i == -1:
+            print(f"Compilation time: {elapsed:.2f} seconds", flush=True)
+            continue
+        if print_result:
+            print(tokenizer.decode(y.reshape(-1).tolist()))
+        tokens_sec = (y.size(-1) - prompt_length) / elapsed
+        tps.append(tokens_sec)
+        if i + 1 == num_samples:
+            print(f"Time for inference {i + 1}: {elapsed:.02f} sec total, {tokens_sec:.02f} tokens/sec")
+            print(f"Bandwidth achieved: {model_size * tokens_sec / 1e9:.02f} GB/s")
+            print(f"FLOPS achieved: {params * (y.numel() / elapsed) * 2 / 1e12:.02f} TF/s")
+            print(flush=True)
+    print("==========")
+    print(f"Batch Size: {batch_size}")
+    print(f"Prompt Length: {prompt_length}")
+    print(f"Generated tokens: {max_new_tokens}")
+    print(f"Average tokens/sec: {float(np.mean(tps)):.2f}")
+    print(f"Std of tokens/sec: {float(np.std(tps, ddof=1)) if len(tps) > 1 else 0.0:.2f}")
+    return tps
+
+
+if __name__ == "__main__":
+    import argparse
+    parser = argparse.ArgumentParser(description="Decode benchmark / text generation (flags of the reference's inference/generate.py)")
+    parser.add_argument('--prompt', type=str, default=None, help="Input prompt. None: only the bos token (benchmarking)")
+    parser.add_argument('--num_samples', type=int, default=5)
+    parser.add_argument('--max_new_tokens', type=int, default=100)
+    parser.add_argument('--batch_size', type=int, default=1)
+    parser.add_argument('--top_k', type=int, default=32)
+    parser.add_argument('--temperature', type=float, default=0.0)
+    parser.add_argument('--compile', type=int, default=2, help='0: eager launches, otherwise the captured hipGraph decode step')
+    parser.add_argument('--compile_prefill', action='store_true', help='accepted for compatibility (prefill is not captured)')
+    parser.add_argument('--profile', type=str, default=None, help='accepted for compatibility (use rocprofv3)')
+    parser.add_argument('--device', type=str, default="cuda")
+    parser.add_argument('--model_name', type=str, default=None)
+    parser.add_argument('--bitwidth', type=int, default=None, choices=[2, 3, 4, 16])
+    parser.add_argument('--checkpoint_path', type=str, default=None)
+    parser.add_argument('--config_path', type=str, default=None, help='QTIP config path')
+    parser.add_argument('--dtype', type=str, default="float16", choices=["float16", "float32", "bfloat16"])
+    parser.add_argument('--backend', type=str, default=None, choices=["ap", "lutgemm", "qtip", None])
+    parser.add_argument('--print_result', action='store_true')
+    parser.add_argument('--random_init', action='store_true')
+    a = parser.parse_args()
+    main(a.prompt, a.num_samples, a.max_new_tokens, a.batch_size, a.top_k, a.temperature, a.compile, a.compile_prefill, a.profile,
+         a.device, a.model_name, a.backend, a.bitwidth, a.checkpoint_path, a.config_path, a.dtype, a.print_result, a.random_init)

@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parallel", choices=["replicas", "pp"], default="replicas",
                     help="N>1: independent replicas (default) or the layer pipeline with point-to-point hops (pp)")
+    ap.add_argument("--model", default=MODEL, help="model name from guidedquant_amd.model.transformer_configs (e.g. "
+                    "meta-llama/Llama-3.3-70B-Instruct with --parallel pp on 8 GPUs); the headline metric is quoted on the default")
     ap.add_argument("--torch-sampling", action="store_true", help="sample with the reference's torch ops instead of the fused HIP sampler")
     args = ap.parse_args()
 
@@ -76,7 +78,7 @@ def main():
         _lib.check(L.gq_set_ap_mode(1 if args.mode == "exact" else 0), "gq_set_ap_mode")
 
     torch.manual_seed(1234)
-    model = load_model(MODEL, dev, "ap", args.bits, random_init=True)
+    model = load_model(args.model, dev, "ap", args.bits, random_init=True)
     cfg = model.config
     model.setup_caches(1, SEQ_NEW_TOKENS + 1)
     assert model.native_ready()
@@ -159,7 +161,7 @@ def main():
         with open(tpath) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": "AP-GEMV w1w3 28672x4096",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": "AP-GEMV w1w3 %dx%d" % (2 * I, D),
                 "avg_launch_us": round(t_kernel_us, 3), "algorithmic_bytes_per_launch": bytes_launch}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0 only, bounded sample)
@@ -174,8 +176,8 @@ def main():
             "metric": "decode tokens/sec (bs=1)", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "Llama-3.1-8B-Instruct 2-bit Any-Precision (LNQ format), fused QKV/UpGate, bs=1 decode, "
-                                   "BOS prompt, 100 new tokens per sequence, top_k=32, temperature=0",
+            "config": {"workload": "%s %d-bit Any-Precision (LNQ format), fused QKV/UpGate, bs=1 decode, "
+                                   "BOS prompt, 100 new tokens per sequence, top_k=32, temperature=0" % (cfg.model_name, args.bits),
                        "bits": args.bits, "parallelism": ("pp%d (layer pipeline, p2p hops, %d sequences in flight)" % (world, world)) if pp else ("replicas" if world > 1 else "single"), "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
                        "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -14,7 +14,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from guidedquant_amd import _lib  # noqa: E402
 
-SHAPES = {"wqkv": (6144, 4096), "wo": (4096, 4096), "w1w3": (28672, 4096), "w2": (4096, 14336)}
+SHAPES = {"wqkv": (6144, 4096), "wo": (4096, 4096), "w1w3": (28672, 4096), "w2": (4096, 14336),
+          # Llama-3.3-70B layer shapes (BASELINE config 5)
+          "70b_wqkv": (10240, 8192), "70b_wo": (8192, 8192), "70b_w1w3": (57344, 8192), "70b_w2": (8192, 28672)}
 
 
 def b_ap(bits, N, K):
@@ -63,7 +65,7 @@ def bench_shape(name, N, K, bits, iters=200, min_ws=512 << 20):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--bits", type=int, nargs="*", default=[2, 3, 4])
-    ap.add_argument("--shapes", nargs="*", default=list(SHAPES))
+    ap.add_argument("--shapes", nargs="*", default=["wqkv", "wo", "w1w3", "w2"])
     ap.add_argument("--iters", type=int, default=200)
     a = ap.parse_args()
     for b in a.bits:

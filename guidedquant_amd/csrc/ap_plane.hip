@@ -39,7 +39,10 @@ struct PlaneArgs {
     uint16_t *out;
     const uint16_t *normw;
     const uint16_t *resid;
-    u32 N, K;
+    u32 N, K;    // K = the columns served by this launch (a slice of the row when the matrix is split along K)
+    u32 wpr_ld;  // plane words per stored row (row stride), word0 = first plane word of the slice (multiple of 32)
+    u32 word0;
+    u32 x_ld;    // activations per batch row in memory
     u32 RGB;     // row groups (16 rows) per block
     u32 log2CS;  // a row group's chunks are split over 2^log2CS wave items
     u32 cpi;     // chunks per item
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     u32x4 rawv[NI], rawa[NI];
     const u32 pt = l & 31u, pb = ((w & 1u) << 1) | (l >> 5);  // the same for every pass (E * 64 is a multiple of 128)
     if (early) {
-        const u32x4 rsx = make_rsrc(a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
+        const u32x4 rsx = make_rsrc(a.x + (size_t)m * a.x_ld, (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
         const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
         if (a.rawx) {
 #pragma unroll
@@ -244,7 +247,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     const u32 my_steps = (a.xflags & 2u) ? 0u : items_w * cpi;
     auto item_after = [&](u32 item) { return item < L ? L + w : item + W; };  // the wave's next item
     const u32 item0 = first_late ? w - E : L + w;
-    const u32 plane_bytes = a.N * G.wpr * 4u;
+    const u32 plane_bytes = a.N * a.wpr_ld * 4u;
     const u32x4 rq = make_rsrc(a.qw, plane_bytes * (u32)BITS);
     const u32 ring_lds = (u32)(uintptr_t)ring;
     // Per-lane part of a tile address is constant (atile_src); the tile part is wave-uniform and goes into the
@@ -255,9 +258,9 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     {
         u32 lr, lseg;
         atile_src(0u, l, lr, lseg);
-        lane_off[0] = (lr * G.wpr + 4u * lseg) * 4u;
+        lane_off[0] = (lr * a.wpr_ld + 4u * lseg) * 4u;
         atile_src(1u, l, lr, lseg);
-        lane_off[1] = (lr * G.wpr + 4u * lseg) * 4u;
+        lane_off[1] = (lr * a.wpr_ld + 4u * lseg) * 4u;
     }
     u32 iq_item = item0, iq_c = 0, iq_slot = 0, iq_n = 0;  // next step to request
     auto issue = [&]() {
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         const u32 chunk = (iq_item & (CS - 1u)) * cpi + iq_c;
         const u32 rgi = rg0 + (iq_item >> a.log2CS);
         const u32 slot_lds = ring_lds + iq_slot * SLOT;
-        const u32 tile_off = (rgi * 16u * G.wpr + 32u * (chunk < G.nchunks ? chunk : 0u)) * 4u;
+        const u32 tile_off = (rgi * 16u * a.wpr_ld + a.word0 + 32u * (chunk < G.nchunks ? chunk : 0u)) * 4u;
 #pragma unroll
         for (u32 p = 0; p < (u32)BITS; p++)
 #pragma unroll
@@ -720,31 +723,31 @@ unsigned long long *g_dbg = nullptr;
 
 extern "C" void gq_debug_set_timing_buffer(void *p) { g_dbg = (unsigned long long *)p; }
 
-// returns GQ_ENOTSUP when the shape is not served by this path (caller falls back to the exact kernels)
-int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
-                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
-    if (bits < 2 || bits > 4) return GQ_ENOTSUP;
-    const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
-    if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
-    if (((uintptr_t)qweight | (uintptr_t)x | (uintptr_t)normw) & 15u) return GQ_ENOTSUP;
+namespace {
+int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t Kfull,
+                       uint32_t k0, uint32_t Ks, int bits, const void *normw, float eps, const void *resid, int pro, int pairs,
+                       hipStream_t stream) {
     PlaneCfg c;
-    if (!pick_plane_cfg(N, K, bits, c)) return GQ_ENOTSUP;
+    if (!pick_plane_cfg(N, Ks, bits, c)) return GQ_ENOTSUP;
     PlaneArgs a{};
     a.qw = qweight;
     a.lut = (const uint16_t *)lut;
-    a.x = (const uint16_t *)x;
+    a.x = (const uint16_t *)x + k0;
     a.out = (uint16_t *)out;
     a.normw = (const uint16_t *)normw;
     a.resid = (const uint16_t *)resid;
     a.N = N;
-    a.K = K;
+    a.K = Ks;
+    a.wpr_ld = Kfull / 32u;
+    a.word0 = k0 / 32u;
+    a.x_ld = pro == PRO_SILUMUL ? 2u * Kfull : Kfull;
     a.RGB = c.RGB;
     a.log2CS = c.log2CS;
     a.cpi = c.cpi;
     a.S = c.S;
     a.pairs = pairs ? 1u : 0u;
     {
-        const size_t need = (size_t)K * 2u * (pro == PRO_NONE ? 1u : 2u), have = (size_t)(c.T / 128u) * c.S * 2048u * (size_t)bits;
+        const size_t need = (size_t)Ks * 2u * (pro == PRO_NONE ? 1u : 2u), have = (size_t)(c.T / 128u) * c.S * 2048u * (size_t)bits;
         a.rawx = (need <= have && gq_env_int("GQ_PL_RAWX", 1)) ? 1u : 0u;
     }
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);
@@ -755,4 +758,26 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
         case 3: return launch_plane<3>(a, c, M, pro, stream);
         default: return launch_plane<4>(a, c, M, pro, stream);
     }
+}
+}  // namespace
+
+// returns GQ_ENOTSUP when the shape is not served by this path (caller falls back to the exact kernels)
+int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
+                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
+    if (bits < 2 || bits > 4) return GQ_ENOTSUP;
+    const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
+    if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
+    if (((uintptr_t)qweight | (uintptr_t)x | (uintptr_t)normw) & 15u) return GQ_ENOTSUP;
+    if (K <= 16384u) return plane_launch_slice(x, out, qweight, lut, M, N, K, 0u, K, bits, normw, eps, resid, pro, pairs, stream);
+    // 16384 < K <= 32768 (the 70B down projection): the B image of the whole row does not fit LDS, so the row is split at a
+    // chunk boundary into two launches; the second adds its half to the first one's fp16 result through the residual
+    // epilogue (out[n] = out[n] + y2[n], every element read and written by the same lane).  Two fp16 roundings instead
+    // of one; plain and residual epilogues only.
+    if (K > 32768u || K % 256u || pro != PRO_NONE || pairs) return GQ_ENOTSUP;
+    const uint32_t k1 = ((K / 2u + 1023u) / 1024u) * 1024u;
+    PlaneCfg c;
+    if (!pick_plane_cfg(N, k1, bits, c) || !pick_plane_cfg(N, K - k1, bits, c)) return GQ_ENOTSUP;
+    int rc = plane_launch_slice(x, out, qweight, lut, M, N, K, 0u, k1, bits, nullptr, eps, resid, pro, 0, stream);
+    if (rc != GQ_OK) return rc;
+    return plane_launch_slice(x, out, qweight, lut, M, N, K, k1, K - k1, bits, nullptr, eps, out, pro, 0, stream);
 }

@@ -1,6 +1,6 @@
 // fp4_probe.hip -- v_mfma_scale_f32_16x16x128_f8f6f4 with A = FP4 (e2m1, cbsz = 4) and B = BF8 (e5m2, blgp = 1):
 // for an A one-hot (lane la, VGPR va, nibble ia) find, by brute force over all 2048 single B bytes, the B positions
-// (lane lb, VGPR vb, byte bb) with a nonzero product; the nibble pattern values are printed first.
+// (lane lb, VGPR vb, byte bb) with a nonzero product (A nibble 0x2 = 1.0, B byte 0x3C = 1.0).
 // Result: A (lane group g = lane / 16, VGPR v, nibble i) is k = 32 g + 8 v + i; B keeps k = 64 (vb / 4) + 16 kb + 4 (vb % 4) + bb;
 // patterns 0x1 / 0x2 / 0x4 / 0x8 = 0.5 / 1 / 2 / -0.   Build: hipcc --offload-arch=gfx950 -O3 fp4_probe.hip -o fp4_probe
 #include <hip/hip_runtime.h>

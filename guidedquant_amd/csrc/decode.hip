@@ -61,27 +61,38 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
     float *red2 = red + 4 * HD + 16;              // [4 waves * positions-per-wave-instruction][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
     const u32 h = blockIdx.x, group = H / Hkv, g = h / group;
-    u32 pos = (u32)pos_ptr[0];
-    if (pos >= max_seq) pos = max_seq - 1;
     const uint16_t *q = qkv + (size_t)h * HD;
     const uint16_t *k = qkv + (size_t)H * HD + (size_t)g * HD;
     const uint16_t *v = qkv + (size_t)(H + Hkv) * HD + (size_t)g * HD;
+    // q / k / v do not depend on the position: their loads are issued before the position is read, so the two
+    // dependent round trips (position -> cos / sin rows) overlap with them
+    uint16_t qd_b = 0, kd_b = 0, qr_b = 0, kr_b = 0, vd_b = 0;
+    if (tid < HD) {
+        const u32 d = tid, dr = d < HD / 2 ? d + HD / 2 : d - HD / 2;
+        qd_b = q[d];
+        kd_b = k[d];
+        qr_b = q[dr];
+        kr_b = k[dr];
+        vd_b = v[d];
+    }
+    u32 pos = (u32)pos_ptr[0];
+    if (pos >= max_seq) pos = max_seq - 1;
     uint16_t *kcg = kc + (size_t)g * max_seq * HD;
     uint16_t *vcg = vc + (size_t)g * max_seq * HD;
     if (tid < HD) {
         const u32 d = tid;
         const h16 c = u2h(cos_t[(size_t)pos * HD + d]), s = u2h(sin_t[(size_t)pos * HD + d]);
-        const h16 qd = u2h(q[d]), kd = u2h(k[d]);
-        const h16 qr = d < HD / 2 ? -u2h(q[d + HD / 2]) : u2h(q[d - HD / 2]);
-        const h16 kr = d < HD / 2 ? -u2h(k[d + HD / 2]) : u2h(k[d - HD / 2]);
+        const h16 qd = u2h(qd_b), kd = u2h(kd_b);
+        const h16 qr = d < HD / 2 ? -u2h(qr_b) : u2h(qr_b);
+        const h16 kr = d < HD / 2 ? -u2h(kr_b) : u2h(kr_b);
         const h16 qe = (h16)(qd * c) + (h16)(qr * s);
         const h16 ke = (h16)(kd * c) + (h16)(kr * s);
         qs[d] = (float)qe;
         kcur[d] = (float)ke;
-        vcur[d] = h2f(v[d]);
+        vcur[d] = h2f(vd_b);
         if (h % group == 0) {
             kcg[(size_t)pos * HD + d] = h2u(ke);
-            vcg[(size_t)pos * HD + d] = v[d];
+            vcg[(size_t)pos * HD + d] = vd_b;
         }
     }
     __syncthreads();

@@ -48,8 +48,9 @@ __global__ void embed_kernel(const int *tok, const uint16_t *table, uint16_t *ou
 // built by the host from fp32 (LlamaRotaryEmbedding.forward, model.py:379-405).  The rotated k and the v of this
 // token are written to the cache at `pos` (KVCache.update, model.py:69-79) by the first head of each KV group.
 // Scores / softmax / weighted sum run in fp32 from the fp16 operands; the output is rounded to fp16 once.
+constexpr int ATTN_WAVES = 8;  // 8 waves x 4 positions x 4 in flight = 128 positions per pass (HD = 128)
 template <int HD>
-__global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, const int *pos_ptr, const uint16_t *cos_t,
+__global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint16_t *qkv, const int *pos_ptr, const uint16_t *cos_t,
                                                           const uint16_t *sin_t, uint16_t *kc, uint16_t *vc, uint16_t *out,
                                                           u32 H, u32 Hkv, u32 max_seq, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -57,8 +58,9 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
     float *qs = sc + max_seq;                     // [HD]
     float *kcur = qs + HD;                        // [HD]
     float *vcur = kcur + HD;                      // [HD]
-    float *red = vcur + HD;                       // [4 * HD] (+8 scratch at 4*HD)
-    float *red2 = red + 4 * HD + 16;              // [4 waves * positions-per-wave-instruction][HD] partial outputs
+    constexpr u32 NW = ATTN_WAVES, NT = 64 * ATTN_WAVES;
+    float *red = vcur + HD;                       // [4 * HD] (+ 2 * NW scratch at 4*HD)
+    float *red2 = red + 4 * HD + 2 * NW;          // [NW waves * positions-per-wave-instruction][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
     const u32 h = blockIdx.x, group = H / Hkv, g = h / group;
     const uint16_t *q = qkv + (size_t)h * HD;
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
     float qreg[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) qreg[e] = qs[ld * 8 + e];
-    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += 4 * PPW * U) {
+    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += NW * PPW * U) {
         uint4 kv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -137,26 +139,30 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
     }
     __syncthreads();
     float mx = -3.0e38f;
-    for (u32 t = tid; t <= pos; t += 256) mx = fmaxf(mx, sc[t]);
+    for (u32 t = tid; t <= pos; t += NT) mx = fmaxf(mx, sc[t]);
     mx = wave_reduce<true>(mx);
     if (l == 0) red[4 * HD + w] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[4 * HD], red[4 * HD + 1]), fmaxf(red[4 * HD + 2], red[4 * HD + 3]));
+    mx = red[4 * HD];
+#pragma unroll
+    for (u32 i = 1; i < NW; i++) mx = fmaxf(mx, red[4 * HD + i]);
     float sum = 0.f;
-    for (u32 t = tid; t <= pos; t += 256) {
+    for (u32 t = tid; t <= pos; t += NT) {
         const float e = __expf(sc[t] - mx);
         sc[t] = e;
         sum += e;
     }
     sum = wave_reduce<false>(sum);
-    if (l == 0) red[4 * HD + 4 + w] = sum;
+    if (l == 0) red[4 * HD + NW + w] = sum;
     __syncthreads();
-    sum = red[4 * HD + 4] + red[4 * HD + 5] + red[4 * HD + 6] + red[4 * HD + 7];
+    sum = 0.f;
+#pragma unroll
+    for (u32 i = 0; i < NW; i++) sum += red[4 * HD + NW + i];
     // weighted sum of values, same lane layout: lane (sub, ld) accumulates 8 dims over its positions
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += 4 * PPW * U) {
+    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += NW * PPW * U) {
         uint4 vv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -188,7 +194,7 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const uint16_t *qkv, c
     if (tid < HD) {
         float o = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4 * PPW; i++) o += red2[i * HD + tid];
+        for (int i = 0; i < (int)(NW * PPW); i++) o += red2[i * HD + tid];
         out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
     }
 }
@@ -434,7 +440,7 @@ extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_t
     if (!qkv || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (n_kv_head == 0 || n_head % n_kv_head) return gq_fail(GQ_EINVAL, "n_head must be a multiple of n_kv_head.");
     if (head_dim != 64 && head_dim != 128) return gq_fail(GQ_ENOTSUP, "head_dim must be 64 or 128.");
-    const size_t smem = ((size_t)max_seq + 7u * head_dim + 32u + (size_t)(4u * 64u / (head_dim / 8u)) * head_dim) * 4u;
+    const size_t smem = ((size_t)max_seq + 7u * head_dim + 2u * ATTN_WAVES + 16u + (size_t)((u32)ATTN_WAVES * 64u / (head_dim / 8u)) * head_dim) * 4u;
     if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "max_seq too large for the single-pass attention kernel.");
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 128) {
@@ -444,7 +450,7 @@ extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_t
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             set = true;
         }
-        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(n_head), dim3(256), smem, s, (const uint16_t *)qkv, pos,
+        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(n_head), dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
                            (uint16_t *)out, n_head, n_kv_head, max_seq, scale);
     } else {
@@ -454,7 +460,7 @@ extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_t
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             set = true;
         }
-        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(n_head), dim3(256), smem, s, (const uint16_t *)qkv, pos,
+        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(n_head), dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
                            (uint16_t *)out, n_head, n_kv_head, max_seq, scale);
     }

@@ -54,11 +54,11 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
                                                           const uint16_t *sin_t, uint16_t *kc, uint16_t *vc, uint16_t *out,
                                                           u32 H, u32 Hkv, u32 max_seq, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *sc = reinterpret_cast<float *>(smem);  // [max_seq] scores / probabilities
-    float *qs = sc + max_seq;                     // [HD]
+    constexpr u32 NW = ATTN_WAVES;
+    float *sc = reinterpret_cast<float *>(smem);  // [2 * NW * 64 / (HD / 8)] running max / sum of the position streams
+    float *qs = sc + 2u * NW * (64u / (HD / 8u));  // [HD]
     float *kcur = qs + HD;                        // [HD]
     float *vcur = kcur + HD;                      // [HD]
-    constexpr u32 NW = ATTN_WAVES, NT = 64 * ATTN_WAVES;
     float *red = vcur + HD;                       // [4 * HD] (+ 2 * NW scratch at 4*HD)
     float *red2 = red + 4 * HD + 2 * NW;          // [NW waves * positions-per-wave-instruction][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
@@ -98,8 +98,11 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
         }
     }
     __syncthreads();
-    // scores: 16 lanes per position (8 dims = one 16-byte load per lane, a position's row is one coalesced 256-byte
-    // line pair), 4 positions per wave-instruction, U independent iterations in flight per wave.
+    // One pass, online softmax per position stream.  16 lanes per position (8 dims = one 16-byte load per lane, a
+    // position's K / V row is one coalesced 256-byte line pair), PPW positions per wave instruction, U independent
+    // positions in flight per lane group; the K and the V rows of a batch are requested together (one memory round trip
+    // instead of two), and each lane group keeps a running (max, sum, weighted V) that is rescaled when the max moves.
+    // The NW * PPW streams of the block are combined once, through LDS.
     constexpr int LPP = HD / 8;          // lanes per position: 16 (HD=128) or 8 (HD=64)
     constexpr int PPW = 64 / LPP;        // positions per wave instruction
     constexpr int U = 4;
@@ -107,94 +110,74 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
     float qreg[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) qreg[e] = qs[ld * 8 + e];
+    float m_run = -3.0e38f, s_run = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
     for (u32 t0 = w * PPW * U; t0 <= pos; t0 += NW * PPW * U) {
-        uint4 kv[U];
+        uint4 kv[U], vv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const u32 t = t0 + (u32)u * PPW + sub;
             kv[u] = t < pos ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u32 t = t0 + (u32)u * PPW + sub;
-            const u32 ww[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
-            float p = 0.f;
-            if (t == pos) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) p += qreg[e] * kcur[ld * 8 + e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    p += qreg[2 * e] * h2f((uint16_t)(ww[e] & 0xFFFF));
-                    p += qreg[2 * e + 1] * h2f((uint16_t)(ww[e] >> 16));
-                }
-            }
-            // sum over the LPP lanes of this position (xor butterflies inside a 16-lane DPP row)
-            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
-            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
-            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
-            if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
-            if (ld == 0 && t <= pos) sc[t] = p * scale;
-        }
-    }
-    __syncthreads();
-    float mx = -3.0e38f;
-    for (u32 t = tid; t <= pos; t += NT) mx = fmaxf(mx, sc[t]);
-    mx = wave_reduce<true>(mx);
-    if (l == 0) red[4 * HD + w] = mx;
-    __syncthreads();
-    mx = red[4 * HD];
-#pragma unroll
-    for (u32 i = 1; i < NW; i++) mx = fmaxf(mx, red[4 * HD + i]);
-    float sum = 0.f;
-    for (u32 t = tid; t <= pos; t += NT) {
-        const float e = __expf(sc[t] - mx);
-        sc[t] = e;
-        sum += e;
-    }
-    sum = wave_reduce<false>(sum);
-    if (l == 0) red[4 * HD + NW + w] = sum;
-    __syncthreads();
-    sum = 0.f;
-#pragma unroll
-    for (u32 i = 0; i < NW; i++) sum += red[4 * HD + NW + i];
-    // weighted sum of values, same lane layout: lane (sub, ld) accumulates 8 dims over its positions
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += NW * PPW * U) {
-        uint4 vv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u32 t = t0 + (u32)u * PPW + sub;
             vv[u] = t < pos ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const u32 t = t0 + (u32)u * PPW + sub;
-            if (t > pos) continue;
-            const float p = sc[t];
+            const u32 kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w}, vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+            float p = 0.f, vf[8];
             if (t == pos) {
 #pragma unroll
-                for (int e = 0; e < 8; e++) acc[e] += p * vcur[ld * 8 + e];
+                for (int e = 0; e < 8; e++) {
+                    p += qreg[e] * kcur[ld * 8 + e];
+                    vf[e] = vcur[ld * 8 + e];
+                }
             } else {
-                const u32 ww[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    acc[2 * e] += p * h2f((uint16_t)(ww[e] & 0xFFFF));
-                    acc[2 * e + 1] += p * h2f((uint16_t)(ww[e] >> 16));
+                    p += qreg[2 * e] * h2f((uint16_t)(kw[e] & 0xFFFF));
+                    p += qreg[2 * e + 1] * h2f((uint16_t)(kw[e] >> 16));
+                    vf[2 * e] = h2f((uint16_t)(vw[e] & 0xFFFF));
+                    vf[2 * e + 1] = h2f((uint16_t)(vw[e] >> 16));
                 }
+            }
+            // sum over the LPP lanes of this position (xor butterflies inside a 16-lane DPP row): every lane gets the score
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
+            if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
+            if (t <= pos) {
+                p *= scale;
+                const float m_new = fmaxf(m_run, p);
+                const float resc = __expf(m_run - m_new), wgt = __expf(p - m_new);
+                s_run = s_run * resc + wgt;
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] = acc[e] * resc + wgt * vf[e];
+                m_run = m_new;
             }
         }
     }
-    // red: [4 waves * PPW position groups][HD]
+    // combine the streams: red2[stream][HD] weighted sums, sc[stream] = running max, sc[NS + stream] = running sum
+    constexpr u32 NS = NW * PPW;
+    const u32 stream = w * PPW + sub;
 #pragma unroll
-    for (int e = 0; e < 8; e++) red2[(w * PPW + sub) * HD + ld * 8 + e] = acc[e];
+    for (int e = 0; e < 8; e++) red2[stream * HD + ld * 8 + e] = acc[e];
+    if (ld == 0) {
+        sc[stream] = m_run;
+        sc[NS + stream] = s_run;
+    }
     __syncthreads();
     if (tid < HD) {
-        float o = 0.f;
+        float M = -3.0e38f;
 #pragma unroll
-        for (int i = 0; i < (int)(NW * PPW); i++) o += red2[i * HD + tid];
+        for (u32 i = 0; i < NS; i++) M = fmaxf(M, sc[i]);
+        float o = 0.f, sum = 0.f;
+#pragma unroll
+        for (u32 i = 0; i < NS; i++) {
+            const float f = __expf(sc[i] - M);  // streams without a position: exp(-3e38 - M) = 0
+            sum += sc[NS + i] * f;
+            o += red2[i * HD + tid] * f;
+        }
         out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
     }
 }
@@ -440,8 +423,8 @@ extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_t
     if (!qkv || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (n_kv_head == 0 || n_head % n_kv_head) return gq_fail(GQ_EINVAL, "n_head must be a multiple of n_kv_head.");
     if (head_dim != 64 && head_dim != 128) return gq_fail(GQ_ENOTSUP, "head_dim must be 64 or 128.");
-    const size_t smem = ((size_t)max_seq + 7u * head_dim + 2u * ATTN_WAVES + 16u + (size_t)((u32)ATTN_WAVES * 64u / (head_dim / 8u)) * head_dim) * 4u;
-    if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "max_seq too large for the single-pass attention kernel.");
+    const u32 nstreams = (u32)ATTN_WAVES * 64u / (head_dim / 8u);
+    const size_t smem = ((size_t)2u * nstreams + 7u * head_dim + 2u * ATTN_WAVES + 16u + (size_t)nstreams * head_dim) * 4u;
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 128) {
         static bool set = false;

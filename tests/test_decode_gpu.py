@@ -265,3 +265,39 @@ def test_silu_pairs_epilogue_matches_separate_ops(mode, N, K):
     assert float((o != want).float().mean()) < 0.02
     # validation
     assert L.gq_anyprec_gemv_fused(x.data_ptr(), o.data_ptr(), qp.data_ptr(), lp.data_ptr(), N, K, 2, None, 0.0, y.data_ptr(), 5, None) != 0
+
+
+@pytest.mark.parametrize("hd,H,Hkv", [(128, 32, 8), (64, 8, 2)])
+def test_attention_kernel_long_context(hd, H, Hkv):
+    """several passes of the position loop (128 positions per pass at head_dim 128) and a context far beyond what a
+    score buffer in LDS would hold: pre-filled caches, decode at positions up to 5000"""
+    from guidedquant_amd import _lib
+    from guidedquant_amd.model import apply_rotary_pos_emb, rope_tables
+    d = _dev()
+    L = _lib.lib()
+    max_seq = 5120
+    g = torch.Generator(device=d)
+    g.manual_seed(7)
+    cos, sin = rope_tables(hd, max_seq, 500000.0, d)
+    kc = (torch.randn(1, Hkv, max_seq, hd, device=d, generator=g) * 0.5).half()
+    vc = (torch.randn(1, Hkv, max_seq, hd, device=d, generator=g)).half()
+    out = torch.zeros(H * hd, dtype=torch.float16, device=d)
+    for p in (127, 128, 129, 1000, 4999):
+        kc_ref, vc_ref = kc.clone(), vc.clone()
+        qkv = torch.randn((H + 2 * Hkv) * hd, device=d, generator=g).half()
+        pos = torch.tensor([p], dtype=torch.int32, device=d)
+        _lib.check(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                    out.data_ptr(), H, Hkv, hd, max_seq, 1.0 / math.sqrt(hd), _lib.current_stream_ptr()), "attn")
+        q, k, v = qkv.split([H * hd, Hkv * hd, Hkv * hd])
+        q = q.view(1, 1, H, hd).transpose(1, 2)
+        k = k.view(1, 1, Hkv, hd).transpose(1, 2)
+        v = v.view(1, 1, Hkv, hd).transpose(1, 2)
+        q, k = apply_rotary_pos_emb(q, k, cos[p:p + 1].unsqueeze(0), sin[p:p + 1].unsqueeze(0))
+        kc_ref[:, :, p] = k[:, :, 0]
+        vc_ref[:, :, p] = v[:, :, 0]
+        kk = kc_ref[:, :, :p + 1].float().repeat_interleave(H // Hkv, dim=1)
+        vv = vc_ref[:, :, :p + 1].float().repeat_interleave(H // Hkv, dim=1)
+        ref = (torch.softmax((q.float() @ kk.transpose(-1, -2)) / math.sqrt(hd), dim=-1) @ vv).transpose(1, 2).reshape(-1)
+        torch.cuda.synchronize()
+        assert torch.equal(kc[:, :, p], kc_ref[:, :, p]) and torch.equal(vc[:, :, p], vc_ref[:, :, p])
+        assert (out.float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())

@@ -313,82 +313,69 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     int sb = 127;
     if (early) {
     wait_vm<0>();  // the activation loads (an early wave has nothing else in flight)
-    if (a.rawx) {
-        unsigned char *raw = smem;  // the early waves' ring slots
-#pragma unroll
-        for (u32 n = 0; n < (u32)NI; n++) {
-            tie128(rawv[n]);
-            const u32 idx = tid + n * (E * 64u);
-            if (idx < G.K / 8u) {
-                *reinterpret_cast<u32x4 *>(raw + 16u * idx) = rawv[n];
-                if constexpr (PRO != PRO_NONE) {
-                    tie128(rawa[n]);
-                    *reinterpret_cast<u32x4 *>(raw + 2u * G.K + 16u * idx) = rawa[n];
-                }
-            }
-        }
-        arrive(ctr + 2, l);
-        wait_count(ctr + 2, E);
-        const uint16_t *rx = reinterpret_cast<const uint16_t *>(raw), *ra = rx + G.K;
-#pragma unroll
-        for (u32 n = 0; n < (u32)NI; n++) {
-            const u32 chunk = (w >> 1) + n * (E / 2u);
-            const u32 tp = G.tpw(chunk);
-            const bool ok = chunk < G.nchunks && pt < tp;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
-                const u32 e = 1024u * chunk + 8u * tp * c + 8u * pt + 3u - pb;
-                xr[n][c] = ok ? ((u32)rx[e + 4u] | ((u32)rx[e] << 16)) : 0u;
-                if constexpr (PRO != PRO_NONE) ar[n][c] = ok ? ((u32)ra[e + 4u] | ((u32)ra[e] << 16)) : 0u;
-            }
-        }
-    } else {
-#pragma unroll
-        for (u32 n = 0; n < (u32)NI; n++) {
-            tie4(xr[n]);
-            tie4(xh[n]);
-            if constexpr (PRO != PRO_NONE) {
-                tie4(ar[n]);
-                tie4(ah[n]);
-            }
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
-                xr[n][c] |= xh[n][c] << 16;
-                if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
-            }
-        }
-    }
-    // ---------------------------------------------------------------- 1. statistics -> barrier
-    // RMSNorm: sum x^2 and max |x * w| (bounds the normalised maximum); otherwise max |x'| of the transformed vector
+    // ---------------------------------------------------------------- 1. statistics (+ staging) -> one early-wave barrier
+    // RMSNorm: sum x^2 and max |x * w| (bounds the normalised maximum); otherwise max |x'| of the transformed vector.
+    // With the LDS staging they are taken in the coalesced (raw) domain, before the copy is written, so the staging
+    // barrier is also the statistics barrier; SiLU(gate) * up is applied there too and only the product is staged.
     float nscale = 0.f, xmax = 0.f;
     {
         float ss = 0.f, mx = 0.f;
         u32 mxi = 0;
+        auto silu_mul = [](u32 gw, u32 uw) {  // F.silu(gate) * up on fp16 tensors -- inference/model.py:266
+            _Float16 hh[2];
 #pragma unroll
-        for (u32 n = 0; n < (u32)NI; n++)
+            for (int k = 0; k < 2; k++) {
+                const float gv = h2f((uint16_t)(gw >> (16 * k)));
+                hh[k] = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, (uint16_t)(uw >> (16 * k)));
+            }
+            return (u32)__builtin_bit_cast(uint16_t, hh[0]) | ((u32)__builtin_bit_cast(uint16_t, hh[1]) << 16);
+        };
+        auto stat = [&](u32 xw, u32 aw) {  // one packed pair of activations (and of norm weights)
+            if constexpr (PRO == PRO_RMSNORM) {
+                const float p = h2f(xw & 0xFFFF), q = h2f(xw >> 16);
+                ss += p * p;
+                ss += q * q;
+                mx = fmaxf(mx, fmaxf(fabsf(p * h2f(aw & 0xFFFF)), fabsf(q * h2f(aw >> 16))));
+            } else {
+                const u32 ab = xw & 0x7FFF7FFFu;  // |fp16| bit patterns order like unsigned integers
+                mxi = max(mxi, max(ab & 0xFFFFu, ab >> 16));
+            }
+        };
+        if (a.rawx) {
+            unsigned char *raw = smem;  // the early waves' ring slots
 #pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                if constexpr (PRO == PRO_RMSNORM) {
-                    const float p = h2f(xr[n][c] & 0xFFFF), q = h2f(xr[n][c] >> 16);
-                    ss += p * p;
-                    ss += q * q;
-                    mx = fmaxf(mx, fmaxf(fabsf(p * h2f(ar[n][c] & 0xFFFF)), fabsf(q * h2f(ar[n][c] >> 16))));
-                } else {
-                    if constexpr (PRO == PRO_SILUMUL) {
-                        // F.silu(gate) * up on fp16 tensors -- inference/model.py:266
-                        _Float16 hh[2];
+            for (u32 n = 0; n < (u32)NI; n++) {
+                tie128(rawv[n]);
+                if constexpr (PRO != PRO_NONE) tie128(rawa[n]);
 #pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const float gv = h2f((uint16_t)(xr[n][c] >> (16 * k)));
-                            hh[k] = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, (uint16_t)(ar[n][c] >> (16 * k)));
-                        }
-                        xr[n][c] = (u32)__builtin_bit_cast(uint16_t, hh[0]) | ((u32)__builtin_bit_cast(uint16_t, hh[1]) << 16);
-                    }
-                    // |fp16| bit patterns order like unsigned integers
-                    const u32 ab = xr[n][c] & 0x7FFF7FFFu;
-                    mxi = max(mxi, max(ab & 0xFFFFu, ab >> 16));
+                for (int k = 0; k < 4; k++) {
+                    if constexpr (PRO == PRO_SILUMUL) rawv[n][k] = silu_mul(rawv[n][k], rawa[n][k]);
+                    stat(rawv[n][k], PRO == PRO_RMSNORM ? rawa[n][k] : 0u);
+                }
+                const u32 idx = tid + n * (E * 64u);
+                if (idx < G.K / 8u) {
+                    *reinterpret_cast<u32x4 *>(raw + 16u * idx) = rawv[n];
+                    if constexpr (PRO == PRO_RMSNORM) *reinterpret_cast<u32x4 *>(raw + 2u * G.K + 16u * idx) = rawa[n];
                 }
             }
+        } else {
+#pragma unroll
+            for (u32 n = 0; n < (u32)NI; n++) {
+                tie4(xr[n]);
+                tie4(xh[n]);
+                if constexpr (PRO != PRO_NONE) {
+                    tie4(ar[n]);
+                    tie4(ah[n]);
+                }
+#pragma unroll
+                for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
+                    xr[n][c] |= xh[n][c] << 16;
+                    if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
+                    if constexpr (PRO == PRO_SILUMUL) xr[n][c] = silu_mul(xr[n][c], ar[n][c]);
+                    stat(xr[n][c], PRO == PRO_RMSNORM ? ar[n][c] : 0u);
+                }
+            }
+        }
         if constexpr (PRO != PRO_RMSNORM) mx = h2f((uint16_t)mxi);
         mx = wave_reduce<true>(mx);
         if constexpr (PRO == PRO_RMSNORM) ss = wave_reduce<false>(ss);
@@ -406,6 +393,22 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
             for (u32 i = 0; i < E; i++) tot += red[16 + i];
             nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
             xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
+        }
+        if (a.rawx) {
+            // the staged copy is complete: gather this thread's items (for SiLU the staged vector is already the product)
+            const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;
+#pragma unroll
+            for (u32 n = 0; n < (u32)NI; n++) {
+                const u32 chunk = (w >> 1) + n * (E / 2u);
+                const u32 tp = G.tpw(chunk);
+                const bool ok = chunk < G.nchunks && pt < tp;
+#pragma unroll
+                for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
+                    const u32 e = 1024u * chunk + 8u * tp * c + 8u * pt + 3u - pb;
+                    xr[n][c] = ok ? ((u32)rx[e + 4u] | ((u32)rx[e] << 16)) : 0u;
+                    if constexpr (PRO == PRO_RMSNORM) ar[n][c] = ok ? ((u32)ra[e + 4u] | ((u32)ra[e] << 16)) : 0u;
+                }
+            }
         }
     }
     stamp(7);
@@ -747,7 +750,7 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
     a.S = c.S;
     a.pairs = pairs ? 1u : 0u;
     {
-        const size_t need = (size_t)Ks * 2u * (pro == PRO_NONE ? 1u : 2u), have = (size_t)(c.T / 128u) * c.S * 2048u * (size_t)bits;
+        const size_t need = (size_t)Ks * 2u * (pro == PRO_RMSNORM ? 2u : 1u), have = (size_t)(c.T / 128u) * c.S * 2048u * (size_t)bits;
         a.rawx = (need <= have && gq_env_int("GQ_PL_RAWX", 1)) ? 1u : 0u;
     }
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);

@@ -654,9 +654,10 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     if (rgb < 1) rgb = 1;
     c.RGB = rgb;
     c.grid = (RGt + rgb - 1u) / rgb;
-    // split K of a row group over 2^log2CS items until the block has ~1.5 items per wave
+    // split K of a row group over 2^log2CS items until the block has about 3/4 of an item per wave (measured over the 8B and
+    // 70B shapes: 12..16 items per 16-wave block is the optimum -- fewer item ends / partial sums, still every SIMD busy)
     u32 lcs = 0;
-    while (2u * (rgb << lcs) < 3u * W && (2u << lcs) <= nchunks) lcs++;
+    while (4u * (rgb << lcs) < 3u * W && (2u << lcs) <= nchunks) lcs++;
     const int envcs = gq_env_int("GQ_PL_LOG2CS", -1);
     if (envcs >= 0 && (1u << envcs) <= nchunks) lcs = (u32)envcs;
     c.log2CS = lcs;

@@ -166,3 +166,37 @@ def test_load_model_qtip_backend_builds_unfused_tree():
     assert att.wk.out_features == 128 and ff.w2.in_features == 512 and att.wq.K == 2 and att.wq.decode_mode == "quantlut_sym"
     assert att.wq.trellis.dtype == torch.int16 and att.wq.trellis.shape == (256 // 16 * (256 // 16), 16 * 16 * 2 // 16)
     assert bool(att.wq.trellis.any()) and set(att.wq.SU.unique().tolist()) <= {-1.0, 1.0}
+
+
+def test_hf_anyprec_loader(tmp_path):
+    """HF-layout checkpoint directory (config.json with the anyprec section + safetensors with HF keys, tied embeddings)
+    -> fused Transformer: geometry from the config, strict state-dict load, plane slicing at the requested precision."""
+    import json
+    from safetensors.torch import save_file
+    from guidedquant_amd.hf_loader import load_anyprec_hf, model_args_from_hf_config
+    D, I, H, KV, Lr, V = 256, 512, 4, 2, 2, 128
+    cfg = dict(model_type="llama", _name_or_path="meta-llama/Llama-test", hidden_size=D, intermediate_size=I, num_hidden_layers=Lr,
+               num_attention_heads=H, num_key_value_heads=KV, vocab_size=V, rope_theta=500000.0, rms_norm_eps=1e-5,
+               max_position_embeddings=64, tie_word_embeddings=True, anyprec=dict(seed_precision=2, parent_precision=3))
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    g = torch.Generator().manual_seed(1)
+    hd = D // H
+    sd = {"model.embed_tokens.weight": torch.randn(V, D, generator=g).half(), "model.norm.weight": torch.ones(D).half()}
+    shapes = {"self_attn.q_proj": (D, D), "self_attn.k_proj": (KV * hd, D), "self_attn.v_proj": (KV * hd, D), "self_attn.o_proj": (D, D),
+              "mlp.gate_proj": (I, D), "mlp.up_proj": (I, D), "mlp.down_proj": (D, I)}
+    for i in range(Lr):
+        sd[f"model.layers.{i}.input_layernorm.weight"] = torch.ones(D).half()
+        sd[f"model.layers.{i}.post_attention_layernorm.weight"] = torch.ones(D).half()
+        for name, (n, k) in shapes.items():
+            sd[f"model.layers.{i}.{name}.qweight"] = torch.randint(-2**31, 2**31 - 1, (3, n, k // 32), dtype=torch.int32, generator=g)
+            for b in (2, 3):
+                sd[f"model.layers.{i}.{name}.lut{b}"] = torch.randn(n, 2**b, generator=g).half()
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    a = model_args_from_hf_config(cfg)
+    assert (a.dim, a.n_head, a.n_local_heads, a.head_dim, a.intermediate_size, a.n_layer) == (D, H, KV, hd, I, Lr)
+    m = load_anyprec_hf(str(tmp_path), bitwidth=2, device="cpu")
+    assert m.layers[1].attention.wqkv.qweight.shape == (2, D + 2 * KV * hd, D // 32)
+    assert torch.equal(m.layers[0].feed_forward.w1w3.lut[:I], sd["model.layers.0.mlp.gate_proj.lut2"])
+    assert torch.equal(m.output.weight, sd["model.embed_tokens.weight"])  # tied
+    with pytest.raises(ValueError):
+        load_anyprec_hf(str(tmp_path), bitwidth=4, device="cpu")

@@ -42,9 +42,10 @@ __device__ __forceinline__ u32 unit_of<4>(const u32 (&d)[4], u32 j) { return d[j
 template <int R>
 __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32 *comp, const uint16_t *x, const uint16_t *tlut,
                                                           u32 M, u32 K) {
+    // the codebook sits in a STATIC LDS array (address 0, known to the compiler: the lookup address needs no base add)
+    __shared__ __attribute__((aligned(16))) u32 tl[512];         // [512] half2 codebook
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32 *tl = reinterpret_cast<u32 *>(smem);                    // [512] half2 codebook
-    uint16_t *xs = reinterpret_cast<uint16_t *>(tl + 512);      // [K]
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);          // [K]
     float *part = reinterpret_cast<float *>(xs + K);            // [waves][32 rows]
     const u32 T = blockDim.x, tid = threadIdx.x, W = T >> 6, w = tid >> 6, l = tid & 63u;
     for (u32 i = tid; i < 512u; i += T) tl[i] = reinterpret_cast<const u32 *>(tlut)[i];
@@ -83,13 +84,17 @@ __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32
                 const u32 u = unit_of<R>(d, 2u * a3 + a4);
                 const u32 un = (u32)__shfl((int)u, (int)((l & 32u) | ((s + 1u) & 31u)), 64);
                 const u64 comb = ((u64)u << (8 * R)) | (u64)un;
+                const u32 comb32 = (u << 16) | un;  // R == 2: the whole window in one register
                 const uint16_t *xk = xs + 32u * K2 + 16u * a3 + 2u * b;
                 const u32 x0 = *reinterpret_cast<const u32 *>(xk), x1 = *reinterpret_cast<const u32 *>(xk + 8);
 #pragma unroll
                 for (u32 i = 0; i < 4; i++) {
-                    const u32 st = (u32)(comb >> (16 * R - 2 * R * i - 16)) & 0xFFFFu;
-                    const u32 idx = st * (st + 1u);
-                    const u32 w2 = tl[(idx >> 6) & 0x1FFu] ^ (idx & 0x8000u);
+                    // state -> st * (st + 1) (24-bit multiply-add: st < 2^16) -> codebook word at byte (idx >> 4) & 0x7FC,
+                    // sign of the low half folded in with one 3-input op
+                    const u32 st = R == 2 ? __builtin_amdgcn_ubfe(comb32, 16u - 4u * i, 16u)
+                                          : (u32)(comb >> (16 * R - 2 * R * i - 16)) & 0xFFFFu;
+                    const u32 idx = __umul24(st, st) + st;
+                    const u32 w2 = *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(tl) + ((idx >> 4) & 0x7FCu)) ^ (idx & 0x8000u);
                     const u32 xv = (i & 2u) ? x1 : x0;  // cc = i / 2
                     if (i & 1u)                        // d = i % 2
                         acc1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, w2), __builtin_bit_cast(h16x2, xv), acc1, false);
@@ -148,7 +153,7 @@ extern "C" int gq_qtip_matvec(float *out, const uint32_t *compressed, const void
     u32 waves = nK2 >= 8u ? 8u : (nK2 >= 4u ? 4u : (nK2 >= 2u ? 2u : 1u));
     // fewer 32-row bands than CUs (e.g. M = 4096: 128 blocks): 16 waves per band shorten the per-wave decode loop
     if (nK2 >= 32u && M / 32u <= 256u) waves = 16u;
-    const size_t smem = 2048u + (size_t)K * 2u + (size_t)waves * 32u * 4u;
+    const size_t smem = (size_t)K * 2u + (size_t)waves * 32u * 4u;  // + 2 KiB static codebook
     if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "K too large.");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(M / 32u), block(waves * 64u);

@@ -48,6 +48,7 @@ struct PlaneArgs {
     u32 cpi;     // chunks per item
     u32 S;       // LDS ring slots (steps) per wave
     u32 rawx;    // the activations are staged through LDS (coalesced 16-byte loads into the early waves' still unused ring slots)
+    u32 himg;    // the late waves build the second half of the image passes (needs rawx; they have little to request)
     u32 pairs;   // GQ_EPI_SILU_PAIRS: rows are (gate, up) pairs, out[i] = silu(y[2i]) * y[2i+1]
     u32 xflags;  // ablation experiments (GQ_PL_XFLAGS): 1 no MFMA work, 2 no steps at all, 8 no activation loads, 16 no LUT, 32 empty kernel,
                  // 256 late waves request only their first item up front, 1024 no plane loads (the MFMA phase runs on stale LDS)
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     // the block is issued before the first plane load; this barrier (the LDS counters are zero behind it) costs the
     // launch skew of the last wave, ~800 cycles.
     if (tid < 4) ctr[tid] = 0u;
+    if (tid < 16) red[32 + tid] = 0.f;
     if (tid < 16) reinterpret_cast<u32 *>(zero32)[tid] = 0u;
     __syncthreads();
     // The LUT rows of the block ride in the queue of the last wave as nlut pseudo steps of exactly LPS loads each
@@ -311,13 +313,13 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
 
     float X = 0.f;
     int sb = 127;
+    float nscale = 0.f, xmax = 0.f;
     if (early) {
     wait_vm<0>();  // the activation loads (an early wave has nothing else in flight)
     // ---------------------------------------------------------------- 1. statistics (+ staging) -> one early-wave barrier
     // RMSNorm: sum x^2 and max |x * w| (bounds the normalised maximum); otherwise max |x'| of the transformed vector.
     // With the LDS staging they are taken in the coalesced (raw) domain, before the copy is written, so the staging
     // barrier is also the statistics barrier; SiLU(gate) * up is applied there too and only the product is staged.
-    float nscale = 0.f, xmax = 0.f;
     {
         float ss = 0.f, mx = 0.f;
         u32 mxi = 0;
@@ -384,6 +386,15 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
             if constexpr (PRO == PRO_RMSNORM) red[16 + w] = ss;
         }
         arrive(ctr + 0, l);
+    }
+    }  // early: staging + statistics
+    // image passes: early wave w takes passes [0, NIe), with a.himg late wave w the passes [NIe, NI) of early wave w - E
+    constexpr u32 NIe = (NI + 1) / 2;
+    const bool helper = !early && a.himg;
+    const u32 vw = early ? w : w - E;
+    const u32 n0 = a.himg ? (early ? 0u : NIe) : 0u, n1 = a.himg ? (early ? NIe : (u32)NI) : (u32)NI;
+    if (early || helper) {
+    {
         wait_count(ctr + 0, E);
 #pragma unroll
         for (u32 i = 0; i < E; i++) xmax = fmaxf(xmax, red[i]);
@@ -399,7 +410,8 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
             const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;
 #pragma unroll
             for (u32 n = 0; n < (u32)NI; n++) {
-                const u32 chunk = (w >> 1) + n * (E / 2u);
+                if (n < n0 || n >= n1) continue;
+                const u32 chunk = (vw >> 1) + n * (E / 2u);
                 const u32 tp = G.tpw(chunk);
                 const bool ok = chunk < G.nchunks && pt < tp;
 #pragma unroll
@@ -421,8 +433,8 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         float xsum = 0.f;
 #pragma unroll
         for (u32 n = 0; n < (u32)NI; n++) {
-            const u32 chunk = (w >> 1) + n * (E / 2u);
-            if (chunk >= G.nchunks) continue;
+            const u32 chunk = (vw >> 1) + n * (E / 2u);
+            if (n < n0 || n >= n1 || chunk >= G.nchunks) continue;
             const u32 t = pt, g = t >> 3, hh = (t >> 2) & 1u, vA = t & 3u;
             u32 P[4][4];  // [piece][c]
 #pragma unroll
@@ -458,11 +470,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     }
     stamp(1);
     arrive(ctr + 1, l);
-    }  // early
-    wait_count(ctr + 1, E);  // the B image is complete
+    }  // image builders
+    wait_count(ctr + 1, a.himg ? W : E);  // the B image is complete
     stamp(2);
 #pragma unroll
-    for (u32 i = 0; i < E; i++) X += red[32 + i];
+    for (u32 i = 0; i < W; i++) X += red[32 + i];
     sb = (int)__builtin_bit_cast(u32, red[48]);
 
     // ---------------------------------------------------------------- 3. main loop: the steps of this wave
@@ -753,6 +765,7 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
     {
         const size_t need = (size_t)Ks * 2u * (pro == PRO_RMSNORM ? 2u : 1u), have = (size_t)(c.T / 128u) * c.S * 2048u * (size_t)bits;
         a.rawx = (need <= have && gq_env_int("GQ_PL_RAWX", 1)) ? 1u : 0u;
+        a.himg = (a.rawx && c.NI >= 2u && c.S == 1u && gq_env_int("GQ_PL_HIMG", 1)) ? 1u : 0u;
     }
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);
     a.eps = eps;

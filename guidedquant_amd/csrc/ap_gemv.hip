@@ -534,7 +534,9 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     // (w1w3, w2); everything else runs the exact kernels, whose results are bit-identical to the reference.
     // GQ_PL_MIN_MWEIGHTS overrides the threshold for every bit width, GQ_PL_MAX_BITS the widest plane-served width.
     const int env_min = gq_env_int("GQ_PL_MIN_MWEIGHTS", -1);
-    const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : (bits == 2 ? 20 : 32)) * 1000000ull;
+    // (without the RMSNorm prologue the 2- and 3-bit kernels need no block-wide activation pass: >= 16 M weights, wo)
+    const int def_min = bits == 2 ? (pro == PRO_RMSNORM ? 20 : 16) : (bits == 3 && pro != PRO_RMSNORM ? 16 : 32);
+    const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : def_min) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {
         int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s);

@@ -153,6 +153,173 @@ __device__ __forceinline__ void wait_count(const u32 *ctr, u32 target) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// ---- pieces shared by the two kernels below
+// one tile (16 rows x one chunk x all planes) from its ring slot: lane (row r, lane group kb) gets words 8 kb .. 8 kb + 7
+template <int BITS>
+__device__ __forceinline__ void load_tile(u32 (&Wd)[BITS][8], const unsigned char *slot, u32 offA0, u32 offA1) {
+#pragma unroll
+    for (int p = 0; p < BITS; p++) {
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA0);
+        const uint4 a1 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA1);
+        Wd[p][0] = a0.x, Wd[p][1] = a0.y, Wd[p][2] = a0.z, Wd[p][3] = a0.w;
+        Wd[p][4] = a1.x, Wd[p][5] = a1.y, Wd[p][6] = a1.z, Wd[p][7] = a1.w;
+    }
+}
+
+// the 8 x (2^BITS - 1) MFMAs of one step.  bbase = this lane's 16 bytes of the chunk's (b = 0, h = 0) image block,
+// bstep = distance of the next (b, h) block, bhalf = distance of the lane's second 16 bytes (k + 64)
+template <int BITS>
+__device__ __forceinline__ void mfma_chunk(v4f (&acc)[(1 << BITS) - 1], const u32 (&Wd)[BITS][8], const unsigned char *bbase, u32 bstep,
+                                           u32 bhalf, int sb) {
+    // B operand (activation pieces) double-buffered over the 8 (nibble bit b, word half h) MFMAs per subset
+    uint4 bn0 = *reinterpret_cast<const uint4 *>(bbase);
+    uint4 bn1 = *reinterpret_cast<const uint4 *>(bbase + bhalf);
+#pragma unroll
+    for (int bh = 0; bh < 8; bh++) {
+        const int nb = bh >> 1, hh = bh & 1;
+        const uint4 b0 = bn0, b1 = bn1;
+        if (bh < 7) {
+            bn0 = *reinterpret_cast<const uint4 *>(bbase + (u32)(bh + 1) * bstep);
+            bn1 = *reinterpret_cast<const uint4 *>(bbase + (u32)(bh + 1) * bstep + bhalf);
+        }
+        // keep the loads of the next MFMA group ahead of this one (the scheduler otherwise sinks them behind the
+        // MFMAs into a single B buffer and exposes the LDS latency 8 times per step)
+        __builtin_amdgcn_sched_barrier(0);
+        v8i Bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        // FP4 A operands of the 2^BITS - 1 plane subsets, built on the fly: the mask commutes with AND, so a subset's
+        // operand is the AND of its planes' masked words; a depth-first walk over the subset lattice keeps only one
+        // partial product per level alive (no register-resident AND words: 4-bit would need 120 of them).
+        // Plane p holds code bit BITS-1-p; subset index cm = OR of the code bits.
+        v4i Mp[BITS];
+#pragma unroll
+        for (int p = 0; p < BITS; p++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Mp[p][v] = (int)extract4(Wd[p][4 * hh + v], nb);
+        const int sa = scale_byte4(nb);
+#pragma unroll
+        for (int p0 = 0; p0 < BITS; p0++) {
+            const v4i A1 = Mp[p0];
+            const int c1 = 1 << (BITS - 1 - p0);
+            mfma_f4_bf8(acc[c1 - 1], A1, Bv, sa, sb);
+#pragma unroll
+            for (int p1 = p0 + 1; p1 < BITS; p1++) {
+                const v4i A2 = A1 & Mp[p1];
+                const int c2 = c1 | (1 << (BITS - 1 - p1));
+                mfma_f4_bf8(acc[c2 - 1], A2, Bv, sa, sb);
+#pragma unroll
+                for (int p2 = p1 + 1; p2 < BITS; p2++) {
+                    const v4i A3 = A2 & Mp[p2];
+                    const int c3 = c2 | (1 << (BITS - 1 - p2));
+                    mfma_f4_bf8(acc[c3 - 1], A3, Bv, sa, sb);
+#pragma unroll
+                    for (int p3 = p2 + 1; p3 < BITS; p3++) {
+                        const v4i A4 = A3 & Mp[p3];
+                        const int c4 = c3 | (1 << (BITS - 1 - p3));
+                        mfma_f4_bf8(acc[c4 - 1], A4, Bv, sa, sb);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
+// (pitem[subset][row]: lane (col 0, kb) owns rows 4kb..4kb+3) and clear the accumulators
+template <int NP1>
+__device__ __forceinline__ void park_item(v4f (&acc)[NP1], float *pitem, u32 col, u32 kb) {
+#pragma unroll
+    for (int cm = 0; cm < NP1; cm++) {
+        v4f v = acc[cm];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            float f = v[q4];
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
+            v[q4] = f;
+        }
+        if (col == 0u) *reinterpret_cast<v4f *>(pitem + (size_t)cm * 16u + 4u * kb) = v;
+        acc[cm] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// coefficients x plane sums.  lane = (output row, Moebius index c): term c = coef[c] * (c == 0 ? sum(x) : T[c]); the NP
+// terms of a row sit in NP adjacent lanes and are added by a fixed DPP tree (deterministic order)
+template <int BITS>
+__device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lutl, const float *part, float X, u32 rg0, u32 m, u32 tid,
+                                               u32 T) {
+    constexpr int NP = 1 << BITS, NP1 = NP - 1;
+    const u32 CS = 1u << a.log2CS;
+    for (u32 e = tid; e < a.RGB * 16u * (u32)NP; e += T) {
+        const u32 i = e / (u32)NP, c = e % (u32)NP;
+        const u32 rgl = i >> 4, rr = i & 15u;
+        const u32 row = (rg0 + rgl) * 16u + rr;
+        float f[NP];
+#pragma unroll
+        for (int cc = 0; cc < NP / 2; cc++) {
+            const u32 lw = lutl[(size_t)i * (NP / 2) + cc];
+            f[2 * cc] = h2f((uint16_t)(lw & 0xFFFF));
+            f[2 * cc + 1] = h2f((uint16_t)(lw >> 16));
+        }
+        moebius<BITS>(f);
+        float coef = f[0];
+#pragma unroll
+        for (int cc = 1; cc < NP; cc++) coef = c == (u32)cc ? f[cc] : coef;
+        float term = X;
+        if (c != 0u) {
+            // the K-split partial sums, added in item order; all loads of a batch are in flight together (a plain loop
+            // pays the LDS latency once per partial: 2000 cycles for 16 of them)
+            term = 0.f;
+            const float *pp = part + (((size_t)(rgl << a.log2CS)) * NP1 + (c - 1u)) * 16u + rr;
+            constexpr u32 PS = NP1 * 16u;
+            if (CS >= 8u) {
+                for (u32 cs = 0; cs < CS; cs += 8u) {
+                    float v[8];
+#pragma unroll
+                    for (u32 k = 0; k < 8; k++) v[k] = pp[(size_t)(cs + k) * PS];
+#pragma unroll
+                    for (u32 k = 0; k < 8; k++) term += v[k];
+                }
+            } else {
+                float v[4];
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) v[k] = k < CS ? pp[(size_t)k * PS] : 0.f;
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) term += v[k];
+            }
+        }
+        float y = coef * term;
+        y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0xB1, 0xF, 0xF, false));
+        y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x4E, 0xF, 0xF, false));
+        if constexpr (NP >= 8) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x141, 0xF, 0xF, false));
+        if constexpr (NP >= 16) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x140, 0xF, 0xF, false));
+        _Float16 yh = (_Float16)y;
+        if (a.pairs) {
+            // the partner row of the pair sits NP lanes away: F.silu(gate) * up on fp16 values -- inference/model.py:266
+            const _Float16 yo = __builtin_bit_cast(_Float16, (uint16_t)__shfl_xor((int)__builtin_bit_cast(uint16_t, yh), NP));
+            if (c == 0u && !(rr & 1u) && row + 1u < a.N) {
+                const float gv = (float)yh;
+                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * yo;
+                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
+            }
+        } else if (c == 0u && row < a.N) {
+            if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[(size_t)m * a.N + row]) + yh;
+            a.out[(size_t)m * a.N + row] = __builtin_bit_cast(uint16_t, yh);
+        }
+    }
+}
+
+// F.silu(gate) * up on two packed fp16 pairs -- inference/model.py:266
+__device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
+    _Float16 hh[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float gv = h2f((uint16_t)(gw >> (16 * k)));
+        hh[k] = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, (uint16_t)(uw >> (16 * k)));
+    }
+    return (u32)__builtin_bit_cast(uint16_t, hh[0]) | ((u32)__builtin_bit_cast(uint16_t, hh[1]) << 16);
+}
+
+
 // Work unit ("step") = 16 rows x one 1024-weight chunk x all planes = one A tile of BITS * 2 KiB; an item = cpi
 // consecutive chunks of a row group, accumulated in registers by one wave.  Every wave streams its own tiles
 // (direct-to-LDS loads into a private ring of S slots, own vmcnt) and multiplies them; what differs is the start:
@@ -323,15 +490,6 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     {
         float ss = 0.f, mx = 0.f;
         u32 mxi = 0;
-        auto silu_mul = [](u32 gw, u32 uw) {  // F.silu(gate) * up on fp16 tensors -- inference/model.py:266
-            _Float16 hh[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const float gv = h2f((uint16_t)(gw >> (16 * k)));
-                hh[k] = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, (uint16_t)(uw >> (16 * k)));
-            }
-            return (u32)__builtin_bit_cast(uint16_t, hh[0]) | ((u32)__builtin_bit_cast(uint16_t, hh[1]) << 16);
-        };
         auto stat = [&](u32 xw, u32 aw) {  // one packed pair of activations (and of norm weights)
             if constexpr (PRO == PRO_RMSNORM) {
                 const float p = h2f(xw & 0xFFFF), q = h2f(xw >> 16);
@@ -351,7 +509,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
                 if constexpr (PRO != PRO_NONE) tie128(rawa[n]);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if constexpr (PRO == PRO_SILUMUL) rawv[n][k] = silu_mul(rawv[n][k], rawa[n][k]);
+                    if constexpr (PRO == PRO_SILUMUL) rawv[n][k] = silu_mul2(rawv[n][k], rawa[n][k]);
                     stat(rawv[n][k], PRO == PRO_RMSNORM ? rawa[n][k] : 0u);
                 }
                 const u32 idx = tid + n * (E * 64u);
@@ -373,7 +531,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
                 for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
                     xr[n][c] |= xh[n][c] << 16;
                     if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
-                    if constexpr (PRO == PRO_SILUMUL) xr[n][c] = silu_mul(xr[n][c], ar[n][c]);
+                    if constexpr (PRO == PRO_SILUMUL) xr[n][c] = silu_mul2(xr[n][c], ar[n][c]);
                     stat(xr[n][c], PRO == PRO_RMSNORM ? ar[n][c] : 0u);
                 }
             }
@@ -493,16 +651,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         const u32 after = iq_n - 1u - q + (q < lut_from ? lut_after : 0u);  // (pseudo) steps requested behind this one
         wait_vm_steps<LPS>(after);
         u32 Wd[BITS][8];
-        {
-            const unsigned char *slot = ring + cq_slot * SLOT;
-#pragma unroll
-            for (int p = 0; p < BITS; p++) {
-                const uint4 a0 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA0);
-                const uint4 a1 = *reinterpret_cast<const uint4 *>(slot + p * 2048 + offA1);
-                Wd[p][0] = a0.x, Wd[p][1] = a0.y, Wd[p][2] = a0.z, Wd[p][3] = a0.w;
-                Wd[p][4] = a1.x, Wd[p][5] = a1.y, Wd[p][6] = a1.z, Wd[p][7] = a1.w;
-            }
-        }
+        load_tile<BITS>(Wd, ring + cq_slot * SLOT, offA0, offA1);
         if (iq_n < my_steps) {
             // refill this slot with the step S ahead: the ds_reads above must have returned first
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -510,77 +659,14 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
         }
         if (++cq_slot == S) cq_slot = 0;
         if (chunk < G.nchunks && !(a.xflags & 1u)) {
-            // B operand (activation pieces) double-buffered over the 8 (nibble bit b, word half h) MFMAs per subset
             const unsigned char *bbase = bcol ? bimg + bimg4_off(chunk, 0u, 0u, col) + 16u * kb : zero32;
-            const u32 bstep = bcol ? 512u : 0u, bhalf = bcol ? 64u : 0u;  // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
-            uint4 bn0 = *reinterpret_cast<const uint4 *>(bbase);
-            uint4 bn1 = *reinterpret_cast<const uint4 *>(bbase + bhalf);
-#pragma unroll
-            for (int bh = 0; bh < 8; bh++) {
-                const int nb = bh >> 1, hh = bh & 1;
-                const uint4 b0 = bn0, b1 = bn1;
-                if (bh < 7) {
-                    bn0 = *reinterpret_cast<const uint4 *>(bbase + (u32)(bh + 1) * bstep);
-                    bn1 = *reinterpret_cast<const uint4 *>(bbase + (u32)(bh + 1) * bstep + bhalf);
-                }
-                // keep the loads of the next MFMA group ahead of this one (the scheduler otherwise sinks them behind the
-                // MFMAs into a single B buffer and exposes the LDS latency 8 times per step)
-                __builtin_amdgcn_sched_barrier(0);
-                v8i Bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-                // FP4 A operands of the 2^BITS - 1 plane subsets, built on the fly: the mask commutes with AND, so a subset's
-                // operand is the AND of its planes' masked words; a depth-first walk over the subset lattice keeps only one
-                // partial product per level alive (no register-resident AND words: 4-bit would need 120 of them).
-                // Plane p holds code bit BITS-1-p; subset index cm = OR of the code bits.
-                v4i Mp[BITS];
-#pragma unroll
-                for (int p = 0; p < BITS; p++)
-#pragma unroll
-                    for (int v = 0; v < 4; v++) Mp[p][v] = (int)extract4(Wd[p][4 * hh + v], nb);
-                const int sa = scale_byte4(nb);
-#pragma unroll
-                for (int p0 = 0; p0 < BITS; p0++) {
-                    const v4i A1 = Mp[p0];
-                    const int c1 = 1 << (BITS - 1 - p0);
-                    mfma_f4_bf8(acc[c1 - 1], A1, Bv, sa, sb);
-#pragma unroll
-                    for (int p1 = p0 + 1; p1 < BITS; p1++) {
-                        const v4i A2 = A1 & Mp[p1];
-                        const int c2 = c1 | (1 << (BITS - 1 - p1));
-                        mfma_f4_bf8(acc[c2 - 1], A2, Bv, sa, sb);
-#pragma unroll
-                        for (int p2 = p1 + 1; p2 < BITS; p2++) {
-                            const v4i A3 = A2 & Mp[p2];
-                            const int c3 = c2 | (1 << (BITS - 1 - p2));
-                            mfma_f4_bf8(acc[c3 - 1], A3, Bv, sa, sb);
-#pragma unroll
-                            for (int p3 = p2 + 1; p3 < BITS; p3++) {
-                                const v4i A4 = A3 & Mp[p3];
-                                const int c4 = c3 | (1 << (BITS - 1 - p3));
-                                mfma_f4_bf8(acc[c4 - 1], A4, Bv, sa, sb);
-                            }
-                        }
-                    }
-                }
-            }
+            // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
+            mfma_chunk<BITS>(acc, Wd, bbase, bcol ? 512u : 0u, bcol ? 64u : 0u, sb);
         } else if (a.xflags & 1u) {
             acc[0][0] += __builtin_bit_cast(float, Wd[0][0] ^ Wd[BITS - 1][7]);
         }
         if (++cq_c == cpi) {
-            // item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
-#pragma unroll
-            for (int cm = 0; cm < NP1; cm++) {
-                v4f v = acc[cm];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    float f = v[q4];
-                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
-                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
-                    v[q4] = f;
-                }
-                // part[item][subset][row]: lane (col 0, kb) owns rows 4kb..4kb+3
-                if (col == 0u) *reinterpret_cast<v4f *>(part + ((size_t)cq_item * NP1 + cm) * 16u + 4u * kb) = v;
-                acc[cm] = (v4f){0.f, 0.f, 0.f, 0.f};
-            }
+            park_item<NP1>(acc, part + (size_t)cq_item * NP1 * 16u, col, kb);  // part[item][subset][row]
             cq_c = 0;
             cq_item = item_after(cq_item);
         }
@@ -591,48 +677,228 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     stamp(4);
 
     // ---------------------------------------------------------------- 4. epilogue: coefficients x plane sums
-    // lane = (output row, Moebius index c): term c = coef[c] * (c == 0 ? sum(x) : T[c]); the NP terms of a row sit in
-    // NP adjacent lanes and are added by a fixed DPP tree (deterministic order)
-    for (u32 e = tid; e < a.RGB * 16u * (u32)NP; e += T) {
-        const u32 i = e / (u32)NP, c = e % (u32)NP;
-        const u32 rgl = i >> 4, rr = i & 15u;
-        const u32 row = (rg0 + rgl) * 16u + rr;
-        float f[NP];
+    plane_epilogue<BITS>(a, lutl, part, X, rg0, m, tid, T);
+    stamp(5);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// "Local image" variant for the prologues without a whole-vector statistic (plain, SiLU(gate) * up): every wave loads the
+// activations of ITS chunks (contiguous 2 KiB each), scales them by a power of two of its own (the E8M0 scale of its
+// MFMAs undoes it, so waves with different scales add up in fp32 like any other partial sums), splits them and scatters
+// the pieces into a private image.  No wave waits for another one before the K-split sums are added: the launch ->
+// activation -> statistics -> image -> MFMA chain of the kernel above, with its two block-wide barriers, is what bounds
+// the small matrices (N = 4096: 57 KiB of planes per CU), not the plane stream.
+//   items: wave w takes items w, w + W, ...; CS divides W, so all of them cover the same chunks cs * cpi .. + cpi - 1,
+//   cs = w mod CS, of different row groups.  Waves with the same cs build the same image redundantly (RGB > 1).
+//   LDS: [A rings: W x S slots][LUT rows][images: W x NC x 4096][red: 64 floats][part]
+template <int BITS, int PRO, int NC>
+__global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(PlaneArgs a) {
+    static_assert(PRO != PRO_RMSNORM, "the RMSNorm scale needs the whole vector");
+    constexpr int NP = 1 << BITS, NP1 = NP - 1;
+    constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u;
+    constexpr u32 LPS = 2u * BITS, SLOT = 2048u * BITS, OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    Geom G;
+    G.init(a.K);
+    const u32 tid = threadIdx.x;
+    const u32 w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 l = tid & 63u;
+    const u32 CS = 1u << a.log2CS, cpi = a.cpi, S = a.S;
+    const u32 nIt = a.RGB * CS;
+    unsigned char *ring = smem + (size_t)w * S * SLOT;
+    const u32 lut_bytes = (a.RGB * 16u * (u32)NP * 2u + LPS * 1024u - 1u) / (LPS * 1024u) * (LPS * 1024u);
+    unsigned char *lutb = smem + (size_t)W * S * SLOT;
+    const u32 *lutl = reinterpret_cast<const u32 *>(lutb);
+    unsigned char *img = lutb + lut_bytes + (size_t)w * NC * 4096u;
+    float *red = reinterpret_cast<float *>(lutb + lut_bytes + (size_t)W * NC * 4096u);
+    float *part = red + 64;
+    const u32 rg0 = blockIdx.x * a.RGB;
+    const u32 m = blockIdx.y;
+    const u32 items_w = nIt > w ? (nIt - w + W - 1u) / W : 0u;
+    const u32 my_steps = items_w * cpi;
+    const u32 chunk0 = (w & (CS - 1u)) * cpi;
+    auto stamp = [&](int i) {
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
+    };
+    stamp(0);
+
+    // ---- 0. this wave's activations (16-byte units u = l, l + 64 of each chunk), then all of its tiles
+    u32x4 xv[NC][2], gv[NC][2];
+    {
+        const u32x4 rsx = make_rsrc(a.x + (size_t)m * a.x_ld, (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
 #pragma unroll
-        for (int cc = 0; cc < NP / 2; cc++) {
-            const u32 lw = lutl[(size_t)i * (NP / 2) + cc];
-            f[2 * cc] = h2f((uint16_t)(lw & 0xFFFF));
-            f[2 * cc + 1] = h2f((uint16_t)(lw >> 16));
-        }
-        moebius<BITS>(f);
-        float coef = f[0];
+        for (u32 n = 0; n < (u32)NC; n++) {
+            const u32 chunk = chunk0 + n;
+            const u32 tp = G.tpw(chunk);
 #pragma unroll
-        for (int cc = 1; cc < NP; cc++) coef = c == (u32)cc ? f[cc] : coef;
-        float term = X;
-        if (c != 0u) {
-            term = 0.f;
-            const float *pp = part + (((size_t)(rgl << a.log2CS)) * NP1 + (c - 1u)) * 16u + rr;
-            for (u32 cs = 0; cs < CS; cs++) term += pp[(size_t)cs * NP1 * 16u];
-        }
-        float y = coef * term;
-        y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0xB1, 0xF, 0xF, false));
-        y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x4E, 0xF, 0xF, false));
-        if constexpr (NP >= 8) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x141, 0xF, 0xF, false));
-        if constexpr (NP >= 16) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x140, 0xF, 0xF, false));
-        _Float16 yh = (_Float16)y;
-        if (a.pairs) {
-            // the partner row of the pair sits NP lanes away: F.silu(gate) * up on fp16 values -- inference/model.py:266
-            const _Float16 yo = __builtin_bit_cast(_Float16, (uint16_t)__shfl_xor((int)__builtin_bit_cast(uint16_t, yh), NP));
-            if (c == 0u && !(rr & 1u) && row + 1u < a.N) {
-                const float gv = (float)yh;
-                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * yo;
-                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
+            for (u32 k = 0; k < 2; k++) {
+                const u32 u = l + 64u * k;
+                const bool ok = items_w && n < cpi && chunk < G.nchunks && u < 4u * tp;
+                const u32 voff = ok ? 2048u * chunk + 16u * u : OOB;
+                xv[n][k] = bload128(rsx, voff, 0u);
+                if constexpr (PRO == PRO_SILUMUL) gv[n][k] = bload128(rsx, voff, 2u * G.K);
             }
-        } else if (c == 0u && row < a.N) {
-            if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[(size_t)m * a.N + row]) + yh;
-            a.out[(size_t)m * a.N + row] = __builtin_bit_cast(uint16_t, yh);
         }
     }
+    const u32 plane_bytes = a.N * a.wpr_ld * 4u;
+    const u32x4 rq = make_rsrc(a.qw, plane_bytes * (u32)BITS);
+    const u32 ring_lds = (u32)(uintptr_t)ring;
+    u32 lane_off[2];
+    {
+        u32 lr, lseg;
+        atile_src(0u, l, lr, lseg);
+        lane_off[0] = (lr * a.wpr_ld + 4u * lseg) * 4u;
+        atile_src(1u, l, lr, lseg);
+        lane_off[1] = (lr * a.wpr_ld + 4u * lseg) * 4u;
+    }
+    u32 iq_item = w, iq_c = 0, iq_slot = 0, iq_n = 0;  // next step to request
+    auto issue = [&]() {
+        const u32 chunk = chunk0 + iq_c;
+        const u32 rgi = rg0 + (iq_item >> a.log2CS);
+        const u32 slot_lds = ring_lds + iq_slot * SLOT;
+        const u32 tile_off = (rgi * 16u * a.wpr_ld + a.word0 + 32u * (chunk < G.nchunks ? chunk : 0u)) * 4u;
+#pragma unroll
+        for (u32 p = 0; p < (u32)BITS; p++)
+#pragma unroll
+            for (u32 h = 0; h < 2; h++) dma16s(rq, slot_lds + (p * 2u + h) * 1024u, lane_off[h], tile_off + p * plane_bytes);
+        if (++iq_c == cpi) {
+            iq_c = 0;
+            iq_item += W;
+        }
+        if (++iq_slot == S) iq_slot = 0;
+        iq_n++;
+    };
+    while (iq_n < my_steps && iq_n < S) issue();
+    // LUT rows of the block: pseudo steps of exactly LPS loads in the queue of the last wave (see the kernel above)
+    const u32 nlut = w == W - 1u ? lut_bytes / (LPS * 1024u) : 0u;
+    if (nlut) {
+        const u32x4 rl = make_rsrc(a.lut, a.N * (u32)NP * 2u);
+        const u32 want = a.RGB * 16u * (u32)NP * 2u;
+        for (u32 o = 0; o < lut_bytes; o += 1024u)
+            dma16(rl, (u32)(uintptr_t)lutb + o, o + 16u * l < want ? rg0 * 16u * (u32)NP * 2u + o + 16u * l : OOB);
+    }
+    const u32 lut_from = iq_n, lut_after = nlut;
+    stamp(6);
+
+    // ---- 1. scale of this wave, pieces, image
+    wait_vm_steps<LPS>(iq_n + nlut);  // the activation loads were issued first (host: S + nlut <= 4)
+    stamp(7);
+    int sb = 127;
+    if (items_w) {
+        u32 mxi = 0;
+#pragma unroll
+        for (u32 n = 0; n < (u32)NC; n++)
+#pragma unroll
+            for (u32 k = 0; k < 2; k++) {
+                tie128(xv[n][k]);
+                if constexpr (PRO == PRO_SILUMUL) tie128(gv[n][k]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if constexpr (PRO == PRO_SILUMUL) xv[n][k][q] = silu_mul2(xv[n][k][q], gv[n][k][q]);
+                    const u32 ab = xv[n][k][q] & 0x7FFF7FFFu;  // |fp16| bit patterns order like unsigned integers
+                    mxi = max(mxi, max(ab & 0xFFFFu, ab >> 16));
+                }
+            }
+        const float mx = wave_reduce<true>(h2f((uint16_t)mxi));
+        const float xmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 63));
+        const int ksh = piece_shift(xmax);
+        sb = 127 - ksh;
+        const h2v kk = u2h2((u32)pow2_f16(ksh) * 0x10001u), one2 = u2h2(0x3C003C00u);
+        float xsum = 0.f;
+#pragma unroll
+        for (u32 n = 0; n < (u32)NC; n++) {
+            const u32 chunk = chunk0 + n;
+            if (n >= cpi || chunk >= G.nchunks) continue;
+            const u32 tp = G.tpw(chunk);
+#pragma unroll
+            for (u32 k = 0; k < 2; k++) {
+                // unit u = the 8 activations j = 0..7 of (byte c, virtual lane t): word q holds j = 2q (low half), 2q + 1
+                const u32 u = l + 64u * k;
+                const u32 c = tp == 32u ? u >> 5 : u / tp, t = tp == 32u ? u & 31u : u % tp;
+                u32 P[4][4];  // [piece][q]
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 xw = xv[n][k][q];
+                    xsum = __builtin_amdgcn_fdot2(u2h2(xw), one2, xsum, false);
+                    h2v rem = u2h2(xw) * kk;
+#pragma unroll
+                    for (u32 p = 0; p < 4; p++) {
+                        P[p][q] = h22u(rem) & 0xFF00FF00u;
+                        if (p < 3) rem = rem - u2h2(P[p][q]);
+                    }
+                }
+                if (u >= 4u * tp) continue;
+                // weight j has plane bit s = 7 - j: nibble bit b = s & 3, nibble i = 2 (3 - c) + (s >> 2), k = 32 g + 8 v + i.
+                // For b: the bytes at i = 2(3-c), 2(3-c)+1 are j = 7 - b (byte 1 or 3 of word (7-b)/2) and j = 3 - b.
+                unsigned char *dst = img + n * 4096u + (((t >> 2) & 1u) << 9) + 32u * (t >> 3) + 8u * (t & 3u) + 2u * (3u - c);
+#pragma unroll
+                for (u32 p = 0; p < 4; p++) {
+                    // b = 0: j = 7, 3 (byte 3 of words 3, 1); b = 1: j = 6, 2 (byte 1 of words 3, 1)
+                    const u32 v01 = __builtin_amdgcn_perm(P[p][1], P[p][3], 0x05010703u);  // lo half: b = 0, hi half: b = 1
+                    // b = 2: j = 5, 1 (byte 3 of words 2, 0); b = 3: j = 4, 0 (byte 1 of words 2, 0)
+                    const u32 v23 = __builtin_amdgcn_perm(P[p][0], P[p][2], 0x05010703u);
+                    unsigned char *d = dst + p * 128u;  // (b, h) blocks are 4 pieces * 128 B = 512 B apart, b major: b * 1024 + h * 512
+                    *reinterpret_cast<uint16_t *>(d) = (uint16_t)v01;
+                    *reinterpret_cast<uint16_t *>(d + 1024u) = (uint16_t)(v01 >> 16);
+                    *reinterpret_cast<uint16_t *>(d + 2048u) = (uint16_t)v23;
+                    *reinterpret_cast<uint16_t *>(d + 3072u) = (uint16_t)(v23 >> 16);
+                }
+            }
+        }
+        // a short tail chunk leaves the words of its missing virtual lanes untouched: clear them (k positions with t >= tp)
+#pragma unroll
+        for (u32 n = 0; n < (u32)NC; n++) {
+            const u32 chunk = chunk0 + n;
+            if (n >= cpi || chunk >= G.nchunks || G.tpw(chunk) == 32u) continue;
+            const u32 tp = G.tpw(chunk);
+            for (u32 o = l; o < 1024u; o += 64u) {  // dword o of the chunk image: block o / 32, k = 4 (o % 32) -> t = 8 (k/32) + 4 h + (k%32)/8
+                const u32 blk = o >> 5, k4 = (o & 31u) * 4u, hh = (blk >> 2) & 1u;
+                const u32 t = 8u * (k4 >> 5) + 4u * hh + ((k4 & 31u) >> 3);
+                if (t >= tp) reinterpret_cast<u32 *>(img + n * 4096u)[o] = 0u;
+            }
+        }
+        xsum = wave_reduce<false>(xsum);
+        if (l == 63) red[32 + w] = w < CS ? xsum : 0.f;  // sum(x): every chunk range counted once
+    } else if (l == 63) {
+        red[32 + w] = 0.f;
+    }
+    stamp(1);
+    asm volatile("" ::: "memory");  // the image of this wave is read by this wave only: program order suffices
+
+    // ---- 2. the steps of this wave
+    const u32 r = l & 15u, kb = l >> 4, col = l & 15u;
+    const u32 offA0 = atile_unit(r, 2u * kb) * 16u, offA1 = atile_unit(r, 2u * kb + 1u) * 16u;
+    const unsigned char *blane = img + ((col & 3u) << 7) + 16u * kb;  // columns 4..15 repeat 0..3 (their sums are never read)
+    v4f acc[NP1];
+#pragma unroll
+    for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    u32 cq_item = w, cq_c = 0, cq_slot = 0;
+    for (u32 q = 0; q < my_steps; q++) {
+        const u32 chunk = chunk0 + cq_c;
+        const u32 after = iq_n - 1u - q + (q < lut_from ? lut_after : 0u);
+        wait_vm_steps<LPS>(after);
+        u32 Wd[BITS][8];
+        load_tile<BITS>(Wd, ring + cq_slot * SLOT, offA0, offA1);
+        if (iq_n < my_steps) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue();
+        }
+        if (++cq_slot == S) cq_slot = 0;
+        if (chunk < G.nchunks) mfma_chunk<BITS>(acc, Wd, blane + cq_c * 4096u, 512u, 64u, sb);
+        if (++cq_c == cpi) {
+            park_item<NP1>(acc, part + (size_t)cq_item * NP1 * 16u, col, kb);
+            cq_c = 0;
+            cq_item += W;
+        }
+    }
+    wait_vm<0>();
+    stamp(3);
+    __syncthreads();
+    stamp(4);
+    float X = 0.f;
+#pragma unroll
+    for (u32 i = 0; i < W; i++) X += red[32 + i];
+    plane_epilogue<BITS>(a, lutl, part, X, rg0, m, tid, T);
     stamp(5);
 }
 
@@ -698,6 +964,67 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     return true;
 }
 
+// the local-image kernel: same grid / K split, a private image of cpi chunks per wave, every tile requested up front
+bool pick_local_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
+    // 4-bit (8 waves, 15 subsets): the shared image with the late-wave helpers measured faster
+    if (K % 256u || bits > gq_env_int("GQ_PL_LOCAL_MAXBITS", 3)) return false;
+    const u32 nchunks = K / 1024u + ((K % 1024u) ? 1u : 0u);
+    const u32 RGt = (N + 15u) / 16u, ncu = (u32)cus(), W = bits == 2 ? 16u : 8u;
+    c.T = 64u * W;
+    c.RGB = (RGt + ncu - 1u) / ncu;
+    if (c.RGB < 1) c.RGB = 1;
+    // waves of different row groups would build the same image: measured slower than the shared image from 2 row groups on
+    if (c.RGB > (u32)gq_env_int("GQ_PL_LOCAL_MAXRGB", 1)) return false;
+    c.grid = (RGt + c.RGB - 1u) / c.RGB;
+    u32 lcs = 0;
+    while ((c.RGB << lcs) < W && (1u << lcs) < nchunks) lcs++;  // up to one item per wave: nothing is shared between waves
+    c.log2CS = lcs;
+    c.cpi = (nchunks + (1u << lcs) - 1u) >> lcs;
+    if (c.cpi > 4u) return false;
+    c.NI = c.cpi <= 1u ? 1u : (c.cpi == 2u ? 2u : 4u);  // NC
+    const u32 nIt = c.RGB << lcs, steps_w = ((nIt + W - 1u) / W) * c.cpi;
+    const u32 np1 = (1u << bits) - 1u;
+    const size_t lps_bytes = 2048u * (size_t)bits, slot = lps_bytes, lds = 160u * 1024u;
+    const size_t lutb = ((size_t)c.RGB * 16u * (np1 + 1u) * 2u + lps_bytes - 1u) / lps_bytes * lps_bytes;
+    const u32 nlut = (u32)(lutb / lps_bytes);
+    const size_t fixed = lutb + (size_t)W * c.NI * 4096u + 64u * 4u + (size_t)nIt * np1 * 16u * 4u;
+    if (nlut > 2u || fixed + W * slot > lds) return false;
+    u32 S = (u32)((lds - fixed) / (W * slot));
+    if (S > 4u - nlut) S = 4u - nlut;  // the activation loads are waited for with everything else in flight (vmcnt immediates)
+    if (S > steps_w) S = steps_w;
+    c.S = S;
+    c.E = 0;
+    c.smem = fixed + (size_t)W * S * slot;
+    return true;
+}
+
+template <int BITS, int PRO, int NC>
+int launch_local_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = ap_plane_local_kernel<BITS, PRO, NC>;
+    if (!attr_set) {
+        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(160u * 1024u)));
+        attr_set = true;
+    }
+    dim3 grid(c.grid, M), block(c.T);
+    hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+template <int BITS>
+int launch_local(const PlaneArgs &a, const PlaneCfg &c, u32 M, int pro, hipStream_t s) {
+    if (pro == PRO_SILUMUL) {
+        if (c.NI == 1) return launch_local_inst<BITS, PRO_SILUMUL, 1>(a, c, M, s);
+        if (c.NI == 2) return launch_local_inst<BITS, PRO_SILUMUL, 2>(a, c, M, s);
+        return launch_local_inst<BITS, PRO_SILUMUL, 4>(a, c, M, s);
+    }
+    if (c.NI == 1) return launch_local_inst<BITS, PRO_NONE, 1>(a, c, M, s);
+    if (c.NI == 2) return launch_local_inst<BITS, PRO_NONE, 2>(a, c, M, s);
+    return launch_local_inst<BITS, PRO_NONE, 4>(a, c, M, s);
+}
+
 template <int BITS, int PRO, int NI>
 int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     static bool attr_set = false;
@@ -744,7 +1071,8 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
                        uint32_t k0, uint32_t Ks, int bits, const void *normw, float eps, const void *resid, int pro, int pairs,
                        hipStream_t stream) {
     PlaneCfg c;
-    if (!pick_plane_cfg(N, Ks, bits, c)) return GQ_ENOTSUP;
+    const bool local = pro != PRO_RMSNORM && gq_env_int("GQ_PL_LOCAL", 1) && pick_local_cfg(N, Ks, bits, c);
+    if (!local && !pick_plane_cfg(N, Ks, bits, c)) return GQ_ENOTSUP;
     PlaneArgs a{};
     a.qw = qweight;
     a.lut = (const uint16_t *)lut;
@@ -770,6 +1098,14 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);
     a.eps = eps;
     a.dbg = g_dbg;
+    if (local) {
+        a.rawx = a.himg = 0u;
+        switch (bits) {
+            case 2: return launch_local<2>(a, c, M, pro, stream);
+            case 3: return launch_local<3>(a, c, M, pro, stream);
+            default: return launch_local<4>(a, c, M, pro, stream);
+        }
+    }
     switch (bits) {
         case 2: return launch_plane<2>(a, c, M, pro, stream);
         case 3: return launch_plane<3>(a, c, M, pro, stream);

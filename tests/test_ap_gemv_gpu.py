@@ -21,19 +21,22 @@ def _exact_mode():
     _lib.check(_lib.lib().gq_set_ap_mode(1), "gq_set_ap_mode")
     yield
     _lib.lib().gq_set_ap_mode(-1)
-    for k in ("GQ_PL_MIN_MWEIGHTS", "GQ_PL_MAX_BITS"):
+    for k in ("GQ_PL_MIN_MWEIGHTS", "GQ_PL_MAX_BITS", "GQ_PL_LOCAL"):
         os.environ.pop(k, None)
     _lib.lib().gq_reset_env_cache()
 
 
-def _fast(force_plane=True):
+def _fast(force_plane=True, local=1):
     """Fast mode.  By default the dispatcher sends only the shapes on which the plane-MFMA kernel wins to it
-    (2-bit, >= 32 M weights); the parity tests of that kernel lift the thresholds so that every shape runs on it."""
+    (DESIGN.md section 7); the parity tests of that kernel lift the thresholds so that every shape runs on it.
+    local = 0 keeps the shapes that would run the local-image variant (<= 16 rows per CU, 2/3-bit, no RMSNorm) on the
+    shared-image kernel, so both are checked on the same inputs."""
     from guidedquant_amd import _lib
     _lib.check(_lib.lib().gq_set_ap_mode(0), "gq_set_ap_mode")
     if force_plane:
         os.environ["GQ_PL_MIN_MWEIGHTS"] = "0"
         os.environ["GQ_PL_MAX_BITS"] = "4"
+        os.environ["GQ_PL_LOCAL"] = str(local)
         _lib.lib().gq_reset_env_cache()
 
 
@@ -247,10 +250,11 @@ def test_aplinear_module_and_custom_op(oracle):
 
 # ----------------------------------------------------------------------------- fast (plane-MFMA) mode
 @pytest.mark.parametrize("path", [p for p in golden_files("ap_b") if int(np.load(p)["bits"]) in (2, 3, 4)])
-def test_fast_mode_goldens(oracle, path):
+@pytest.mark.parametrize("local", [1, 0])
+def test_fast_mode_goldens(oracle, path, local):
     g = np.load(path)
     bits = int(g["bits"])
-    _fast()
+    _fast(local=local)
     got = _run_gemv(g["x"], g["qweight"], g["lut"], bits)[0]
     _check_fast(got, g["x"], g["qweight"], g["lut"], bits, oracle)
 
@@ -258,13 +262,14 @@ def test_fast_mode_goldens(oracle, path):
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("N,K", [(64, 4096), (36, 1024), (20, 1280), (12, 11008), (8, 14336), (16, 2048), (4, 8192),
                                  (200, 256), (17, 5120)])
-def test_fast_mode_random(oracle, bits, N, K):
+@pytest.mark.parametrize("local", [1, 0])
+def test_fast_mode_random(oracle, bits, N, K, local):
     rng = np.random.default_rng(bits * 7919 + N * 131 + K + 1)
     codes = rng.integers(0, 1 << bits, (N, K), dtype=np.uint8)
     q = oracle.ap_pack(codes, bits)
     lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
     x = (rng.normal(0, 1, K) * np.where(rng.random(K) < 0.02, 40.0, 1.0)).astype(np.float16)
-    _fast()
+    _fast(local=local)
     got = _run_gemv(x, q, lut, bits)[0]
     _check_fast(got, x, q, lut, bits, oracle)
 
@@ -272,27 +277,29 @@ def test_fast_mode_random(oracle, bits, N, K):
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (3072, 2048),
                                  (10240, 8192), (8192, 28672)])
-def test_fast_mode_full_size_sampled_rows(oracle, bits, N, K):
+@pytest.mark.parametrize("local", [1, 0])
+def test_fast_mode_full_size_sampled_rows(oracle, bits, N, K, local):
     from guidedquant_amd import pack
     rng = np.random.default_rng(bits + N + K)
     q = pack.random_planes(N, K, bits, seed=bits * 31 + N)
     lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
     x = rng.normal(0, 1, K).astype(np.float16)
-    _fast()
+    _fast(local=local)
     got = _run_gemv(x, q, lut, bits)[0]
     assert np.isfinite(got.astype(np.float32)).all()
     rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(N - 40, N), rng.integers(0, N, 64)]))
     _check_fast(got, x, q, lut, bits, oracle, rows=rows)
 
 
-def test_fast_mode_tiny_and_huge_activations(oracle):
+@pytest.mark.parametrize("local", [1, 0])
+def test_fast_mode_tiny_and_huge_activations(oracle, local):
     """block scaling of the activation pieces: vectors of very small / very large / mixed magnitude stay accurate"""
     bits, N, K = 2, 48, 4096
     rng = np.random.default_rng(9)
     codes = rng.integers(0, 1 << bits, (N, K), dtype=np.uint8)
     q = oracle.ap_pack(codes, bits)
     lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
-    _fast()
+    _fast(local=local)
     for mag in (1e-4, 1.0, 3e2):
         x = (rng.normal(0, mag, K)).astype(np.float16)
         got = _run_gemv(x, q, lut, bits)[0]
@@ -310,7 +317,7 @@ def test_default_dispatch_is_hybrid(oracle):
     from guidedquant_amd import pack
     rng = np.random.default_rng(21)
     _fast(force_plane=False)
-    for N, K, plane in ((4096, 4096, False), (28672, 4096, True)):
+    for N, K, plane in ((2048, 4096, False), (4096, 4096, True), (28672, 4096, True)):
         q = pack.random_planes(N, K, 2, seed=N)
         lut = np.sort(rng.normal(0, 0.02, (N, 4)).astype(np.float16), axis=1)
         x = rng.normal(0, 1, K).astype(np.float16)
@@ -323,7 +330,8 @@ def test_default_dispatch_is_hybrid(oracle):
             assert np.array_equal(got[rows].view(np.uint16), want.view(np.uint16))
 
 
-@pytest.mark.parametrize("bits,N,K", [(2, 28672, 4096), (2, 4096, 14336), (3, 4096, 8192), (4, 2048, 4096), (2, 6144, 4096)])
+@pytest.mark.parametrize("bits,N,K", [(2, 28672, 4096), (2, 4096, 14336), (3, 4096, 8192), (4, 2048, 4096), (2, 6144, 4096), (2, 4096, 4096),
+                                       (3, 4096, 14336), (2, 4096, 4352)])
 def test_fast_mode_is_deterministic(bits, N, K):
     """size-independent property: the plane-MFMA kernel has no order-dependent reductions (fixed DPP trees, ordered LDS
     sums, no atomics on data) -- 100 launches on the same inputs give bit-identical outputs (also a race detector for

@@ -105,7 +105,7 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
                 const u32 nw[4] = {n4.x, n4.y, n4.z, n4.w};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    uint16_t a = f2h(h2f(in[v][i] & 0xFFFF) * scale), b = f2h(h2f(in[v][i] >> 16) * scale);
+                    uint16_t a = f2h(gq_pin_f32(h2f(in[v][i] & 0xFFFF) * scale)), b = f2h(gq_pin_f32(h2f(in[v][i] >> 16) * scale));
                     _Float16 ra = __builtin_bit_cast(_Float16, a) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] & 0xFFFF));
                     _Float16 rb = __builtin_bit_cast(_Float16, b) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] >> 16));
                     in[v][i] = (u32)__builtin_bit_cast(uint16_t, ra) | ((u32)__builtin_bit_cast(uint16_t, rb) << 16);

@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
                 u32 xw = xr[n][c];
                 if constexpr (PRO == PRO_RMSNORM) {
                     // (x.float() * rsqrt(mean(x^2)+eps)).half() * w  -- inference/model.py:281-292, both fp16 roundings kept
-                    const _Float16 h0 = (_Float16)(h2f(xw & 0xFFFF) * nscale), h1 = (_Float16)(h2f(xw >> 16) * nscale);
+                    const _Float16 h0 = (_Float16)gq_pin_f32(h2f(xw & 0xFFFF) * nscale), h1 = (_Float16)gq_pin_f32(h2f(xw >> 16) * nscale);
                     xw = h22u((h2v){h0, h1} * u2h2(ar[n][c]));
                 }
                 xsum = __builtin_amdgcn_fdot2(u2h2(xw), one2, xsum, false);

@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(256) dense_gemv_kernel(const uint16_t *x, cons
             const u32 nw[4] = {nv.x, nv.y, nv.z, nv.w};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const h16 a = (h16)(h2f(ww[i] & 0xFFFF) * nscale) * u2h((uint16_t)(nw[i] & 0xFFFF));
-                const h16 b = (h16)(h2f(ww[i] >> 16) * nscale) * u2h((uint16_t)(nw[i] >> 16));
+                const h16 a = (h16)gq_pin_f32(h2f(ww[i] & 0xFFFF) * nscale) * u2h((uint16_t)(nw[i] & 0xFFFF));
+                const h16 b = (h16)gq_pin_f32(h2f(ww[i] >> 16) * nscale) * u2h((uint16_t)(nw[i] >> 16));
                 ww[i] = (u32)h2u(a) | ((u32)h2u(b) << 16);
             }
             v = make_uint4(ww[0], ww[1], ww[2], ww[3]);

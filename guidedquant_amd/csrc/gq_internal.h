@@ -8,6 +8,16 @@ int gq_fail(int code, const char *msg);            // records msg (thread-local)
 int gq_fail_hip(hipError_t e, const char *where);  // records the HIP error string, returns GQ_EHIP
 int gq_env_int(const char *name, int dflt);        // cached getenv -> int (tuning knobs)
 
+#if defined(__HIPCC__)
+// `(half)(a * b)` on floats: the compiler folds the conversion into v_fma_mixlo_f16, which rounds the EXACT product once.
+// The reference's torch ops round the fp32 product first and convert then (two roundings; they differ on fp16 ties of the
+// fp32 value).  Pinning the product in a register keeps the two-step rounding.
+__device__ __forceinline__ float gq_pin_f32(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+#endif
+
 #define GQ_STR2(x) #x
 #define GQ_STR(x) GQ_STR2(x)
 #define GQ_HIP_CHECK(expr)                                                        \

@@ -13,6 +13,7 @@
 // Also: gq_hadamard, y = scale * x @ H_n for n a power of two (fast_hadamard_transform as used by
 // inference/lib/utils/matmul_had.py:96-106).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "gq_internal.h"
@@ -39,19 +40,11 @@ __device__ __forceinline__ u32 unit_of<3>(const u32 (&d)[3], u32 j) {
 template <>
 __device__ __forceinline__ u32 unit_of<4>(const u32 (&d)[4], u32 j) { return d[j]; }
 
+// one 32-row band M2 of the matvec: xs (fp16 [K]) and the codebook tl are in LDS (barrier done by the caller), part is
+// [waves][32] scratch; out[M2 * 32 .. + 31] is written by the first 32 threads
 template <int R>
-__global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32 *comp, const uint16_t *x, const uint16_t *tlut,
-                                                          u32 M, u32 K) {
-    // the codebook sits in a STATIC LDS array (address 0, known to the compiler: the lookup address needs no base add)
-    __shared__ __attribute__((aligned(16))) u32 tl[512];         // [512] half2 codebook
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);          // [K]
-    float *part = reinterpret_cast<float *>(xs + K);            // [waves][32 rows]
+__device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uint16_t *xs, const u32 *tl, float *part, u32 M2, u32 K) {
     const u32 T = blockDim.x, tid = threadIdx.x, W = T >> 6, w = tid >> 6, l = tid & 63u;
-    for (u32 i = tid; i < 512u; i += T) tl[i] = reinterpret_cast<const u32 *>(tlut)[i];
-    for (u32 i = tid; i < K / 8u; i += T) reinterpret_cast<uint4 *>(xs)[i] = reinterpret_cast<const uint4 *>(x)[i];
-    __syncthreads();
-    const u32 M2 = blockIdx.x;           // 32-row band
     const u32 a4 = l >> 5, s = l & 31u;  // tile-row parity, stream unit
     const u32 a = s >> 2, b = s & 3u;
     const u32 nK2 = K / 32u;
@@ -121,6 +114,133 @@ __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32
     }
 }
 
+template <int R>
+__global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32 *comp, const uint16_t *x, const uint16_t *tlut,
+                                                          u32 M, u32 K) {
+    // the codebook sits in a STATIC LDS array (address 0, known to the compiler: the lookup address needs no base add)
+    __shared__ __attribute__((aligned(16))) u32 tl[512];         // [512] half2 codebook
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);          // [K]
+    float *part = reinterpret_cast<float *>(xs + K);            // [waves][32 rows]
+    const u32 T = blockDim.x, tid = threadIdx.x;
+    for (u32 i = tid; i < 512u; i += T) tl[i] = reinterpret_cast<const u32 *>(tlut)[i];
+    for (u32 i = tid; i < K / 8u; i += T) reinterpret_cast<uint4 *>(xs)[i] = reinterpret_cast<const uint4 *>(x)[i];
+    __syncthreads();
+    qtip_band<R>(out, comp, xs, tl, part, blockIdx.x, K);
+}
+
+// in-place Sylvester butterflies on n floats in LDS (n a power of two), barrier after every stage; the order of
+// fwht_kernel below, so the fused linear and hadamard -> matvec -> hadamard agree bit for bit
+__device__ __forceinline__ void fwht_lds(float *v, u32 n) {
+    const u32 T = blockDim.x, tid = threadIdx.x;
+    for (u32 h = 1; h < n; h <<= 1) {
+        for (u32 p = tid; p < n / 2u; p += T) {
+            const u32 j = (p / h) * 2u * h + (p % h);
+            const float a = v[j], b = v[j + h];
+            v[j] = a + b;
+            v[j + h] = a - b;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused QTIP linear
+// BitshiftLinear.forward (inference/lib/codebook/bitshift.py:415-472, eval, one row, no tensor-parallel Hadamard split):
+//   x32 = x.float() * SU;  x = hadamard(x32) * n^-1/2 / 32;  y = decompress_matvec(trellis, x.half(), tlut)       [kernel A]
+//   y = hadamard(y) * m^-1/2;  out = (y * (SV * 32)).half()  (+ the residual add of the block, model.py:311-313)       [kernel B]
+// Kernel A fuses what produces x in the decode step -- RMSNorm (model.py:281-292) or silu(gate) * up (model.py:266) --
+// and serves up to 3 linears that share the input (q/k/v, gate/up) in one launch; every 32-row band block repeats the
+// K-point transform (K log K / 2 butterflies: small next to its 32 x K trellis decode).
+struct QtipIn {
+    const u32 *comp;
+    const float *SU;
+    const uint16_t *tlut;
+    float *y32;
+    u32 band0;  // first block of this linear
+};
+struct QtipInArgs {
+    const uint16_t *x, *x2, *normw;
+    float eps, kscale;  // kscale = (float)K^-1/2, rounded from double like the scale argument of hadamard()
+    u32 K, n;
+    QtipIn lin[3];
+};
+enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2 };
+
+template <int R, int PRO>
+__global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 tl[512];
+    __shared__ float redf[17];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 K = a.K, T = blockDim.x, tid = threadIdx.x;
+    float *v = reinterpret_cast<float *>(smem);                 // [K] fp32 transform buffer
+    uint16_t *xs = reinterpret_cast<uint16_t *>(v + K);         // [K] fp16 matvec input
+    float *part = reinterpret_cast<float *>(xs + K);            // [waves][32]
+    u32 li = 0;
+    if (a.n > 1 && blockIdx.x >= a.lin[1].band0) li = 1;
+    if (a.n > 2 && blockIdx.x >= a.lin[2].band0) li = 2;
+    const QtipIn L = a.lin[li];
+    for (u32 i = tid; i < 512u; i += T) tl[i] = reinterpret_cast<const u32 *>(L.tlut)[i];
+    float nscale = 0.f;
+    if constexpr (PRO == QPRO_RMSNORM) {
+        float ss = 0.f;
+        for (u32 i = tid; i < K; i += T) {
+            const float f = (float)__builtin_bit_cast(h16, a.x[i]);
+            ss += f * f;
+        }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if ((tid & 63u) == 0) redf[tid >> 6] = ss;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
+            redf[16] = 1.0f / sqrtf(t / (float)K + a.eps);
+        }
+        __syncthreads();
+        nscale = redf[16];
+    }
+    for (u32 i = tid; i < K; i += T) {
+        h16 xh = __builtin_bit_cast(h16, a.x[i]);
+        if constexpr (PRO == QPRO_RMSNORM) xh = (h16)gq_pin_f32((float)xh * nscale) * __builtin_bit_cast(h16, a.normw[i]);
+        if constexpr (PRO == QPRO_SILUMUL) {
+            const float g = (float)xh;
+            xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, a.x2[i]);
+        }
+        v[i] = (float)xh * L.SU[i];
+    }
+    __syncthreads();
+    fwht_lds(v, K);
+    const float sc = a.kscale;
+    for (u32 i = tid; i < K; i += T) xs[i] = __builtin_bit_cast(uint16_t, (h16)((v[i] * sc) / 32.0f));
+    __syncthreads();
+    qtip_band<R>(L.y32, L.comp, xs, tl, part, blockIdx.x - L.band0, K);
+}
+
+struct QtipOut {
+    const float *y32, *SV32;  // SV32 = SV * 32 (fp32)
+    const uint16_t *resid;
+    uint16_t *out;
+    u32 M;
+    float mscale;
+};
+struct QtipOutArgs {
+    QtipOut lin[3];
+};
+__global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *v = reinterpret_cast<float *>(smem);
+    const QtipOut L = a.lin[blockIdx.x];
+    const u32 T = blockDim.x, tid = threadIdx.x, M = L.M;
+    for (u32 i = tid; i < M; i += T) v[i] = L.y32[i];
+    __syncthreads();
+    fwht_lds(v, M);
+    const float sc = L.mscale;
+    for (u32 i = tid; i < M; i += T) {
+        h16 y = (h16)gq_pin_f32((v[i] * sc) * L.SV32[i]);
+        if (L.resid) y = __builtin_bit_cast(h16, L.resid[i]) + y;
+        L.out[i] = __builtin_bit_cast(uint16_t, y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Hadamard (FWHT)
 __global__ void __launch_bounds__(1024) fwht_kernel(const float *x, float *y, u32 n, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -172,6 +292,90 @@ extern "C" int gq_qtip_matvec(float *out, const uint32_t *compressed, const void
     else if (R == 3) GQ_LAUNCH_QTIP(3);
     else GQ_LAUNCH_QTIP(4);
 #undef GQ_LAUNCH_QTIP
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+namespace {
+bool pow2(u32 n) { return n && !(n & (n - 1u)); }
+}
+
+extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
+                                 int n, const GqQtipIn *lin, void *stream) {
+    if (!x || !lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: x, 1..3 linears.");
+    if (R < 2 || R > 4) return gq_fail(GQ_ENOTSUP, "R (bits per weight) must be 2, 3 or 4 (kernel_check.py:1-14).");
+    if (!pow2(K) || K < 32u || K > 16384u) return gq_fail(GQ_ENOTSUP, "fused QTIP linear: K must be a power of two in 32..16384.");
+    if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2) || prologue < 0 || prologue > 2)
+        return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: prologue operand missing.");
+    QtipInArgs a{};
+    a.x = (const uint16_t *)x;
+    a.x2 = (const uint16_t *)x2;
+    a.normw = (const uint16_t *)norm_weight;
+    a.eps = eps;
+    a.kscale = (float)pow((double)K, -0.5);
+    a.K = K;
+    a.n = (u32)n;
+    u32 bands = 0, minM = 0xFFFFFFFFu;
+    for (int i = 0; i < n; i++) {
+        if (!lin[i].trellis || !lin[i].SU || !lin[i].tlut || !lin[i].y32 || lin[i].M == 0 || lin[i].M % 32u)
+            return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: null pointer or M not a multiple of 32.");
+        if (((uintptr_t)lin[i].trellis | (uintptr_t)lin[i].tlut) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
+        a.lin[i] = QtipIn{lin[i].trellis, lin[i].SU, (const uint16_t *)lin[i].tlut, lin[i].y32, bands};
+        bands += lin[i].M / 32u;
+        if (lin[i].M < minM) minM = lin[i].M;
+    }
+    const u32 nK2 = K / 32u;
+    u32 waves = nK2 >= 8u ? 8u : (nK2 >= 4u ? 4u : (nK2 >= 2u ? 2u : 1u));
+    if (nK2 >= 32u && bands <= 256u) waves = 16u;
+    if (waves < 4u) waves = 4u;  // the transform wants threads
+    const size_t smem = (size_t)K * 6u + (size_t)waves * 32u * 4u;  // <= 98 KiB
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bands), block(waves * 64u);
+#define GQ_LAUNCH_QIN(RR, PP)                                                                                         \
+    do {                                                                                                              \
+        static bool set = false;                                                                                      \
+        if (!set) {                                                                                                   \
+            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_in_kernel<RR, PP>),           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); /* + static */ \
+            set = true;                                                                                               \
+        }                                                                                                             \
+        hipLaunchKernelGGL((qtip_linear_in_kernel<RR, PP>), grid, block, smem, s, a);                                 \
+    } while (0)
+#define GQ_LAUNCH_QIN_R(RR)                                                   \
+    do {                                                                      \
+        if (prologue == GQ_QPRO_RMSNORM) GQ_LAUNCH_QIN(RR, QPRO_RMSNORM);     \
+        else if (prologue == GQ_QPRO_SILU_MUL) GQ_LAUNCH_QIN(RR, QPRO_SILUMUL); \
+        else GQ_LAUNCH_QIN(RR, QPRO_NONE);                                    \
+    } while (0)
+    if (R == 2) GQ_LAUNCH_QIN_R(2);
+    else if (R == 3) GQ_LAUNCH_QIN_R(3);
+    else GQ_LAUNCH_QIN_R(4);
+#undef GQ_LAUNCH_QIN_R
+#undef GQ_LAUNCH_QIN
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
+    if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out: 1..3 linears.");
+    QtipOutArgs a{};
+    u32 maxM = 0;
+    for (int i = 0; i < n; i++) {
+        if (!lin[i].y32 || !lin[i].SV32 || !lin[i].out) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out: null pointer argument.");
+        if (!pow2(lin[i].M) || lin[i].M < 32u || lin[i].M > 32768u)
+            return gq_fail(GQ_ENOTSUP, "fused QTIP linear: M must be a power of two in 32..32768.");
+        a.lin[i] = QtipOut{lin[i].y32, lin[i].SV32, (const uint16_t *)lin[i].resid, (uint16_t *)lin[i].out, lin[i].M,
+                           (float)pow((double)lin[i].M, -0.5)};
+        if (lin[i].M > maxM) maxM = lin[i].M;
+    }
+    const size_t smem = (size_t)maxM * 4u;
+    static bool set = false;
+    if (!set) {
+        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+        set = true;
+    }
+    hipLaunchKernelGGL(qtip_linear_out_kernel, dim3((u32)n), dim3(1024), smem, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

@@ -264,6 +264,7 @@ class Transformer(nn.Module):
         self.rope_cos, self.rope_sin = rope_tables(head_dim, max_seq_length, self.config.rope_base, device, dtype)
         self.cache_initialized = True
         self._native = None
+        self._native_kind_cache = None
 
     def forward(self, idx: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:
         assert self.cache_initialized, "Caches must be initialized first"
@@ -276,16 +277,38 @@ class Transformer(nn.Module):
 
     # ------------------------------------------------------------------------------------------ fused HIP decode step
     def native_ready(self) -> bool:
+        return self._native_kind() is not None
+
+    def _native_kind(self):
+        """'ap': fused-linear Any-Precision model (<= 4 bit) -> gq_anyprec_gemv_fused chain; 'qtip': unfused QTIP model
+        with power-of-two widths -> gq_qtip_linear_in / _out chain; None: the module-by-module forward."""
         from .APLinear import APLinear
-        if not (self.fuse_linears and self.cache_initialized and self.output.weight.is_cuda):
-            return False
+        if not (self.cache_initialized and self.output.weight.is_cuda):
+            return None
         if self.output.weight.dtype != torch.float16 or self.max_batch_size < 1:
-            return False
-        for b in self.layers:
-            for m in (b.attention.wqkv, b.attention.wo, b.feed_forward.w1w3, b.feed_forward.w2):
-                if not isinstance(m, APLinear) or m.bias is not None or m.bitwidth > 4 or m.in_features % 128:
-                    return False
-        return True
+            return None
+        kind = getattr(self, "_native_kind_cache", None)
+        if kind is not None:
+            return kind or None
+        kind = ""
+        if self.fuse_linears:
+            if all(isinstance(m, APLinear) and m.bias is None and m.bitwidth <= 4 and m.in_features % 128 == 0
+                   for b in self.layers for m in (b.attention.wqkv, b.attention.wo, b.feed_forward.w1w3, b.feed_forward.w2)):
+                kind = "ap"
+        elif os.environ.get("GQ_NATIVE_QTIP", "1") != "0":
+            from .qtip import QuantizedLinear
+
+            def ok(m):
+                p2 = lambda n: n > 0 and (n & (n - 1)) == 0  # noqa: E731
+                return (isinstance(m, QuantizedLinear) and m.bias is None and m.has_kernel and m.K_left == 1 and m.K_right == 1
+                        and int(m.rcp.item()) == 0 and p2(m.in_features) and p2(m.out_features) and 32 <= m.in_features <= 16384
+                        and m.out_features <= 32768)
+            if self.config.head_dim in (64, 128) and all(
+                    ok(m) for b in self.layers for m in (b.attention.wq, b.attention.wk, b.attention.wv, b.attention.wo,
+                                                         b.feed_forward.w1, b.feed_forward.w3, b.feed_forward.w2)):
+                kind = "qtip"
+        self._native_kind_cache = kind
+        return kind or None
 
     def _native_state(self):
         if self._native is None:
@@ -300,12 +323,88 @@ class Transformer(nn.Module):
             # w1w3 tensor lets the w1w3 GEMV write silu(gate) * up directly (model.py:266 of the reference), so w2 reads a
             # plain vector.  The module buffers keep the reference layout [w1; w3] (state-dict contract, prefill path).
             self._native["pairs"] = None
-            if os.environ.get("GQ_NATIVE_PAIRS", "1") != "0":
+            if self._native_kind() == "qtip":
+                self._native_qtip_state(self._native)
+            elif os.environ.get("GQ_NATIVE_PAIRS", "1") != "0":
                 inter = c.intermediate_size
                 perm = torch.stack((torch.arange(inter, device=dev), torch.arange(inter, 2 * inter, device=dev)), dim=1).reshape(-1)
                 self._native["pairs"] = [(b.feed_forward.w1w3.qweight[:b.feed_forward.w1w3.bitwidth, perm, :].contiguous(),
                                           b.feed_forward.w1w3.lut[perm].contiguous()) for b in self.layers]
         return self._native
+
+    def _native_qtip_state(self, st):
+        """descriptor arrays of the fused QTIP linears (gq_qtip_linear_in / _out), per layer: (qkv in, qkv out, o in, o out,
+        gate/up in, gate/up out, down in, down out).  SU as fp32, SV * 32 as fp32 (the values BitshiftLinear.forward
+        multiplies with, bitshift.py:441,470); q/k/v land in the packed buffer the attention kernel reads."""
+        c = self.config
+        dev = self.output.weight.device
+        kv = c.n_local_heads * c.head_dim
+        st["g"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
+        st["u"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
+        mmax = max(c.dim, c.intermediate_size)
+        st["y32"] = torch.zeros(3, mmax, dtype=torch.float32, device=dev)
+        keep = []  # fp32 copies the descriptors point into
+
+        def f32(t, mul=1.0):
+            t = (t.detach().float() * mul).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def lin_in(mods):
+            arr = (_lib.GqQtipIn * len(mods))()
+            for i, m in enumerate(mods):
+                arr[i] = _lib.GqQtipIn(m.trellis.data_ptr(), f32(m.SU), m.tlut.data_ptr(), st["y32"][i].data_ptr(), m.out_features)
+            return arr
+
+        def lin_out(mods, outs, resid):
+            arr = (_lib.GqQtipOut * len(mods))()
+            for i, m in enumerate(mods):
+                arr[i] = _lib.GqQtipOut(st["y32"][i].data_ptr(), f32(m.SV, 32.0), resid, outs[i], m.out_features)
+            return arr
+
+        x, h, y, qkv = st["x"], st["h"], st["y"], st["qkv"]
+        e = qkv.element_size()
+        layers = []
+        for b in self.layers:
+            at, ff = b.attention, b.feed_forward
+            layers.append(dict(
+                qkv_in=lin_in([at.wq, at.wk, at.wv]),
+                qkv_out=lin_out([at.wq, at.wk, at.wv], [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e], None),
+                o_in=lin_in([at.wo]), o_out=lin_out([at.wo], [h.data_ptr()], x.data_ptr()),
+                gu_in=lin_in([ff.w1, ff.w3]), gu_out=lin_out([ff.w1, ff.w3], [st["g"].data_ptr(), st["u"].data_ptr()], None),
+                d_in=lin_in([ff.w2]), d_out=lin_out([ff.w2], [x.data_ptr()], h.data_ptr()), R=at.wq.K))
+        st["qtip_layers"] = layers
+        st["qtip_keep"] = keep
+
+    def _native_layers_qtip(self, x: Tensor, pos: Tensor, l0: int, l1: int, slot: int = 0):
+        """one decode step of layers [l0, l1) of an unfused QTIP model: 9 launches per layer (A = transform-in + trellis
+        matvec, B = transform-out): A(q,k,v | RMSNorm) B(q,k,v) attention A(o) B(o + residual) A(gate,up | RMSNorm)
+        B(gate,up) A(down | silu*mul) B(down + residual)"""
+        L = _lib.lib()
+        sp = _lib.current_stream_ptr()
+        c = self.config
+        b = self._native_state()
+        assert x.data_ptr() == b["x"].data_ptr(), "the QTIP descriptors are bound to the model's own hidden-state buffer"
+        h, y, qkv, g, u = b["h"], b["y"], b["qkv"], b["g"], b["u"]
+        ck = _lib.check
+        scale = 1.0 / math.sqrt(c.head_dim)
+        kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2
+        for li in range(l0, l1):
+            blk, d = self.layers[li], b["qtip_layers"][li]
+            at = blk.attention
+            ck(L.gq_qtip_linear_in(x.data_ptr(), None, blk.input_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 3,
+                                   d["qkv_in"], sp), "qtip qkv in")
+            ck(L.gq_qtip_linear_out(3, d["qkv_out"], sp), "qtip qkv out")
+            ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
+                                at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
+                                y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, sp), "attn")
+            ck(L.gq_qtip_linear_in(y.data_ptr(), None, None, 0.0, 0, c.dim, d["R"], 1, d["o_in"], sp), "qtip o in")
+            ck(L.gq_qtip_linear_out(1, d["o_out"], sp), "qtip o out")
+            ck(L.gq_qtip_linear_in(h.data_ptr(), None, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 2,
+                                   d["gu_in"], sp), "qtip gate/up in")
+            ck(L.gq_qtip_linear_out(2, d["gu_out"], sp), "qtip gate/up out")
+            ck(L.gq_qtip_linear_in(g.data_ptr(), u.data_ptr(), None, 0.0, 2, c.intermediate_size, d["R"], 1, d["d_in"], sp), "qtip down in")
+            ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
 
     def native_embed(self, tok: Tensor, x: Tensor):
         _lib.check(_lib.lib().gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), self.config.dim,
@@ -314,6 +413,8 @@ class Transformer(nn.Module):
     def native_layers(self, x: Tensor, pos: Tensor, l0: int, l1: int, slot: int = 0):
         """layers [l0, l1) of one decode step, in place on the hidden state `x` (fp16 [dim]); `slot` = batch index of
         the KV caches to use (layer-pipelined decode keeps one sequence per slot)."""
+        if self._native_kind() == "qtip":
+            return self._native_layers_qtip(x, pos, l0, l1, slot)
         L = _lib.lib()
         st = _lib.current_stream_ptr()
         c = self.config

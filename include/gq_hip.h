@@ -106,6 +106,41 @@ int gq_qtip_matvec(float *out, const uint32_t *compressed, const void *x, const 
 int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale, void *stream);
 
 /*
+ * Fused QTIP linear for one decode row (bs = 1), in two launches.  Replaces the op sequence of
+ * BitshiftLinear.forward (inference/lib/codebook/bitshift.py:415-472, eval mode, rcp == 0) around
+ * decompress_matvec: x.float() * SU -> hadamard * n^-1/2 / 32 -> .half() -> matvec [gq_qtip_linear_in], then
+ * hadamard * m^-1/2 -> * (SV * 32) -> .half() [gq_qtip_linear_out], with the decode step's own element-wise ops
+ * folded in: the RMSNorm in front of q/k/v and gate/up (inference/model.py:281-292), silu(gate) * up in front of the
+ * down projection (model.py:266), the residual add behind wo / w2 (model.py:311-313).  Up to 3 linears that share the
+ * input (q/k/v; gate/up) go in one launch.  K and every M must be powers of two (the reference's non-power-of-two
+ * Hadamard factors are data tables this library does not carry: those models run the unfused ops).
+ * Same arithmetic and the same butterfly order as gq_hadamard + gq_qtip_matvec: bit-identical to the unfused chain.
+ *   x fp16 [K] (prologue SILU_MUL: x = gate, x2 = up), norm_weight fp16 [K];
+ *   GqQtipIn : trellis u32 [R*M*K/32], SU f32 [K], tlut fp16 [1024], y32 f32 [M] (written);
+ *   GqQtipOut: y32 f32 [M], SV32 f32 [M] (= SV * 32), resid fp16 [M] or NULL, out fp16 [M] (may alias resid).
+ */
+#define GQ_QPRO_NONE 0
+#define GQ_QPRO_RMSNORM 1
+#define GQ_QPRO_SILU_MUL 2
+typedef struct GqQtipIn {
+    const uint32_t *trellis;
+    const float *SU;
+    const void *tlut;
+    float *y32;
+    uint32_t M;
+} GqQtipIn;
+typedef struct GqQtipOut {
+    const float *y32;
+    const float *SV32;
+    const void *resid;
+    void *out;
+    uint32_t M;
+} GqQtipOut;
+int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
+                      int n, const GqQtipIn *lin, void *stream);
+int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
+
+/*
  * Fused decode-step variant of the AP GEMV, M = 1: optional prologue on x
  * (RMSNorm, or SiLU(gate)*up of a fused gate/up vector) and optional residual-add epilogue, with the same
  * fp16 rounding points as the reference's separate kernels (inference/model.py:151-166,259-266,281-292).

@@ -127,3 +127,137 @@ def test_qtip_backend_model_decodes():
         assert nxt.shape[-1] == 1 and 0 <= int(nxt.reshape(-1)[0]) < 512
         assert bool(torch.isfinite(probs.float()).all())
         tok = nxt.reshape(1, 1).to(torch.int32)
+
+
+# ----------------------------------------------------------------------------- fused linear (gq_qtip_linear_in / _out)
+def _fused_linear(lin, x16, pro=0, x2=None, normw=None, eps=1e-5, resid=None, group=None):
+    """runs the two-launch fused linear for the QuantizedLinear modules in `group` (default [lin]) on input x16 (fp16 [K])"""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    mods = group or [lin]
+    d = x16.device
+    K = mods[0].in_features
+    su = [m.SU.float().contiguous() for m in mods]
+    sv = [(m.SV.float() * 32.0).contiguous() for m in mods]
+    y32 = [torch.full((m.out_features,), float("nan"), dtype=torch.float32, device=d) for m in mods]
+    outs = [torch.full((m.out_features,), float("nan"), dtype=torch.float16, device=d) for m in mods]
+    ain = (_lib.GqQtipIn * len(mods))()
+    aout = (_lib.GqQtipOut * len(mods))()
+    for i, m in enumerate(mods):
+        ain[i] = _lib.GqQtipIn(m.trellis.data_ptr(), su[i].data_ptr(), m.tlut.data_ptr(), y32[i].data_ptr(), m.out_features)
+        aout[i] = _lib.GqQtipOut(y32[i].data_ptr(), sv[i].data_ptr(), resid.data_ptr() if resid is not None else None,
+                                 outs[i].data_ptr(), m.out_features)
+    st = _lib.current_stream_ptr()
+    _lib.check(L.gq_qtip_linear_in(x16.data_ptr(), x2.data_ptr() if x2 is not None else None,
+                                   normw.data_ptr() if normw is not None else None, eps, pro, K, mods[0].K, len(mods), ain, st), "in")
+    _lib.check(L.gq_qtip_linear_out(len(mods), aout, st), "out")
+    torch.cuda.synchronize()
+    return outs
+
+
+def _rand_qlinear(K, M, R, seed):
+    from guidedquant_amd.qtip import QuantizedLinear
+    d = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lin = QuantizedLinear(K, M, 16, 16, 16, R, 2, 9, "quantlut_sym", device=d)
+    lin.trellis.copy_(torch.randint(-2**15, 2**15 - 1, lin.trellis.shape, dtype=torch.int16, generator=g))
+    lin.tlut.data.copy_(torch.clamp(torch.randn(512, 2, generator=g) / 16, -1, 1).half())
+    lin.SU.copy_((torch.randint(0, 2, (K,), generator=g) * 2 - 1).half() * (1 + 0.1 * torch.rand(K, generator=g)).half())
+    lin.SV.copy_((torch.randint(0, 2, (M,), generator=g) * 2 - 1).float() * (1 + 0.1 * torch.rand(M, generator=g)))
+    return lin
+
+
+@pytest.mark.parametrize("R", [2, 3, 4])
+@pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 8192), (8192, 4096), (256, 128), (2048, 16384)])
+def test_fused_linear_is_bit_identical_to_the_op_chain(R, M, K):
+    """gq_qtip_linear_in + _out == x*SU -> hadamard -> /32 -> half -> decompress_matvec -> hadamard -> *(SV*32) -> half
+    as QuantizedLinear.forward runs it on the separate ops (bitshift.py:415-472): same arithmetic, same butterfly order"""
+    lin = _rand_qlinear(K, M, R, seed=R * 1000 + M + K)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(1, 1, K, generator=g).half().cuda()
+    with torch.no_grad():
+        want = lin(x).reshape(-1)
+    got = _fused_linear(lin, x.reshape(-1).contiguous())[0]
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+def test_fused_linear_prologues_and_residual(oracle):
+    """RMSNorm / silu*mul prologues and the residual epilogue against the module chain fed with the torch-side ops of the
+    decode step (model.py:266,281-292,311-313); q/k/v-style group launch against per-linear launches (fp32 sum order of
+    the K-split may differ with the block shape: tolerance 2 fp16 ulp)"""
+    from guidedquant_amd.model import RMSNorm
+    K, M, R = 4096, 4096, 2
+    d = torch.device("cuda:0")
+    a, b, c = (_rand_qlinear(K, m, R, seed=s) for m, s in ((M, 1), (1024, 2), (1024, 3)))
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = (torch.randn(K, generator=g) * 0.7).half().to(d)
+    x2 = torch.randn(K, generator=g).half().to(d)
+    norm = RMSNorm(K, 1e-5).to(d).half()
+    norm.weight.data.copy_((1 + 0.2 * torch.randn(K, generator=g)).half())
+    resid = torch.randn(M, generator=g).half().to(d)
+
+    def close(got, want, ulps=2):
+        # the prologue's sum of squares is added in another order than torch's mean(): 1/rms may differ in its last bit, which
+        # flips the fp16 rounding of a few normalised activations -> a perturbation of ~2^-11 of the output's rms
+        gw, ww = got.float(), want.float()
+        tol = ulps * torch.maximum(torch.abs(ww) * 2.0**-10, torch.full_like(ww, 2.0**-24)) + 3e-3 * torch.sqrt(torch.mean(ww * ww))
+        assert bool((torch.abs(gw - ww) <= tol).all()), float(torch.abs(gw - ww).max())
+
+    with torch.no_grad():
+        xn = norm(x.view(1, 1, K))
+        want = [m(xn).reshape(-1).clone() for m in (a, b, c)]
+        got = _fused_linear(a, x, pro=1, normw=norm.weight.data, eps=1e-5, group=[a, b, c])
+        for gq, w in zip(got, want):
+            close(gq, w)
+        xs = torch.nn.functional.silu(x.view(1, 1, K)) * x2.view(1, 1, K)
+        want = resid + a(xs).reshape(-1)
+        got = _fused_linear(a, x, pro=2, x2=x2, resid=resid)[0]
+        close(got, want)
+        assert torch.equal(_fused_linear(a, xs.reshape(-1).contiguous(), resid=resid)[0].view(torch.int16), want.view(torch.int16))
+
+
+def test_fused_linear_validation():
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    lin = _rand_qlinear(128, 64, 2, seed=5)
+    x = torch.zeros(128, dtype=torch.float16, device="cuda:0")
+    with pytest.raises(RuntimeError, match="power of two"):
+        ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), lin.SU.float().data_ptr(), lin.tlut.data_ptr(), x.data_ptr(), 64))
+        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 0, 96, 2, 1, ain, None), "in")
+    with pytest.raises(RuntimeError, match="prologue operand"):
+        ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), lin.SU.float().data_ptr(), lin.tlut.data_ptr(), x.data_ptr(), 64))
+        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 1, 128, 2, 1, ain, None), "in")
+
+
+def test_qtip_native_decode_matches_module_forward():
+    """the 9-launch-per-layer native QTIP decode step (Transformer.decode_native) against the module-by-module forward of
+    the same model: logits agree to fp16 rounding noise, greedy tokens agree"""
+    import os
+    from guidedquant_amd import model as gm
+    from guidedquant_amd.generate import load_model
+    gm.transformer_configs["qtip-native-test"] = dict(model_name="llama-qtip-native-test", block_size=128, vocab_size=512, n_layer=3,
+                                                      n_head=8, dim=1024, intermediate_size=2048, n_local_heads=4)
+    try:
+        m = load_model("qtip-native-test", "cuda:0", "qtip", 2, random_init=True)
+    finally:
+        del gm.transformer_configs["qtip-native-test"]
+    with torch.device("cuda:0"):
+        m.setup_caches(max_batch_size=1, max_seq_length=64)
+    assert m.native_ready() and m._native_kind() == "qtip"
+    toks = [1, 17, 200, 5]
+    ref = []
+    with torch.no_grad():
+        for p, t in enumerate(toks):
+            ref.append(m(torch.tensor([[t]], dtype=torch.int32, device="cuda:0"), torch.tensor([p], dtype=torch.int32, device="cuda:0"))
+                       .float().reshape(-1).clone())
+        for b in m.layers:  # fresh caches for the native pass
+            b.attention.kv_cache.k_cache.zero_()
+            b.attention.kv_cache.v_cache.zero_()
+        for p, t in enumerate(toks):
+            got = m.decode_native(torch.tensor([t], dtype=torch.int32, device="cuda:0"),
+                                  torch.tensor([p], dtype=torch.int32, device="cuda:0")).float().reshape(-1)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(got).all())
+            err = float(torch.abs(got - ref[p]).max()) / (float(torch.abs(ref[p]).max()) + 1e-9)
+            assert err < 2e-2, err
+            assert int(got.argmax()) == int(ref[p].argmax()) or err < 5e-3

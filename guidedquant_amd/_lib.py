@@ -55,7 +55,7 @@ def lib():
         L.gq_lutgemm_gemv.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, i32, vp]
         L.gq_qtip_matvec.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp]
         L.gq_hadamard.argtypes = [vp, vp, u32, u32, f32, vp]
-        L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), vp]
+        L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, ctypes.POINTER(GqQtipOut), vp]
         L.gq_qtip_linear_out.argtypes = [i32, ctypes.POINTER(GqQtipOut), vp]
         L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]
         L.gq_set_ap_mode.argtypes = [i32]

@@ -129,16 +129,52 @@ __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32
     qtip_band<R>(out, comp, xs, tl, part, blockIdx.x, K);
 }
 
-// in-place Sylvester butterflies on n floats in LDS (n a power of two), barrier after every stage; the order of
-// fwht_kernel below, so the fused linear and hadamard -> matvec -> hadamard agree bit for bit
+// in-place Sylvester butterflies on n floats in LDS (n a power of two, barrier behind the last pass).  Stages h = 1, 2, 4, ..
+// in this order with (a + b, a - b) at (j, j + h): the arithmetic of a plain radix-2 loop, but three stages at a time on 8
+// registers per work item (4 barriers for n = 4096 instead of 12).  Every user (gq_hadamard, the fused linear) shares it,
+// so hadamard -> matvec -> hadamard and the fused kernels agree bit for bit.
 __device__ __forceinline__ void fwht_lds(float *v, u32 n) {
     const u32 T = blockDim.x, tid = threadIdx.x;
-    for (u32 h = 1; h < n; h <<= 1) {
-        for (u32 p = tid; p < n / 2u; p += T) {
-            const u32 j = (p / h) * 2u * h + (p % h);
-            const float a = v[j], b = v[j + h];
-            v[j] = a + b;
-            v[j + h] = a - b;
+    u32 h0 = 1;
+    while (h0 < n) {
+        const u32 left = n / h0;  // 2^(stages left)
+        if (left >= 8u) {
+            for (u32 t = tid; t < n / 8u; t += T) {
+                const u32 lo = t & (h0 - 1u), hi = t / h0;
+                float *b = v + hi * 8u * h0 + lo;
+                float r[8];
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) r[k] = b[k * h0];
+#pragma unroll
+                for (u32 st = 1; st < 8; st <<= 1)
+#pragma unroll
+                    for (u32 k = 0; k < 8; k++)
+                        if (!(k & st)) {
+                            const float x0 = r[k], x1 = r[k | st];
+                            r[k] = x0 + x1;
+                            r[k | st] = x0 - x1;
+                        }
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) b[k * h0] = r[k];
+            }
+            h0 *= 8u;
+        } else {  // one or two stages left
+            const u32 rad = left;  // 2 or 4
+            for (u32 t = tid; t < n / rad; t += T) {
+                const u32 lo = t & (h0 - 1u), hi = t / h0;
+                float *b = v + hi * rad * h0 + lo;
+                float r[4];
+                for (u32 k = 0; k < rad; k++) r[k] = b[k * h0];
+                for (u32 st = 1; st < rad; st <<= 1)
+                    for (u32 k = 0; k < rad; k++)
+                        if (!(k & st)) {
+                            const float x0 = r[k], x1 = r[k | st];
+                            r[k] = x0 + x1;
+                            r[k | st] = x0 - x1;
+                        }
+                for (u32 k = 0; k < rad; k++) b[k * h0] = r[k];
+            }
+            h0 *= rad;
         }
         __syncthreads();
     }
@@ -158,11 +194,20 @@ struct QtipIn {
     float *y32;
     u32 band0;  // first block of this linear
 };
+struct QtipOut {
+    const float *y32, *SV32;  // SV32 = SV * 32 (fp32)
+    const uint16_t *resid;
+    uint16_t *out;
+    u32 M;
+    float mscale;
+};
 struct QtipInArgs {
     const uint16_t *x, *x2, *normw;
     float eps, kscale;  // kscale = (float)K^-1/2, rounded from double like the scale argument of hadamard()
     u32 K, n;
     QtipIn lin[3];
+    u32 nprev;          // 1 / 2: x (and x2) are the outputs of the linears prev[] whose transform-out is done here (M == K)
+    QtipOut prev[2];
 };
 enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2 };
 
@@ -180,11 +225,33 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     if (a.n > 2 && blockIdx.x >= a.lin[2].band0) li = 2;
     const QtipIn L = a.lin[li];
     for (u32 i = tid; i < 512u; i += T) tl[i] = reinterpret_cast<const u32 *>(L.tlut)[i];
+    // Folded transform-out of the producing linear(s): what gq_qtip_linear_out would have written is rebuilt in LDS by
+    // every block (same arithmetic, same order) and stored once, by block 0, for the kernels that need it later
+    // (the residual stream).  One launch and one global round trip less per linear.
+    const uint16_t *xg = a.x, *x2g = a.x2;
+    if (a.nprev) {
+        uint16_t *xp = reinterpret_cast<uint16_t *>(part + (T >> 6) * 32u);  // [nprev][K] fp16
+        for (u32 r = 0; r < a.nprev; r++) {
+            const QtipOut P = a.prev[r];
+            for (u32 i = tid; i < K; i += T) v[i] = P.y32[i];
+            __syncthreads();
+            fwht_lds(v, K);
+            for (u32 i = tid; i < K; i += T) {
+                h16 y = (h16)gq_pin_f32((v[i] * P.mscale) * P.SV32[i]);
+                if (P.resid) y = __builtin_bit_cast(h16, P.resid[i]) + y;
+                xp[r * K + i] = __builtin_bit_cast(uint16_t, y);
+                if (blockIdx.x == 0 && P.out) P.out[i] = __builtin_bit_cast(uint16_t, y);
+            }
+            __syncthreads();
+        }
+        xg = xp;
+        x2g = xp + K;
+    }
     float nscale = 0.f;
     if constexpr (PRO == QPRO_RMSNORM) {
         float ss = 0.f;
         for (u32 i = tid; i < K; i += T) {
-            const float f = (float)__builtin_bit_cast(h16, a.x[i]);
+            const float f = (float)__builtin_bit_cast(h16, xg[i]);
             ss += f * f;
         }
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
@@ -199,11 +266,11 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         nscale = redf[16];
     }
     for (u32 i = tid; i < K; i += T) {
-        h16 xh = __builtin_bit_cast(h16, a.x[i]);
+        h16 xh = __builtin_bit_cast(h16, xg[i]);
         if constexpr (PRO == QPRO_RMSNORM) xh = (h16)gq_pin_f32((float)xh * nscale) * __builtin_bit_cast(h16, a.normw[i]);
         if constexpr (PRO == QPRO_SILUMUL) {
             const float g = (float)xh;
-            xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, a.x2[i]);
+            xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, x2g[i]);
         }
         v[i] = (float)xh * L.SU[i];
     }
@@ -215,13 +282,6 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     qtip_band<R>(L.y32, L.comp, xs, tl, part, blockIdx.x - L.band0, K);
 }
 
-struct QtipOut {
-    const float *y32, *SV32;  // SV32 = SV * 32 (fp32)
-    const uint16_t *resid;
-    uint16_t *out;
-    u32 M;
-    float mscale;
-};
 struct QtipOutArgs {
     QtipOut lin[3];
 };
@@ -231,9 +291,34 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     const QtipOut L = a.lin[blockIdx.x];
     const u32 T = blockDim.x, tid = threadIdx.x, M = L.M;
     for (u32 i = tid; i < M; i += T) v[i] = L.y32[i];
+    // the scale and residual vectors are requested before the transform (one block: nothing else hides their latency)
+    constexpr u32 PRE = 8;  // M <= 8192 at 1024 threads
+    float svr[PRE];
+    uint16_t rsr[PRE];
+    const bool pre = M <= PRE * T;
+    if (pre) {
+#pragma unroll
+        for (u32 k = 0; k < PRE; k++) {
+            const u32 i = tid + k * T;
+            svr[k] = i < M ? L.SV32[i] : 0.f;
+            rsr[k] = (i < M && L.resid) ? L.resid[i] : (uint16_t)0;
+        }
+    }
     __syncthreads();
     fwht_lds(v, M);
     const float sc = L.mscale;
+    if (pre) {
+#pragma unroll
+        for (u32 k = 0; k < PRE; k++) {
+            const u32 i = tid + k * T;
+            if (i < M) {
+                h16 y = (h16)gq_pin_f32((v[i] * sc) * svr[k]);
+                if (L.resid) y = __builtin_bit_cast(h16, rsr[k]) + y;
+                L.out[i] = __builtin_bit_cast(uint16_t, y);
+            }
+        }
+        return;
+    }
     for (u32 i = tid; i < M; i += T) {
         h16 y = (h16)gq_pin_f32((v[i] * sc) * L.SV32[i]);
         if (L.resid) y = __builtin_bit_cast(h16, L.resid[i]) + y;
@@ -250,15 +335,7 @@ __global__ void __launch_bounds__(1024) fwht_kernel(const float *x, float *y, u3
     float *yr = y + (size_t)blockIdx.x * n;
     for (u32 i = tid; i < n; i += T) v[i] = xr[i];
     __syncthreads();
-    for (u32 h = 1; h < n; h <<= 1) {
-        for (u32 p = tid; p < n / 2u; p += T) {
-            const u32 j = (p / h) * 2u * h + (p % h);
-            const float a = v[j], b = v[j + h];
-            v[j] = a + b;
-            v[j + h] = a - b;
-        }
-        __syncthreads();
-    }
+    fwht_lds(v, n);
     for (u32 i = tid; i < n; i += T) yr[i] = v[i] * scale;
 }
 }  // namespace
@@ -301,11 +378,15 @@ bool pow2(u32 n) { return n && !(n & (n - 1u)); }
 }
 
 extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
-                                 int n, const GqQtipIn *lin, void *stream) {
-    if (!x || !lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: x, 1..3 linears.");
+                                 int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, void *stream) {
+    if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 1..3 linears.");
+    if (n_prev < 0 || n_prev > 2 || (n_prev && !prev)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 0..2 producing linears.");
+    if (n_prev == 0 && !x) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: x is null.");
+    if (n_prev && n_prev != (prologue == GQ_QPRO_SILU_MUL ? 2 : 1))
+        return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: one producing linear per input vector (two for SILU_MUL).");
     if (R < 2 || R > 4) return gq_fail(GQ_ENOTSUP, "R (bits per weight) must be 2, 3 or 4 (kernel_check.py:1-14).");
     if (!pow2(K) || K < 32u || K > 16384u) return gq_fail(GQ_ENOTSUP, "fused QTIP linear: K must be a power of two in 32..16384.");
-    if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2) || prologue < 0 || prologue > 2)
+    if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2 && !n_prev) || prologue < 0 || prologue > 2)
         return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: prologue operand missing.");
     QtipInArgs a{};
     a.x = (const uint16_t *)x;
@@ -328,7 +409,12 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
     u32 waves = nK2 >= 8u ? 8u : (nK2 >= 4u ? 4u : (nK2 >= 2u ? 2u : 1u));
     if (nK2 >= 32u && bands <= 256u) waves = 16u;
     if (waves < 4u) waves = 4u;  // the transform wants threads
-    const size_t smem = (size_t)K * 6u + (size_t)waves * 32u * 4u;  // <= 98 KiB
+    a.nprev = (u32)n_prev;
+    for (int i = 0; i < n_prev; i++) {
+        if (!prev[i].y32 || !prev[i].SV32 || prev[i].M != K) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: producing linear must have M == K.");
+        a.prev[i] = QtipOut{prev[i].y32, prev[i].SV32, (const uint16_t *)prev[i].resid, (uint16_t *)prev[i].out, K, (float)pow((double)K, -0.5)};
+    }
+    const size_t smem = (size_t)K * 6u + (size_t)waves * 32u * 4u + (size_t)n_prev * K * 2u;  // <= 130 KiB
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bands), block(waves * 64u);
 #define GQ_LAUNCH_QIN(RR, PP)                                                                                         \

@@ -377,9 +377,10 @@ class Transformer(nn.Module):
         st["qtip_keep"] = keep
 
     def _native_layers_qtip(self, x: Tensor, pos: Tensor, l0: int, l1: int, slot: int = 0):
-        """one decode step of layers [l0, l1) of an unfused QTIP model: 9 launches per layer (A = transform-in + trellis
-        matvec, B = transform-out): A(q,k,v | RMSNorm) B(q,k,v) attention A(o) B(o + residual) A(gate,up | RMSNorm)
-        B(gate,up) A(down | silu*mul) B(down + residual)"""
+        """one decode step of layers [l0, l1) of an unfused QTIP model (A = transform-in + trellis matvec, B = transform-out):
+        A(q,k,v | RMSNorm) B(q,k,v) attention A(o) B(o + residual) A(gate,up | RMSNorm) B(gate,up) A(down | silu*mul)
+        B(down + residual) -- 9 launches per layer, 6 with the B of o, gate/up and down folded into the A that consumes
+        it (GQ_NATIVE_QTIP_FOLD; bit-identical, measured slower, default off)"""
         L = _lib.lib()
         sp = _lib.current_stream_ptr()
         c = self.config
@@ -389,22 +390,30 @@ class Transformer(nn.Module):
         ck = _lib.check
         scale = 1.0 / math.sqrt(c.head_dim)
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2
+        # transform-out folded into the consuming kernel: bit-identical, 3 launches per layer fewer, but every block repeats
+        # the producer's transform -- measured slower (222 vs 243 tokens/s on the 7B-like model), so off by default
+        fold = os.environ.get("GQ_NATIVE_QTIP_FOLD", "0") != "0"
         for li in range(l0, l1):
             blk, d = self.layers[li], b["qtip_layers"][li]
             at = blk.attention
+            carry = fold and li > l0  # the hidden state is still the previous layer's untransformed down projection
             ck(L.gq_qtip_linear_in(x.data_ptr(), None, blk.input_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 3,
-                                   d["qkv_in"], sp), "qtip qkv in")
+                                   d["qkv_in"], 1 if carry else 0, b["qtip_layers"][li - 1]["d_out"] if carry else None, sp), "qtip qkv in")
             ck(L.gq_qtip_linear_out(3, d["qkv_out"], sp), "qtip qkv out")
             ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
                                 at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
                                 y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, sp), "attn")
-            ck(L.gq_qtip_linear_in(y.data_ptr(), None, None, 0.0, 0, c.dim, d["R"], 1, d["o_in"], sp), "qtip o in")
-            ck(L.gq_qtip_linear_out(1, d["o_out"], sp), "qtip o out")
+            ck(L.gq_qtip_linear_in(y.data_ptr(), None, None, 0.0, 0, c.dim, d["R"], 1, d["o_in"], 0, None, sp), "qtip o in")
+            if not fold:
+                ck(L.gq_qtip_linear_out(1, d["o_out"], sp), "qtip o out")
             ck(L.gq_qtip_linear_in(h.data_ptr(), None, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 2,
-                                   d["gu_in"], sp), "qtip gate/up in")
-            ck(L.gq_qtip_linear_out(2, d["gu_out"], sp), "qtip gate/up out")
-            ck(L.gq_qtip_linear_in(g.data_ptr(), u.data_ptr(), None, 0.0, 2, c.intermediate_size, d["R"], 1, d["d_in"], sp), "qtip down in")
-            ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
+                                   d["gu_in"], 1 if fold else 0, d["o_out"] if fold else None, sp), "qtip gate/up in")
+            if not fold:
+                ck(L.gq_qtip_linear_out(2, d["gu_out"], sp), "qtip gate/up out")
+            ck(L.gq_qtip_linear_in(g.data_ptr(), u.data_ptr(), None, 0.0, 2, c.intermediate_size, d["R"], 1, d["d_in"],
+                                   2 if fold else 0, d["gu_out"] if fold else None, sp), "qtip down in")
+            if not fold or li == l1 - 1:
+                ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
 
     def native_embed(self, tok: Tensor, x: Tensor):
         _lib.check(_lib.lib().gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), self.config.dim,

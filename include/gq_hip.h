@@ -118,6 +118,10 @@ int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale
  *   x fp16 [K] (prologue SILU_MUL: x = gate, x2 = up), norm_weight fp16 [K];
  *   GqQtipIn : trellis u32 [R*M*K/32], SU f32 [K], tlut fp16 [1024], y32 f32 [M] (written);
  *   GqQtipOut: y32 f32 [M], SV32 f32 [M] (= SV * 32), resid fp16 [M] or NULL, out fp16 [M] (may alias resid).
+ * Folding: with n_prev = 1 (2 for SILU_MUL) the input vector(s) of gq_qtip_linear_in are NOT read from x / x2 but rebuilt
+ * from prev[] -- the transform-out of the linear(s) that produce them (M == K), residual included -- by every block, and
+ * stored to prev[i].out (if not NULL; must not alias prev[i].resid) once: gq_qtip_linear_out and its launch are saved for
+ * wo -> gate/up, gate/up -> down and down -> next layer's q/k/v.  Bit-identical to the two-launch form.
  */
 #define GQ_QPRO_NONE 0
 #define GQ_QPRO_RMSNORM 1
@@ -137,7 +141,7 @@ typedef struct GqQtipOut {
     uint32_t M;
 } GqQtipOut;
 int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
-                      int n, const GqQtipIn *lin, void *stream);
+                      int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, void *stream);
 int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
 
 /*

@@ -149,7 +149,7 @@ def _fused_linear(lin, x16, pro=0, x2=None, normw=None, eps=1e-5, resid=None, gr
                                  outs[i].data_ptr(), m.out_features)
     st = _lib.current_stream_ptr()
     _lib.check(L.gq_qtip_linear_in(x16.data_ptr(), x2.data_ptr() if x2 is not None else None,
-                                   normw.data_ptr() if normw is not None else None, eps, pro, K, mods[0].K, len(mods), ain, st), "in")
+                                   normw.data_ptr() if normw is not None else None, eps, pro, K, mods[0].K, len(mods), ain, 0, None, st), "in")
     _lib.check(L.gq_qtip_linear_out(len(mods), aout, st), "out")
     torch.cuda.synchronize()
     return outs
@@ -216,6 +216,47 @@ def test_fused_linear_prologues_and_residual(oracle):
         assert torch.equal(_fused_linear(a, xs.reshape(-1).contiguous(), resid=resid)[0].view(torch.int16), want.view(torch.int16))
 
 
+def test_folded_transform_out_is_bit_identical():
+    """gq_qtip_linear_in with n_prev: the producer's transform-out (+ residual) rebuilt in the consumer's prologue ==
+    gq_qtip_linear_out followed by gq_qtip_linear_in; the stored vector equals what gq_qtip_linear_out writes"""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    K, R = 4096, 2
+    prod = [_rand_qlinear(2048, K, R, seed=21), _rand_qlinear(2048, K, R, seed=22)]  # two producers with M == K
+    cons = _rand_qlinear(K, 1024, R, seed=23)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    xin = torch.randn(2048, generator=g).half().to(d)
+    resid = torch.randn(K, generator=g).half().to(d)
+    normw = (1 + 0.2 * torch.randn(K, generator=g)).half().to(d)
+    st = _lib.current_stream_ptr()
+    su_p = [m.SU.float().contiguous() for m in prod]
+    sv_p = [(m.SV.float() * 32).contiguous() for m in prod]
+    y32 = [torch.zeros(K, dtype=torch.float32, device=d) for _ in prod]
+    pin = (_lib.GqQtipIn * 2)(*[_lib.GqQtipIn(m.trellis.data_ptr(), su_p[i].data_ptr(), m.tlut.data_ptr(), y32[i].data_ptr(), K)
+                                for i, m in enumerate(prod)])
+    _lib.check(L.gq_qtip_linear_in(xin.data_ptr(), None, None, 0.0, 0, 2048, R, 2, pin, 0, None, st), "producers")
+    su_c, sv_c = cons.SU.float().contiguous(), (cons.SV.float() * 32).contiguous()
+    for pro, nprev in ((0, 1), (1, 1), (2, 2)):
+        outs = [torch.zeros(K, dtype=torch.float16, device=d) for _ in prod]
+        rs = resid if pro != 2 else None
+        pout = (_lib.GqQtipOut * 2)(*[_lib.GqQtipOut(y32[i].data_ptr(), sv_p[i].data_ptr(), rs.data_ptr() if rs is not None else None,
+                                                     outs[i].data_ptr(), K) for i in range(2)])
+        _lib.check(L.gq_qtip_linear_out(nprev, pout, st), "out")
+        yc = [torch.zeros(1024, dtype=torch.float32, device=d) for _ in range(2)]
+        cin = [(_lib.GqQtipIn * 1)(_lib.GqQtipIn(cons.trellis.data_ptr(), su_c.data_ptr(), cons.tlut.data_ptr(), yc[j].data_ptr(), 1024))
+               for j in range(2)]
+        _lib.check(L.gq_qtip_linear_in(outs[0].data_ptr(), outs[1].data_ptr(), normw.data_ptr(), 1e-5, pro, K, R, 1, cin[0], 0, None, st), "two-launch")
+        stored = [torch.full((K,), float("nan"), dtype=torch.float16, device=d) for _ in prod]
+        pfold = (_lib.GqQtipOut * 2)(*[_lib.GqQtipOut(y32[i].data_ptr(), sv_p[i].data_ptr(), rs.data_ptr() if rs is not None else None,
+                                                      stored[i].data_ptr(), K) for i in range(2)])
+        _lib.check(L.gq_qtip_linear_in(None, None, normw.data_ptr(), 1e-5, pro, K, R, 1, cin[1], nprev, pfold, st), "folded")
+        torch.cuda.synchronize()
+        assert torch.equal(yc[0], yc[1]) and bool(torch.isfinite(yc[0]).all())
+        for i in range(nprev):
+            assert torch.equal(stored[i].view(torch.int16), outs[i].view(torch.int16))
+
+
 def test_fused_linear_validation():
     from guidedquant_amd import _lib
     L = _lib.lib()
@@ -223,16 +264,18 @@ def test_fused_linear_validation():
     x = torch.zeros(128, dtype=torch.float16, device="cuda:0")
     with pytest.raises(RuntimeError, match="power of two"):
         ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), lin.SU.float().data_ptr(), lin.tlut.data_ptr(), x.data_ptr(), 64))
-        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 0, 96, 2, 1, ain, None), "in")
+        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 0, 96, 2, 1, ain, 0, None, None), "in")
     with pytest.raises(RuntimeError, match="prologue operand"):
         ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), lin.SU.float().data_ptr(), lin.tlut.data_ptr(), x.data_ptr(), 64))
-        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 1, 128, 2, 1, ain, None), "in")
+        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 1, 128, 2, 1, ain, 0, None, None), "in")
 
 
-def test_qtip_native_decode_matches_module_forward():
-    """the 9-launch-per-layer native QTIP decode step (Transformer.decode_native) against the module-by-module forward of
-    the same model: logits agree to fp16 rounding noise, greedy tokens agree"""
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_qtip_native_decode_matches_module_forward(fold, monkeypatch):
+    """the native QTIP decode step (Transformer.decode_native; 6 launches per layer folded, 9 unfolded) against the
+    module-by-module forward of the same model: logits agree to fp16 rounding noise, greedy tokens agree"""
     import os
+    monkeypatch.setenv("GQ_NATIVE_QTIP_FOLD", fold)
     from guidedquant_amd import model as gm
     from guidedquant_amd.generate import load_model
     gm.transformer_configs["qtip-native-test"] = dict(model_name="llama-qtip-native-test", block_size=128, vocab_size=512, n_layer=3,

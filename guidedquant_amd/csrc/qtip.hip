@@ -42,8 +42,13 @@ __device__ __forceinline__ u32 unit_of<4>(const u32 (&d)[4], u32 j) { return d[j
 
 // one 32-row band M2 of the matvec: xs (fp16 [K]) and the codebook tl are in LDS (barrier done by the caller), part is
 // [waves][32] scratch; out[M2 * 32 .. + 31] is written by the first 32 threads
-template <int R>
-__device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uint16_t *xs, const u32 *tl, float *part, u32 M2, u32 K) {
+struct QtipNoop {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `between` runs behind the request of the first PF tile blocks (the caller's prologue: it does not depend on them)
+template <int R, class F = QtipNoop>
+__device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uint16_t *xs, const u32 *tl, float *part, u32 M2, u32 K,
+                                          F between = F()) {
     const u32 T = blockDim.x, tid = threadIdx.x, W = T >> 6, w = tid >> 6, l = tid & 63u;
     const u32 a4 = l >> 5, s = l & 31u;  // tile-row parity, stream unit
     const u32 a = s >> 2, b = s & 3u;
@@ -63,6 +68,7 @@ __device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uin
     };
 #pragma unroll
     for (u32 p = 0; p < PF; p++) fetch(p, w + p * W);
+    between();
     for (u32 K2b = w; K2b < nK2; K2b += W * PF) {
 #pragma unroll
         for (u32 p = 0; p < PF; p++) {
@@ -129,13 +135,56 @@ __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32
     qtip_band<R>(out, comp, xs, tl, part, blockIdx.x, K);
 }
 
-// in-place Sylvester butterflies on n floats in LDS (n a power of two, barrier behind the last pass).  Stages h = 1, 2, 4, ..
-// in this order with (a + b, a - b) at (j, j + h): the arithmetic of a plain radix-2 loop, but three stages at a time on 8
-// registers per work item (4 barriers for n = 4096 instead of 12).  Every user (gq_hadamard, the fused linear) shares it,
-// so hadamard -> matvec -> hadamard and the fused kernels agree bit for bit.
+// in-place Sylvester butterflies on n floats in LDS (n a power of two, barriers inside, one behind the last pass).
+// Stages h = 1, 2, 4, .. in this order with (a + b, a - b) at (j, j + h) -- the arithmetic of a plain radix-2 loop, so every
+// user (gq_hadamard, the fused linear) agrees bit for bit -- but scheduled for the LDS:
+//   stages h = 1, 2, 4   : 8 consecutive elements per thread in registers (two 16-byte LDS reads);
+//   stages h = 8, 16, 32 : partner elements sit in lanes t ^ 1, t ^ 2, t ^ 4: cross-lane moves, no memory;
+//   stages h >= 64       : three at a time on 8 registers per work item, element stride h0 >= 64: consecutive lanes touch
+//                          consecutive words (a stride of 8 words, as plain radix-8 passes have it at h0 = 1 and 8,
+//                          serialises 8 ways on the 64 banks: measured 7 us for n = 8192).
 __device__ __forceinline__ void fwht_lds(float *v, u32 n) {
     const u32 T = blockDim.x, tid = threadIdx.x;
     u32 h0 = 1;
+    if (n >= 64u) {
+        // n / 8 work items: whole waves, or the first n / 8 lanes of wave 0 (a set closed under t ^ 1, t ^ 2, t ^ 4)
+        for (u32 t = tid; t < n / 8u; t += T) {
+            float r[8];
+            const float4 lo4 = *reinterpret_cast<const float4 *>(v + 8u * t), hi4 = *reinterpret_cast<const float4 *>(v + 8u * t + 4u);
+            r[0] = lo4.x, r[1] = lo4.y, r[2] = lo4.z, r[3] = lo4.w, r[4] = hi4.x, r[5] = hi4.y, r[6] = hi4.z, r[7] = hi4.w;
+#pragma unroll
+            for (u32 st = 1; st < 8; st <<= 1)
+#pragma unroll
+                for (u32 k = 0; k < 8; k++)
+                    if (!(k & st)) {
+                        const float x0 = r[k], x1 = r[k | st];
+                        r[k] = x0 + x1;
+                        r[k | st] = x0 - x1;
+                    }
+#pragma unroll
+            for (u32 m = 1; m < 8; m <<= 1) {  // element stride 8 m: the partner thread is t ^ m (same wave: 8 | 64)
+                const bool upper = (t & m) != 0;
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) {
+                    // lane ^ 1, ^ 2: quad permutes; lane ^ 4 = half-row mirror (^ 7) of the quad reversal (^ 3): DPP moves on
+                    // the VALU instead of 24 ds_bpermute per thread through the LDS crossbar
+                    int o = __builtin_bit_cast(int, r[k]);
+                    if (m == 1u) o = __builtin_amdgcn_update_dpp(o, o, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
+                    else if (m == 2u) o = __builtin_amdgcn_update_dpp(o, o, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+                    else {
+                        o = __builtin_amdgcn_update_dpp(o, o, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+                        o = __builtin_amdgcn_update_dpp(o, o, 0x141, 0xF, 0xF, false);  // row_half_mirror
+                    }
+                    const float other = __builtin_bit_cast(float, o);
+                    r[k] = upper ? other - r[k] : r[k] + other;
+                }
+            }
+            *reinterpret_cast<float4 *>(v + 8u * t) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4 *>(v + 8u * t + 4u) = make_float4(r[4], r[5], r[6], r[7]);
+        }
+        h0 = 64u;
+        __syncthreads();
+    }
     while (h0 < n) {
         const u32 left = n / h0;  // 2^(stages left)
         if (left >= 8u) {
@@ -164,15 +213,14 @@ __device__ __forceinline__ void fwht_lds(float *v, u32 n) {
                 const u32 lo = t & (h0 - 1u), hi = t / h0;
                 float *b = v + hi * rad * h0 + lo;
                 float r[4];
-                for (u32 k = 0; k < rad; k++) r[k] = b[k * h0];
-                for (u32 st = 1; st < rad; st <<= 1)
-                    for (u32 k = 0; k < rad; k++)
-                        if (!(k & st)) {
-                            const float x0 = r[k], x1 = r[k | st];
-                            r[k] = x0 + x1;
-                            r[k | st] = x0 - x1;
-                        }
-                for (u32 k = 0; k < rad; k++) b[k * h0] = r[k];
+                r[0] = b[0], r[1] = b[h0];
+                if (rad == 4u) {
+                    r[2] = b[2u * h0], r[3] = b[3u * h0];
+                    const float s0 = r[0] + r[1], d0 = r[0] - r[1], s1 = r[2] + r[3], d1 = r[2] - r[3];
+                    b[0] = s0 + s1, b[h0] = d0 + d1, b[2u * h0] = s0 - s1, b[3u * h0] = d0 - d1;
+                } else {
+                    b[0] = r[0] + r[1], b[h0] = r[0] - r[1];
+                }
             }
             h0 *= rad;
         }
@@ -224,7 +272,8 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     if (a.n > 1 && blockIdx.x >= a.lin[1].band0) li = 1;
     if (a.n > 2 && blockIdx.x >= a.lin[2].band0) li = 2;
     const QtipIn L = a.lin[li];
-    for (u32 i = tid; i < 512u; i += T) tl[i] = reinterpret_cast<const u32 *>(L.tlut)[i];
+    // codebook words of this thread (T >= 256): requested now, stored to LDS in the prologue
+    const u32 tl0 = reinterpret_cast<const u32 *>(L.tlut)[tid & 511u], tl1 = reinterpret_cast<const u32 *>(L.tlut)[(tid + 256u) & 511u];
     // Folded transform-out of the producing linear(s): what gq_qtip_linear_out would have written is rebuilt in LDS by
     // every block (same arithmetic, same order) and stored once, by block 0, for the kernels that need it later
     // (the residual stream).  One launch and one global round trip less per linear.
@@ -247,39 +296,79 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         xg = xp;
         x2g = xp + K;
     }
-    float nscale = 0.f;
-    if constexpr (PRO == QPRO_RMSNORM) {
-        float ss = 0.f;
-        for (u32 i = tid; i < K; i += T) {
-            const float f = (float)__builtin_bit_cast(h16, xg[i]);
-            ss += f * f;
+    // The input vectors are requested first (registers), the first tile blocks of the band behind them, and the prologue
+    // runs while those are on their way from HBM (vector memory returns in order: requested the other way round, the
+    // first use of x would wait for the tiles).
+    constexpr u32 NX = 8;
+    const bool inreg = !a.nprev && K <= NX * T;
+    uint16_t xr[NX], x2r[NX], nwr[NX];
+    float sur[NX];
+    if (inreg) {
+#pragma unroll
+        for (u32 k = 0; k < NX; k++) {
+            const u32 i = tid + k * T;
+            const bool ok = i < K;
+            xr[k] = ok ? xg[i] : (uint16_t)0;
+            sur[k] = ok ? L.SU[i] : 0.f;
+            if constexpr (PRO == QPRO_RMSNORM) nwr[k] = ok ? a.normw[i] : (uint16_t)0;
+            if constexpr (PRO == QPRO_SILUMUL) x2r[k] = ok ? x2g[i] : (uint16_t)0;
         }
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-        if ((tid & 63u) == 0) redf[tid >> 6] = ss;
-        __syncthreads();
-        if (tid == 0) {
-            float t = 0.f;
-            for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
-            redf[16] = 1.0f / sqrtf(t / (float)K + a.eps);
-        }
-        __syncthreads();
-        nscale = redf[16];
     }
-    for (u32 i = tid; i < K; i += T) {
-        h16 xh = __builtin_bit_cast(h16, xg[i]);
-        if constexpr (PRO == QPRO_RMSNORM) xh = (h16)gq_pin_f32((float)xh * nscale) * __builtin_bit_cast(h16, a.normw[i]);
-        if constexpr (PRO == QPRO_SILUMUL) {
-            const float g = (float)xh;
-            xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, x2g[i]);
+    auto prologue = [&]() {
+        if (tid < 512u) tl[tid] = tl0;
+        if (T == 256u) tl[tid + 256u] = tl1;
+        float nscale = 0.f;
+        if constexpr (PRO == QPRO_RMSNORM) {
+            float ss = 0.f;
+            if (inreg) {
+#pragma unroll
+                for (u32 k = 0; k < NX; k++) {  // (elements beyond K are zero)
+                    const float f = (float)__builtin_bit_cast(h16, xr[k]);
+                    ss += f * f;
+                }
+            } else {
+                for (u32 i = tid; i < K; i += T) {
+                    const float f = (float)__builtin_bit_cast(h16, xg[i]);
+                    ss += f * f;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            if ((tid & 63u) == 0) redf[tid >> 6] = ss;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
+                redf[16] = 1.0f / sqrtf(t / (float)K + a.eps);
+            }
+            __syncthreads();
+            nscale = redf[16];
         }
-        v[i] = (float)xh * L.SU[i];
-    }
-    __syncthreads();
-    fwht_lds(v, K);
-    const float sc = a.kscale;
-    for (u32 i = tid; i < K; i += T) xs[i] = __builtin_bit_cast(uint16_t, (h16)((v[i] * sc) / 32.0f));
-    __syncthreads();
-    qtip_band<R>(L.y32, L.comp, xs, tl, part, blockIdx.x - L.band0, K);
+        auto elem = [&](uint16_t xb, uint16_t x2b, uint16_t nwb, float su) {
+            h16 xh = __builtin_bit_cast(h16, xb);
+            if constexpr (PRO == QPRO_RMSNORM) xh = (h16)gq_pin_f32((float)xh * nscale) * __builtin_bit_cast(h16, nwb);
+            if constexpr (PRO == QPRO_SILUMUL) {
+                const float g = (float)xh;
+                xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, x2b);
+            }
+            return (float)xh * su;
+        };
+        if (inreg) {
+#pragma unroll
+            for (u32 k = 0; k < NX; k++) {
+                const u32 i = tid + k * T;
+                if (i < K) v[i] = elem(xr[k], PRO == QPRO_SILUMUL ? x2r[k] : (uint16_t)0, PRO == QPRO_RMSNORM ? nwr[k] : (uint16_t)0, sur[k]);
+            }
+        } else {
+            for (u32 i = tid; i < K; i += T)
+                v[i] = elem(xg[i], PRO == QPRO_SILUMUL ? x2g[i] : (uint16_t)0, PRO == QPRO_RMSNORM ? a.normw[i] : (uint16_t)0, L.SU[i]);
+        }
+        __syncthreads();
+        fwht_lds(v, K);
+        const float sc = a.kscale;
+        for (u32 i = tid; i < K; i += T) xs[i] = __builtin_bit_cast(uint16_t, (h16)((v[i] * sc) / 32.0f));
+        __syncthreads();
+    };
+    qtip_band<R>(L.y32, L.comp, xs, tl, part, blockIdx.x - L.band0, K, prologue);
 }
 
 struct QtipOutArgs {

@@ -511,6 +511,7 @@ int launch_generic(const ApArgs &a, u32 M, hipStream_t s) {
 
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
                       int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream);
+bool gq_plane_local_shape(uint32_t N, uint32_t K, int bits);
 
 namespace {
 
@@ -534,8 +535,10 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     // (w1w3, w2); everything else runs the exact kernels, whose results are bit-identical to the reference.
     // GQ_PL_MIN_MWEIGHTS overrides the threshold for every bit width, GQ_PL_MAX_BITS the widest plane-served width.
     const int env_min = gq_env_int("GQ_PL_MIN_MWEIGHTS", -1);
-    // (without the RMSNorm prologue the 2- and 3-bit kernels need no block-wide activation pass: >= 16 M weights, wo)
-    const int def_min = bits == 2 ? (pro == PRO_RMSNORM ? 20 : 16) : (bits == 3 && pro != PRO_RMSNORM ? 16 : 32);
+    // (matrices of <= 16 rows per CU without the RMSNorm prologue run the local-image variant, which needs no block-wide
+    // activation pass: >= 16 M weights at 2 and 3 bits -- wo)
+    const bool local = pro != PRO_RMSNORM && bits <= 3 && gq_plane_local_shape(a.N, a.K, bits);
+    const int def_min = local ? 16 : (bits == 2 ? 20 : 32);
     const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : def_min) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {

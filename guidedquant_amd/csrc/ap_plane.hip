@@ -1114,6 +1114,12 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
 }
 }  // namespace
 
+// true when the local-image variant would serve this shape (<= 16 rows per CU, 2/3-bit): the dispatcher's threshold differs
+bool gq_plane_local_shape(uint32_t N, uint32_t K, int bits) {
+    PlaneCfg c;
+    return bits >= 2 && K <= 16384u && gq_env_int("GQ_PL_LOCAL", 1) && pick_local_cfg(N, K, bits, c);
+}
+
 // returns GQ_ENOTSUP when the shape is not served by this path (caller falls back to the exact kernels)
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
                       int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {

@@ -143,10 +143,13 @@ __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32
 //   stages h >= 64       : three at a time on 8 registers per work item, element stride h0 >= 64: consecutive lanes touch
 //                          consecutive words (a stride of 8 words, as plain radix-8 passes have it at h0 = 1 and 8,
 //                          serialises 8 ways on the 64 banks: measured 7 us for n = 8192).
-__device__ __forceinline__ void fwht_lds(float *v, u32 n) {
+// P: transform length; the n floats are n / P independent consecutive segments (P = n: one transform)
+__device__ __forceinline__ void fwht_lds(float *v, u32 n, u32 P);
+__device__ __forceinline__ void fwht_lds(float *v, u32 n) { fwht_lds(v, n, n); }
+__device__ __forceinline__ void fwht_lds(float *v, u32 n, u32 P) {
     const u32 T = blockDim.x, tid = threadIdx.x;
     u32 h0 = 1;
-    if (n >= 64u) {
+    if (P >= 64u) {
         // n / 8 work items: whole waves, or the first n / 8 lanes of wave 0 (a set closed under t ^ 1, t ^ 2, t ^ 4)
         for (u32 t = tid; t < n / 8u; t += T) {
             float r[8];
@@ -185,8 +188,8 @@ __device__ __forceinline__ void fwht_lds(float *v, u32 n) {
         h0 = 64u;
         __syncthreads();
     }
-    while (h0 < n) {
-        const u32 left = n / h0;  // 2^(stages left)
+    while (h0 < P) {
+        const u32 left = P / h0;  // 2^(stages left)
         if (left >= 8u) {
             for (u32 t = tid; t < n / 8u; t += T) {
                 const u32 lo = t & (h0 - 1u), hi = t / h0;
@@ -415,6 +418,81 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ transform with a Hadamard factor
+// Widths n = Kf * P with a non-power-of-two Hadamard factor Kf (matmul_had.py:13-67; Llama-2's 11008 = 172 * 64): the
+// transform is the P-point Sylvester transform of every row of the [Kf][P] view followed by hadK @ (or hadK^T @) over
+// the rows (matmul_hadU / matmul_hadUt, matmul_had.py:69-94).  The Kf x Kf product is too much work to repeat in every
+// band block of the matvec, so these widths run transform -> gq_qtip_matvec -> transform: this kernel is either side.
+// Block b owns RB rows of the result; every block loads the vector and does the (cheap) row transforms itself.
+//   IN : v = pro(x) * SU            -> rows, hadK^T -> out16 = half(val * n^-1/2 / 32)          (input of the matvec)
+//   OUT: v = y32                    -> rows, hadK   -> out16 = half(val * n^-1/2 * SV32) (+ resid)
+struct QtipXfArgs {
+    const uint16_t *x, *x2, *normw, *resid;
+    const float *y32, *vec, *hadK;  // vec = SU (IN) or SV * 32 (OUT); hadK fp32 [Kf][Kf]
+    uint16_t *out;
+    float eps, nscale;  // nscale = (float)n^-1/2
+    u32 n, Kf, P, RB, in, pro, transpose;
+};
+__global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
+    __shared__ float redf[17];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *v = reinterpret_cast<float *>(smem);
+    const u32 n = a.n, T = blockDim.x, tid = threadIdx.x;
+    if (a.in) {
+        float rs = 0.f;
+        if (a.pro == QPRO_RMSNORM) {
+            float ss = 0.f;
+            for (u32 i = tid; i < n; i += T) {
+                const float f = (float)__builtin_bit_cast(h16, a.x[i]);
+                ss += f * f;
+            }
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            if ((tid & 63u) == 0) redf[tid >> 6] = ss;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
+                redf[16] = 1.0f / sqrtf(t / (float)n + a.eps);
+            }
+            __syncthreads();
+            rs = redf[16];
+        }
+        for (u32 i = tid; i < n; i += T) {
+            h16 xh = __builtin_bit_cast(h16, a.x[i]);
+            if (a.pro == QPRO_RMSNORM) xh = (h16)gq_pin_f32((float)xh * rs) * __builtin_bit_cast(h16, a.normw[i]);
+            if (a.pro == QPRO_SILUMUL) {
+                const float g = (float)xh;
+                xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, a.x2[i]);
+            }
+            v[i] = (float)xh * a.vec[i];
+        }
+    } else {
+        for (u32 i = tid; i < n; i += T) v[i] = a.y32[i];
+    }
+    __syncthreads();
+    fwht_lds(v, n, a.P);  // every row of the [Kf][P] view
+    // hadamard() scales by n^-1/2 before the factor product (matmul_had.py:88-90): same rounding points here
+    for (u32 i = tid; i < n; i += T) v[i] = v[i] * a.nscale;
+    __syncthreads();
+    const u32 P = a.P, Kf = a.Kf, r0 = blockIdx.x * a.RB;
+    for (u32 o = tid; o < a.RB * P; o += T) {
+        const u32 kr = r0 + o / P, p = o % P;
+        if (kr >= Kf) continue;
+        float acc = 0.f;
+        const float *hrow = a.transpose ? a.hadK + kr : a.hadK + (size_t)kr * Kf;
+        const u32 hs = a.transpose ? Kf : 1u;
+        for (u32 k = 0; k < Kf; k++) acc += hrow[(size_t)k * hs] * v[k * P + p];
+        const u32 i = kr * P + p;
+        h16 y;
+        if (a.in) y = (h16)(acc / 32.0f);
+        else {
+            y = (h16)gq_pin_f32(acc * a.vec[i]);
+            if (a.resid) y = __builtin_bit_cast(h16, a.resid[i]) + y;
+        }
+        a.out[i] = __builtin_bit_cast(uint16_t, y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Hadamard (FWHT)
 __global__ void __launch_bounds__(1024) fwht_kernel(const float *x, float *y, u32 n, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -551,6 +629,45 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
         set = true;
     }
     hipLaunchKernelGGL(qtip_linear_out_kernel, dim3((u32)n), dim3(1024), smem, (hipStream_t)stream, a);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, const void *norm_weight, float eps, int prologue,
+                                 const float *y32, const float *vec, const void *resid, void *out, uint32_t n, const float *hadK,
+                                 uint32_t Kf, int transpose, void *stream) {
+    if (!vec || !out || !hadK || Kf < 2u || n == 0 || n % Kf) return gq_fail(GQ_EINVAL, "gq_qtip_transform: vec, out, hadK; n a multiple of Kf.");
+    const u32 P = n / Kf;
+    if (!pow2(P) || P < 64u || n > 32768u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n / Kf must be a power of two >= 64, n <= 32768.");
+    if (input_side ? (!x || (prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2) || prologue < 0 || prologue > 2)
+                   : !y32)
+        return gq_fail(GQ_EINVAL, "gq_qtip_transform: source operand missing.");
+    QtipXfArgs a{};
+    a.x = (const uint16_t *)x;
+    a.x2 = (const uint16_t *)x2;
+    a.normw = (const uint16_t *)norm_weight;
+    a.resid = (const uint16_t *)resid;
+    a.y32 = y32;
+    a.vec = vec;
+    a.hadK = hadK;
+    a.out = (uint16_t *)out;
+    a.eps = eps;
+    a.nscale = (float)pow((double)n, -0.5);
+    a.n = n;
+    a.Kf = Kf;
+    a.P = P;
+    a.RB = P >= 512u ? 1u : (P >= 128u ? 2u : 4u);  // >= 256 results per block
+    a.in = input_side ? 1u : 0u;
+    a.pro = input_side ? (u32)prologue : 0u;
+    a.transpose = transpose ? 1u : 0u;
+    const size_t smem = (size_t)n * 4u;
+    static bool set = false;
+    if (!set) {
+        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_transform_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         156 * 1024));
+        set = true;
+    }
+    hipLaunchKernelGGL(qtip_transform_kernel, dim3((Kf + a.RB - 1u) / a.RB), dim3(1024), smem, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

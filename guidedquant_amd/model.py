@@ -298,14 +298,20 @@ class Transformer(nn.Module):
         elif os.environ.get("GQ_NATIVE_QTIP", "1") != "0":
             from .qtip import QuantizedLinear
 
-            def ok(m):
-                p2 = lambda n: n > 0 and (n & (n - 1)) == 0  # noqa: E731
-                return (isinstance(m, QuantizedLinear) and m.bias is None and m.has_kernel and m.K_left == 1 and m.K_right == 1
-                        and int(m.rcp.item()) == 0 and p2(m.in_features) and p2(m.out_features) and 32 <= m.in_features <= 16384
-                        and m.out_features <= 32768)
-            if self.config.head_dim in (64, 128) and all(
-                    ok(m) for b in self.layers for m in (b.attention.wq, b.attention.wk, b.attention.wv, b.attention.wo,
-                                                         b.feed_forward.w1, b.feed_forward.w3, b.feed_forward.w2)):
+            p2 = lambda n: n > 0 and (n & (n - 1)) == 0  # noqa: E731
+
+            def ok(m, factor_in=False, factor_out=False):
+                # model widths: power of two (fused transform), or -- the MLP width only -- Kf * 2^p with the caller's
+                # Hadamard factor table loaded (gq_qtip_transform; e.g. 11008 = 172 * 64)
+                def side(nf, K, had, allow):
+                    return p2(nf) if K == 1 else (allow and had is not None and p2(nf // K) and nf // K >= 64 and nf <= 32768)
+                return (isinstance(m, QuantizedLinear) and m.bias is None and m.has_kernel and int(m.rcp.item()) == 0
+                        and side(m.in_features, m.K_left, m.had_left, factor_in) and side(m.out_features, m.K_right, m.had_right, factor_out)
+                        and 32 <= m.in_features and (m.in_features <= 16384 or m.K_left != 1) and m.out_features <= 32768)
+            if self.config.head_dim in (64, 128) and p2(self.config.dim) and all(
+                    all(ok(m) for m in (b.attention.wq, b.attention.wk, b.attention.wv, b.attention.wo))
+                    and ok(b.feed_forward.w1, factor_out=True) and ok(b.feed_forward.w3, factor_out=True)
+                    and ok(b.feed_forward.w2, factor_in=True) for b in self.layers):
                 kind = "qtip"
         self._native_kind_cache = kind
         return kind or None
@@ -343,10 +349,11 @@ class Transformer(nn.Module):
         st["u"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
         mmax = max(c.dim, c.intermediate_size)
         st["y32"] = torch.zeros(3, mmax, dtype=torch.float32, device=dev)
+        st["xs16"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)  # transformed input of the down projection
         keep = []  # fp32 copies the descriptors point into
 
         def f32(t, mul=1.0):
-            t = (t.detach().float() * mul).contiguous()
+            t = (t.detach().to(dev).float() * mul).contiguous()
             keep.append(t)
             return t.data_ptr()
 
@@ -367,7 +374,12 @@ class Transformer(nn.Module):
         layers = []
         for b in self.layers:
             at, ff = b.attention, b.feed_forward
+            factor = None
+            if ff.w2.K_left != 1:  # MLP width with a Hadamard factor: transform kernels on that side (gq_qtip_transform)
+                factor = dict(Kf=ff.w2.K_left, had=f32(ff.w2.had_left), su_d=f32(ff.w2.SU), sv_g=f32(ff.w1.SV, 32.0), sv_u=f32(ff.w3.SV, 32.0),
+                              had_g=f32(ff.w1.had_right), had_u=f32(ff.w3.had_right))
             layers.append(dict(
+                factor=factor,
                 qkv_in=lin_in([at.wq, at.wk, at.wv]),
                 qkv_out=lin_out([at.wq, at.wk, at.wv], [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e], None),
                 o_in=lin_in([at.wo]), o_out=lin_out([at.wo], [h.data_ptr()], x.data_ptr()),
@@ -392,7 +404,7 @@ class Transformer(nn.Module):
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2
         # transform-out folded into the consuming kernel: bit-identical, 3 launches per layer fewer, but every block repeats
         # the producer's transform -- measured slower (222 vs 243 tokens/s on the 7B-like model), so off by default
-        fold = os.environ.get("GQ_NATIVE_QTIP_FOLD", "0") != "0"
+        fold = os.environ.get("GQ_NATIVE_QTIP_FOLD", "0") != "0" and all(d["factor"] is None for d in b["qtip_layers"])
         for li in range(l0, l1):
             blk, d = self.layers[li], b["qtip_layers"][li]
             at = blk.attention
@@ -408,6 +420,21 @@ class Transformer(nn.Module):
                 ck(L.gq_qtip_linear_out(1, d["o_out"], sp), "qtip o out")
             ck(L.gq_qtip_linear_in(h.data_ptr(), None, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 2,
                                    d["gu_in"], 1 if fold else 0, d["o_out"] if fold else None, sp), "qtip gate/up in")
+            fa = d["factor"]
+            if fa is not None:
+                # MLP width = Kf * 2^p: gate/up outputs and the down input go through the factor transform kernels
+                ff = blk.feed_forward
+                y32 = b["y32"]
+                ck(L.gq_qtip_transform(0, None, None, None, 0.0, 0, y32[0].data_ptr(), fa["sv_g"], None, g.data_ptr(),
+                                       c.intermediate_size, fa["had_g"], fa["Kf"], 0, sp), "qtip gate out")
+                ck(L.gq_qtip_transform(0, None, None, None, 0.0, 0, y32[1].data_ptr(), fa["sv_u"], None, u.data_ptr(),
+                                       c.intermediate_size, fa["had_u"], fa["Kf"], 0, sp), "qtip up out")
+                ck(L.gq_qtip_transform(1, g.data_ptr(), u.data_ptr(), None, 0.0, 2, None, fa["su_d"], None, b["xs16"].data_ptr(),
+                                       c.intermediate_size, fa["had"], fa["Kf"], 1, sp), "qtip down in")
+                ck(L.gq_qtip_matvec(y32[0].data_ptr(), ff.w2.trellis.data_ptr(), b["xs16"].data_ptr(), ff.w2.tlut.data_ptr(), c.dim,
+                                    c.intermediate_size, d["R"], sp), "qtip down matvec")
+                ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
+                continue
             if not fold:
                 ck(L.gq_qtip_linear_out(2, d["gu_out"], sp), "qtip gate/up out")
             ck(L.gq_qtip_linear_in(g.data_ptr(), u.data_ptr(), None, 0.0, 2, c.intermediate_size, d["R"], 1, d["d_in"],

@@ -145,6 +145,19 @@ int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, fl
 int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
 
 /*
+ * Either side of a QTIP linear whose width n = Kf * P carries a non-power-of-two Hadamard factor (inference/lib/utils/
+ * matmul_had.py:13-94; Llama-2's MLP width 11008 = 172 * 64): P-point Sylvester transform of every row of the [Kf][P]
+ * view, then hadK @ rows (transpose != 0: hadK^T @, matmul_hadUt).  Such a linear runs transform -> gq_qtip_matvec ->
+ * transform (the Kf x Kf product is too much to repeat in every block of the fused kernel).
+ *   input_side != 0:  out fp16 [n] = half(H(pro(x) * vec) * n^-1/2 / 32),  vec = SU f32 [n], pro as GQ_QPRO_* (x2 / norm_weight)
+ *   input_side == 0:  out fp16 [n] = half(H(y32) * n^-1/2 * vec) (+ resid),  vec = SV * 32 f32 [n]
+ * hadK f32 [Kf][Kf] is the caller's table (the reference's data, not shipped here); P a power of two >= 64.
+ */
+int gq_qtip_transform(int input_side, const void *x, const void *x2, const void *norm_weight, float eps, int prologue,
+                      const float *y32, const float *vec, const void *resid, void *out, uint32_t n, const float *hadK,
+                      uint32_t Kf, int transpose, void *stream);
+
+/*
  * Fused decode-step variant of the AP GEMV, M = 1: optional prologue on x
  * (RMSNorm, or SiLU(gate)*up of a fused gate/up vector) and optional residual-add epilogue, with the same
  * fp16 rounding points as the reference's separate kernels (inference/model.py:151-166,259-266,281-292).

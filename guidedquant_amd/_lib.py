@@ -24,6 +24,11 @@ class GqQtipIn(ctypes.Structure):  # include/gq_hip.h
                 ("M", ctypes.c_uint32)]
 
 
+class GqQtipXf(ctypes.Structure):
+    _fields_ = [("y32", ctypes.c_void_p), ("vec", ctypes.c_void_p), ("hadK", ctypes.c_void_p), ("resid", ctypes.c_void_p),
+                ("out", ctypes.c_void_p)]
+
+
 class GqQtipOut(ctypes.Structure):
     _fields_ = [("y32", ctypes.c_void_p), ("SV32", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("M", ctypes.c_uint32)]
@@ -57,7 +62,7 @@ def lib():
         L.gq_hadamard.argtypes = [vp, vp, u32, u32, f32, vp]
         L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, ctypes.POINTER(GqQtipOut), vp]
         L.gq_qtip_linear_out.argtypes = [i32, ctypes.POINTER(GqQtipOut), vp]
-        L.gq_qtip_transform.argtypes = [i32, vp, vp, vp, f32, i32, vp, vp, vp, vp, u32, vp, u32, i32, vp]
+        L.gq_qtip_transform.argtypes = [i32, vp, vp, vp, f32, i32, i32, ctypes.POINTER(GqQtipXf), u32, u32, i32, vp]
         L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]
         L.gq_set_ap_mode.argtypes = [i32]
         L.gq_embed_lookup.argtypes = [vp, vp, vp, u32, u32, vp]

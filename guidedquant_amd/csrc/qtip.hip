@@ -426,18 +426,31 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
 // Block b owns RB rows of the result; every block loads the vector and does the (cheap) row transforms itself.
 //   IN : v = pro(x) * SU            -> rows, hadK^T -> out16 = half(val * n^-1/2 / 32)          (input of the matvec)
 //   OUT: v = y32                    -> rows, hadK   -> out16 = half(val * n^-1/2 * SV32) (+ resid)
-struct QtipXfArgs {
-    const uint16_t *x, *x2, *normw, *resid;
+struct QtipXfLin {
     const float *y32, *vec, *hadK;  // vec = SU (IN) or SV * 32 (OUT); hadK fp32 [Kf][Kf]
+    const uint16_t *resid;
     uint16_t *out;
+};
+struct QtipXfArgs {
+    const uint16_t *x, *x2, *normw;
+    QtipXfLin lin[2];   // blockIdx.y (OUT: gate and up in one launch)
     float eps, nscale;  // nscale = (float)n^-1/2
     u32 n, Kf, P, RB, in, pro, transpose;
 };
 __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
     __shared__ float redf[17];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *v = reinterpret_cast<float *>(smem);
     const u32 n = a.n, T = blockDim.x, tid = threadIdx.x;
+    const u32 P = a.P, Kf = a.Kf, RB = a.RB, r0 = blockIdx.x * RB;
+    float *v = reinterpret_cast<float *>(smem);  // [n]
+    float *hs = v + n;                           // [RB][Kf] rows (or columns) of the factor this block multiplies with
+    float *ps = hs + RB * Kf;                    // [KQ][RB * P] partial sums of the factor product
+    const QtipXfLin L = a.lin[blockIdx.y];
+    // this block's rows of hadK (columns for the transposed product), requested first
+    for (u32 e = tid; e < RB * Kf; e += T) {
+        const u32 rr = e / Kf, k = e % Kf, kr = r0 + rr;
+        hs[e] = kr < Kf ? (a.transpose ? L.hadK[(size_t)k * Kf + kr] : L.hadK[(size_t)kr * Kf + k]) : 0.f;
+    }
     if (a.in) {
         float rs = 0.f;
         if (a.pro == QPRO_RMSNORM) {
@@ -464,32 +477,43 @@ __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
                 const float g = (float)xh;
                 xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, a.x2[i]);
             }
-            v[i] = (float)xh * a.vec[i];
+            v[i] = (float)xh * L.vec[i];
         }
     } else {
-        for (u32 i = tid; i < n; i += T) v[i] = a.y32[i];
+        for (u32 i = tid; i < n; i += T) v[i] = L.y32[i];
     }
     __syncthreads();
-    fwht_lds(v, n, a.P);  // every row of the [Kf][P] view
+    fwht_lds(v, n, P);  // every row of the [Kf][P] view
     // hadamard() scales by n^-1/2 before the factor product (matmul_had.py:88-90): same rounding points here
     for (u32 i = tid; i < n; i += T) v[i] = v[i] * a.nscale;
     __syncthreads();
-    const u32 P = a.P, Kf = a.Kf, r0 = blockIdx.x * a.RB;
-    for (u32 o = tid; o < a.RB * P; o += T) {
+    // factor product: the RB * P results of the block, the sum over k split over KQ thread groups (fixed order)
+    const u32 NO = RB * P, KQ = NO >= T ? 1u : T / NO, kper = (Kf + KQ - 1u) / KQ;
+    for (u32 ob = 0; ob < NO; ob += T) {
+        const u32 o = ob + tid % (NO < T ? NO : T), kq = NO < T ? tid / NO : 0u;
+        if (o < NO && kq < KQ) {
+            const u32 rr = o / P, p = o % P;
+            const float *hrow = hs + rr * Kf;
+            float acc = 0.f;
+            const u32 k1 = min((kq + 1u) * kper, Kf);
+            for (u32 k = kq * kper; k < k1; k++) acc += hrow[k] * v[k * P + p];
+            ps[kq * NO + o] = acc;
+        }
+    }
+    __syncthreads();
+    for (u32 o = tid; o < NO; o += T) {
         const u32 kr = r0 + o / P, p = o % P;
         if (kr >= Kf) continue;
         float acc = 0.f;
-        const float *hrow = a.transpose ? a.hadK + kr : a.hadK + (size_t)kr * Kf;
-        const u32 hs = a.transpose ? Kf : 1u;
-        for (u32 k = 0; k < Kf; k++) acc += hrow[(size_t)k * hs] * v[k * P + p];
+        for (u32 q = 0; q < KQ; q++) acc += ps[q * NO + o];
         const u32 i = kr * P + p;
         h16 y;
         if (a.in) y = (h16)(acc / 32.0f);
         else {
-            y = (h16)gq_pin_f32(acc * a.vec[i]);
-            if (a.resid) y = __builtin_bit_cast(h16, a.resid[i]) + y;
+            y = (h16)gq_pin_f32(acc * L.vec[i]);
+            if (L.resid) y = __builtin_bit_cast(h16, L.resid[i]) + y;
         }
-        a.out[i] = __builtin_bit_cast(uint16_t, y);
+        L.out[i] = __builtin_bit_cast(uint16_t, y);
     }
 }
 
@@ -634,23 +658,21 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
 }
 
 extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, const void *norm_weight, float eps, int prologue,
-                                 const float *y32, const float *vec, const void *resid, void *out, uint32_t n, const float *hadK,
-                                 uint32_t Kf, int transpose, void *stream) {
-    if (!vec || !out || !hadK || Kf < 2u || n == 0 || n % Kf) return gq_fail(GQ_EINVAL, "gq_qtip_transform: vec, out, hadK; n a multiple of Kf.");
+                                 int n_lin, const GqQtipXf *lin, uint32_t n, uint32_t Kf, int transpose, void *stream) {
+    if (!lin || n_lin < 1 || n_lin > 2 || Kf < 2u || n == 0 || n % Kf) return gq_fail(GQ_EINVAL, "gq_qtip_transform: 1..2 linears; n a multiple of Kf.");
+    if (input_side && n_lin != 1) return gq_fail(GQ_EINVAL, "gq_qtip_transform: one linear on the input side.");
     const u32 P = n / Kf;
     if (!pow2(P) || P < 64u || n > 32768u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n / Kf must be a power of two >= 64, n <= 32768.");
-    if (input_side ? (!x || (prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2) || prologue < 0 || prologue > 2)
-                   : !y32)
+    if (input_side && (!x || (prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2) || prologue < 0 || prologue > 2))
         return gq_fail(GQ_EINVAL, "gq_qtip_transform: source operand missing.");
     QtipXfArgs a{};
     a.x = (const uint16_t *)x;
     a.x2 = (const uint16_t *)x2;
     a.normw = (const uint16_t *)norm_weight;
-    a.resid = (const uint16_t *)resid;
-    a.y32 = y32;
-    a.vec = vec;
-    a.hadK = hadK;
-    a.out = (uint16_t *)out;
+    for (int i = 0; i < n_lin; i++) {
+        if (!lin[i].vec || !lin[i].out || !lin[i].hadK || (!input_side && !lin[i].y32)) return gq_fail(GQ_EINVAL, "gq_qtip_transform: null pointer argument.");
+        a.lin[i] = QtipXfLin{lin[i].y32, lin[i].vec, lin[i].hadK, (const uint16_t *)lin[i].resid, (uint16_t *)lin[i].out};
+    }
     a.eps = eps;
     a.nscale = (float)pow((double)n, -0.5);
     a.n = n;
@@ -660,14 +682,16 @@ extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, 
     a.in = input_side ? 1u : 0u;
     a.pro = input_side ? (u32)prologue : 0u;
     a.transpose = transpose ? 1u : 0u;
-    const size_t smem = (size_t)n * 4u;
+    const u32 NO = a.RB * P, KQ = NO >= 1024u ? 1u : 1024u / NO;
+    const size_t smem = ((size_t)n + (size_t)a.RB * Kf + (size_t)KQ * NO) * 4u;
+    if (smem > 150u * 1024u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n too large.");
     static bool set = false;
     if (!set) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_transform_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          156 * 1024));
         set = true;
     }
-    hipLaunchKernelGGL(qtip_transform_kernel, dim3((Kf + a.RB - 1u) / a.RB), dim3(1024), smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(qtip_transform_kernel, dim3((Kf + a.RB - 1u) / a.RB, (u32)n_lin), dim3(1024), smem, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

@@ -376,8 +376,11 @@ class Transformer(nn.Module):
             at, ff = b.attention, b.feed_forward
             factor = None
             if ff.w2.K_left != 1:  # MLP width with a Hadamard factor: transform kernels on that side (gq_qtip_transform)
-                factor = dict(Kf=ff.w2.K_left, had=f32(ff.w2.had_left), su_d=f32(ff.w2.SU), sv_g=f32(ff.w1.SV, 32.0), sv_u=f32(ff.w3.SV, 32.0),
-                              had_g=f32(ff.w1.had_right), had_u=f32(ff.w3.had_right))
+                y32 = st["y32"]
+                factor = dict(Kf=ff.w2.K_left,
+                              gu=(_lib.GqQtipXf * 2)(_lib.GqQtipXf(y32[0].data_ptr(), f32(ff.w1.SV, 32.0), f32(ff.w1.had_right), None, st["g"].data_ptr()),
+                                                      _lib.GqQtipXf(y32[1].data_ptr(), f32(ff.w3.SV, 32.0), f32(ff.w3.had_right), None, st["u"].data_ptr())),
+                              d=(_lib.GqQtipXf * 1)(_lib.GqQtipXf(None, f32(ff.w2.SU), f32(ff.w2.had_left), None, st["xs16"].data_ptr())))
             layers.append(dict(
                 factor=factor,
                 qkv_in=lin_in([at.wq, at.wk, at.wv]),
@@ -425,12 +428,8 @@ class Transformer(nn.Module):
                 # MLP width = Kf * 2^p: gate/up outputs and the down input go through the factor transform kernels
                 ff = blk.feed_forward
                 y32 = b["y32"]
-                ck(L.gq_qtip_transform(0, None, None, None, 0.0, 0, y32[0].data_ptr(), fa["sv_g"], None, g.data_ptr(),
-                                       c.intermediate_size, fa["had_g"], fa["Kf"], 0, sp), "qtip gate out")
-                ck(L.gq_qtip_transform(0, None, None, None, 0.0, 0, y32[1].data_ptr(), fa["sv_u"], None, u.data_ptr(),
-                                       c.intermediate_size, fa["had_u"], fa["Kf"], 0, sp), "qtip up out")
-                ck(L.gq_qtip_transform(1, g.data_ptr(), u.data_ptr(), None, 0.0, 2, None, fa["su_d"], None, b["xs16"].data_ptr(),
-                                       c.intermediate_size, fa["had"], fa["Kf"], 1, sp), "qtip down in")
+                ck(L.gq_qtip_transform(0, None, None, None, 0.0, 0, 2, fa["gu"], c.intermediate_size, fa["Kf"], 0, sp), "qtip gate/up out")
+                ck(L.gq_qtip_transform(1, g.data_ptr(), u.data_ptr(), None, 0.0, 2, 1, fa["d"], c.intermediate_size, fa["Kf"], 1, sp), "qtip down in")
                 ck(L.gq_qtip_matvec(y32[0].data_ptr(), ff.w2.trellis.data_ptr(), b["xs16"].data_ptr(), ff.w2.tlut.data_ptr(), c.dim,
                                     c.intermediate_size, d["R"], sp), "qtip down matvec")
                 ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")

@@ -150,12 +150,18 @@ int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
  * view, then hadK @ rows (transpose != 0: hadK^T @, matmul_hadUt).  Such a linear runs transform -> gq_qtip_matvec ->
  * transform (the Kf x Kf product is too much to repeat in every block of the fused kernel).
  *   input_side != 0:  out fp16 [n] = half(H(pro(x) * vec) * n^-1/2 / 32),  vec = SU f32 [n], pro as GQ_QPRO_* (x2 / norm_weight)
- *   input_side == 0:  out fp16 [n] = half(H(y32) * n^-1/2 * vec) (+ resid),  vec = SV * 32 f32 [n]
+ *   input_side == 0:  out fp16 [n] = half(H(y32) * n^-1/2 * vec) (+ resid),  vec = SV * 32 f32 [n]; up to 2 linears per launch
  * hadK f32 [Kf][Kf] is the caller's table (the reference's data, not shipped here); P a power of two >= 64.
  */
+typedef struct GqQtipXf {
+    const float *y32;   /* input_side == 0 */
+    const float *vec;
+    const float *hadK;
+    const void *resid;  /* fp16 [n] or NULL */
+    void *out;          /* fp16 [n] */
+} GqQtipXf;
 int gq_qtip_transform(int input_side, const void *x, const void *x2, const void *norm_weight, float eps, int prologue,
-                      const float *y32, const float *vec, const void *resid, void *out, uint32_t n, const float *hadK,
-                      uint32_t Kf, int transpose, void *stream);
+                      int n_lin, const GqQtipXf *lin, uint32_t n, uint32_t Kf, int transpose, void *stream);
 
 /*
  * Fused decode-step variant of the AP GEMV, M = 1: optional prologue on x

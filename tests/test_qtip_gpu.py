@@ -322,16 +322,16 @@ def test_factor_transform_goldens(name):
     for row in range(2):
         y32 = torch.from_numpy(g["X"][row]).to(d).contiguous()
         out = torch.full((n,), float("nan"), dtype=torch.float16, device=d)
-        _lib.check(L.gq_qtip_transform(0, None, None, None, 0.0, 0, y32.data_ptr(), ones.data_ptr(), None, out.data_ptr(), n, hk.data_ptr(), Kf, 0,
-                                       None), "out side")
+        xf = (_lib.GqQtipXf * 1)(_lib.GqQtipXf(y32.data_ptr(), ones.data_ptr(), hk.data_ptr(), None, out.data_ptr()))
+        _lib.check(L.gq_qtip_transform(0, None, None, None, 0.0, 0, 1, xf, n, Kf, 0, None), "out side")
         torch.cuda.synchronize()
         want = g["Y"][row]
         np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=2e-3, atol=2e-3 * np.abs(want).max())
         # input side: the source is fp16, so compare on an fp16-representable input through linearity of the golden pair
         x16 = torch.from_numpy(g["X"][row]).half().to(d)
         out2 = torch.full((n,), float("nan"), dtype=torch.float16, device=d)
-        _lib.check(L.gq_qtip_transform(1, x16.data_ptr(), None, None, 0.0, 0, None, ones.data_ptr(), None, out2.data_ptr(), n, hk.data_ptr(), Kf, 1,
-                                       None), "in side")
+        xf2 = (_lib.GqQtipXf * 1)(_lib.GqQtipXf(None, ones.data_ptr(), hk.data_ptr(), None, out2.data_ptr()))
+        _lib.check(L.gq_qtip_transform(1, x16.data_ptr(), None, None, 0.0, 0, 1, xf2, n, Kf, 1, None), "in side")
         torch.cuda.synchronize()
         want_t = g["Yt"][row] / 32.0
         np.testing.assert_allclose(out2.float().cpu().numpy(), want_t, rtol=4e-3, atol=4e-3 * np.abs(want_t).max())

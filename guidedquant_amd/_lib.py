@@ -31,7 +31,7 @@ class GqQtipXf(ctypes.Structure):
 
 class GqQtipOut(ctypes.Structure):
     _fields_ = [("y32", ctypes.c_void_p), ("SV32", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("out", ctypes.c_void_p),
-                ("M", ctypes.c_uint32)]
+                ("M", ctypes.c_uint32), ("parts", ctypes.c_uint32)]
 
 
 def build(force=False):
@@ -60,7 +60,7 @@ def lib():
         L.gq_lutgemm_gemv.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, i32, vp]
         L.gq_qtip_matvec.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp]
         L.gq_hadamard.argtypes = [vp, vp, u32, u32, f32, vp]
-        L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, ctypes.POINTER(GqQtipOut), vp]
+        L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, ctypes.POINTER(GqQtipOut), i32, vp]
         L.gq_qtip_linear_out.argtypes = [i32, ctypes.POINTER(GqQtipOut), vp]
         L.gq_qtip_transform.argtypes = [i32, vp, vp, vp, f32, i32, i32, ctypes.POINTER(GqQtipXf), u32, u32, i32, vp]
         L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]

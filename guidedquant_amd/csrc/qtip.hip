@@ -48,7 +48,7 @@ struct QtipNoop {
 // `between` runs behind the request of the first PF tile blocks (the caller's prologue: it does not depend on them)
 template <int R, class F = QtipNoop>
 __device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uint16_t *xs, const u32 *tl, float *part, u32 M2, u32 K,
-                                          F between = F()) {
+                                          F between = F(), u32 k2lo = 0u, u32 k2hi = 0xFFFFFFFFu) {
     const u32 T = blockDim.x, tid = threadIdx.x, W = T >> 6, w = tid >> 6, l = tid & 63u;
     const u32 a4 = l >> 5, s = l & 31u;  // tile-row parity, stream unit
     const u32 a = s >> 2, b = s & 3u;
@@ -59,21 +59,22 @@ __device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uin
     // outstanding and the kernel is latency-bound (measured 0.35 TB/s).  PF tile blocks are requested ahead.
     constexpr u32 PF = 8;
     u32 dq[PF][R];
+    if (k2hi > nK2) k2hi = nK2;  // the K range of this block (split-K launches: a part of the band)
     auto fetch = [&](u32 slot, u32 K2) {
-        if (K2 < nK2) {
+        if (K2 < k2hi) {
             const u32 *row = reinterpret_cast<const u32 *>(band + (size_t)K2 * 128u * R + (size_t)s * 4u * R);
 #pragma unroll
             for (int i = 0; i < R; i++) dq[slot][i] = __builtin_nontemporal_load(row + i);
         }
     };
 #pragma unroll
-    for (u32 p = 0; p < PF; p++) fetch(p, w + p * W);
+    for (u32 p = 0; p < PF; p++) fetch(p, k2lo + w + p * W);
     between();
-    for (u32 K2b = w; K2b < nK2; K2b += W * PF) {
+    for (u32 K2b = k2lo + w; K2b < k2hi; K2b += W * PF) {
 #pragma unroll
         for (u32 p = 0; p < PF; p++) {
             const u32 K2 = K2b + p * W;
-            if (K2 >= nK2) break;
+            if (K2 >= k2hi) break;
             u32 d[R];
 #pragma unroll
             for (int i = 0; i < R; i++) d[i] = dq[p][i];
@@ -243,7 +244,8 @@ struct QtipIn {
     const float *SU;
     const uint16_t *tlut;
     float *y32;
-    u32 band0;  // first block of this linear
+    u32 band0;  // first band (block / ksplit) of this linear
+    u32 M;
 };
 struct QtipOut {
     const float *y32, *SV32;  // SV32 = SV * 32 (fp32)
@@ -251,16 +253,18 @@ struct QtipOut {
     uint16_t *out;
     u32 M;
     float mscale;
+    u32 parts;  // y32 is [parts][M] split-K partial sums, added in this order
 };
 struct QtipInArgs {
     const uint16_t *x, *x2, *normw;
     float eps, kscale;  // kscale = (float)K^-1/2, rounded from double like the scale argument of hadamard()
     u32 K, n;
+    u32 ksplit;  // 1 / 2: blocks per band; block (band, ks) covers half of K and writes its sums to y32 + ks * M
     QtipIn lin[3];
     u32 nprev;          // 1 / 2: x (and x2) are the outputs of the linears prev[] whose transform-out is done here (M == K)
     QtipOut prev[2];
 };
-enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2 };
+enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2, QPRO_PRE = 3 };
 
 template <int R, int PRO>
 __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
@@ -271,9 +275,10 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     float *v = reinterpret_cast<float *>(smem);                 // [K] fp32 transform buffer
     uint16_t *xs = reinterpret_cast<uint16_t *>(v + K);         // [K] fp16 matvec input
     float *part = reinterpret_cast<float *>(xs + K);            // [waves][32]
+    const u32 bid = blockIdx.x / a.ksplit, ks = blockIdx.x % a.ksplit;
     u32 li = 0;
-    if (a.n > 1 && blockIdx.x >= a.lin[1].band0) li = 1;
-    if (a.n > 2 && blockIdx.x >= a.lin[2].band0) li = 2;
+    if (a.n > 1 && bid >= a.lin[1].band0) li = 1;
+    if (a.n > 2 && bid >= a.lin[2].band0) li = 2;
     const QtipIn L = a.lin[li];
     // codebook words of this thread (T >= 256): requested now, stored to LDS in the prologue
     const u32 tl0 = reinterpret_cast<const u32 *>(L.tlut)[tid & 511u], tl1 = reinterpret_cast<const u32 *>(L.tlut)[(tid + 256u) & 511u];
@@ -285,7 +290,7 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         uint16_t *xp = reinterpret_cast<uint16_t *>(part + (T >> 6) * 32u);  // [nprev][K] fp16
         for (u32 r = 0; r < a.nprev; r++) {
             const QtipOut P = a.prev[r];
-            for (u32 i = tid; i < K; i += T) v[i] = P.y32[i];
+            for (u32 i = tid; i < K; i += T) v[i] = P.parts == 2u ? P.y32[i] + P.y32[K + i] : P.y32[i];
             __syncthreads();
             fwht_lds(v, K);
             for (u32 i = tid; i < K; i += T) {
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     // runs while those are on their way from HBM (vector memory returns in order: requested the other way round, the
     // first use of x would wait for the tiles).
     constexpr u32 NX = 8;
-    const bool inreg = !a.nprev && K <= NX * T;
+    const bool inreg = !a.nprev && K <= NX * T && PRO != QPRO_PRE;
     uint16_t xr[NX], x2r[NX], nwr[NX];
     float sur[NX];
     if (inreg) {
@@ -320,6 +325,11 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     auto prologue = [&]() {
         if (tid < 512u) tl[tid] = tl0;
         if (T == 256u) tl[tid + 256u] = tl1;
+        if constexpr (PRO == QPRO_PRE) {  // x is the transformed fp16 input already (gq_qtip_transform): K need not be a power of two
+            for (u32 i = tid; i < K / 8u; i += T) reinterpret_cast<uint4 *>(xs)[i] = reinterpret_cast<const uint4 *>(xg)[i];
+            __syncthreads();
+            return;
+        }
         float nscale = 0.f;
         if constexpr (PRO == QPRO_RMSNORM) {
             float ss = 0.f;
@@ -371,7 +381,8 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         for (u32 i = tid; i < K; i += T) xs[i] = __builtin_bit_cast(uint16_t, (h16)((v[i] * sc) / 32.0f));
         __syncthreads();
     };
-    qtip_band<R>(L.y32, L.comp, xs, tl, part, blockIdx.x - L.band0, K, prologue);
+    const u32 nK2 = K / 32u, khalf = (nK2 + a.ksplit - 1u) / a.ksplit;
+    qtip_band<R>(L.y32 + (size_t)ks * L.M, L.comp, xs, tl, part, bid - L.band0, K, prologue, ks * khalf, (ks + 1u) * khalf);
 }
 
 struct QtipOutArgs {
@@ -382,7 +393,7 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     float *v = reinterpret_cast<float *>(smem);
     const QtipOut L = a.lin[blockIdx.x];
     const u32 T = blockDim.x, tid = threadIdx.x, M = L.M;
-    for (u32 i = tid; i < M; i += T) v[i] = L.y32[i];
+    for (u32 i = tid; i < M; i += T) v[i] = L.parts == 2u ? L.y32[i] + L.y32[M + i] : L.y32[i];
     // the scale and residual vectors are requested before the transform (one block: nothing else hides their latency)
     constexpr u32 PRE = 8;  // M <= 8192 at 1024 threads
     float svr[PRE];
@@ -569,15 +580,19 @@ bool pow2(u32 n) { return n && !(n & (n - 1u)); }
 }
 
 extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
-                                 int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, void *stream) {
+                                 int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, void *stream) {
+    if (ksplit < 1 || ksplit > 2) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: ksplit must be 1 or 2.");
     if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 1..3 linears.");
     if (n_prev < 0 || n_prev > 2 || (n_prev && !prev)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 0..2 producing linears.");
     if (n_prev == 0 && !x) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: x is null.");
     if (n_prev && n_prev != (prologue == GQ_QPRO_SILU_MUL ? 2 : 1))
         return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: one producing linear per input vector (two for SILU_MUL).");
     if (R < 2 || R > 4) return gq_fail(GQ_ENOTSUP, "R (bits per weight) must be 2, 3 or 4 (kernel_check.py:1-14).");
-    if (!pow2(K) || K < 32u || K > 16384u) return gq_fail(GQ_ENOTSUP, "fused QTIP linear: K must be a power of two in 32..16384.");
-    if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2 && !n_prev) || prologue < 0 || prologue > 2)
+    if (prologue == GQ_QPRO_PRETRANSFORMED) {
+        if (K == 0 || K % 32u || K > 32768u || n_prev) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: pre-transformed input: K a multiple of 32, no folding.");
+    } else if (!pow2(K) || K < 32u || K > 16384u)
+        return gq_fail(GQ_ENOTSUP, "fused QTIP linear: K must be a power of two in 32..16384.");
+    if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2 && !n_prev) || prologue < 0 || prologue > 3)
         return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: prologue operand missing.");
     QtipInArgs a{};
     a.x = (const uint16_t *)x;
@@ -589,25 +604,28 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
     a.n = (u32)n;
     u32 bands = 0, minM = 0xFFFFFFFFu;
     for (int i = 0; i < n; i++) {
-        if (!lin[i].trellis || !lin[i].SU || !lin[i].tlut || !lin[i].y32 || lin[i].M == 0 || lin[i].M % 32u)
+        if (!lin[i].trellis || (!lin[i].SU && prologue != GQ_QPRO_PRETRANSFORMED) || !lin[i].tlut || !lin[i].y32 || lin[i].M == 0 || lin[i].M % 32u)
             return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: null pointer or M not a multiple of 32.");
         if (((uintptr_t)lin[i].trellis | (uintptr_t)lin[i].tlut) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
-        a.lin[i] = QtipIn{lin[i].trellis, lin[i].SU, (const uint16_t *)lin[i].tlut, lin[i].y32, bands};
+        a.lin[i] = QtipIn{lin[i].trellis, lin[i].SU, (const uint16_t *)lin[i].tlut, lin[i].y32, bands, lin[i].M};
         bands += lin[i].M / 32u;
         if (lin[i].M < minM) minM = lin[i].M;
     }
     const u32 nK2 = K / 32u;
     u32 waves = nK2 >= 8u ? 8u : (nK2 >= 4u ? 4u : (nK2 >= 2u ? 2u : 1u));
-    if (nK2 >= 32u && bands <= 256u) waves = 16u;
+    if (nK2 >= 32u && bands * (u32)ksplit <= 256u) waves = 16u;
     if (waves < 4u) waves = 4u;  // the transform wants threads
+    a.ksplit = (u32)ksplit;
     a.nprev = (u32)n_prev;
     for (int i = 0; i < n_prev; i++) {
         if (!prev[i].y32 || !prev[i].SV32 || prev[i].M != K) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: producing linear must have M == K.");
-        a.prev[i] = QtipOut{prev[i].y32, prev[i].SV32, (const uint16_t *)prev[i].resid, (uint16_t *)prev[i].out, K, (float)pow((double)K, -0.5)};
+        a.prev[i] = QtipOut{prev[i].y32, prev[i].SV32, (const uint16_t *)prev[i].resid, (uint16_t *)prev[i].out, K, (float)pow((double)K, -0.5),
+                            prev[i].parts == 2u ? 2u : 1u};
     }
-    const size_t smem = (size_t)K * 6u + (size_t)waves * 32u * 4u + (size_t)n_prev * K * 2u;  // <= 130 KiB
+    const size_t smem = (size_t)K * 6u + (size_t)waves * 32u * 4u + (size_t)n_prev * K * 2u;  // <= 130 KiB for K <= 16384
+    if (smem > 150u * 1024u) return gq_fail(GQ_ENOTSUP, "gq_qtip_linear_in: K too large.");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(bands), block(waves * 64u);
+    dim3 grid(bands * (u32)ksplit), block(waves * 64u);
 #define GQ_LAUNCH_QIN(RR, PP)                                                                                         \
     do {                                                                                                              \
         static bool set = false;                                                                                      \
@@ -622,6 +640,7 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
     do {                                                                      \
         if (prologue == GQ_QPRO_RMSNORM) GQ_LAUNCH_QIN(RR, QPRO_RMSNORM);     \
         else if (prologue == GQ_QPRO_SILU_MUL) GQ_LAUNCH_QIN(RR, QPRO_SILUMUL); \
+        else if (prologue == GQ_QPRO_PRETRANSFORMED) GQ_LAUNCH_QIN(RR, QPRO_PRE); \
         else GQ_LAUNCH_QIN(RR, QPRO_NONE);                                    \
     } while (0)
     if (R == 2) GQ_LAUNCH_QIN_R(2);
@@ -641,8 +660,9 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
         if (!lin[i].y32 || !lin[i].SV32 || !lin[i].out) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out: null pointer argument.");
         if (!pow2(lin[i].M) || lin[i].M < 32u || lin[i].M > 32768u)
             return gq_fail(GQ_ENOTSUP, "fused QTIP linear: M must be a power of two in 32..32768.");
+        if (lin[i].parts > 2u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out: parts must be 0 / 1 / 2.");
         a.lin[i] = QtipOut{lin[i].y32, lin[i].SV32, (const uint16_t *)lin[i].resid, (uint16_t *)lin[i].out, lin[i].M,
-                           (float)pow((double)lin[i].M, -0.5)};
+                           (float)pow((double)lin[i].M, -0.5), lin[i].parts == 2u ? 2u : 1u};
         if (lin[i].M > maxM) maxM = lin[i].M;
     }
     const size_t smem = (size_t)maxM * 4u;

@@ -348,7 +348,7 @@ class Transformer(nn.Module):
         st["g"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
         st["u"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
         mmax = max(c.dim, c.intermediate_size)
-        st["y32"] = torch.zeros(3, mmax, dtype=torch.float32, device=dev)
+        st["y32"] = torch.zeros(3, 2 * mmax, dtype=torch.float32, device=dev)  # [linear][split-K part][M]
         st["xs16"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)  # transformed input of the down projection
         keep = []  # fp32 copies the descriptors point into
 
@@ -363,10 +363,13 @@ class Transformer(nn.Module):
                 arr[i] = _lib.GqQtipIn(m.trellis.data_ptr(), f32(m.SU), m.tlut.data_ptr(), st["y32"][i].data_ptr(), m.out_features)
             return arr
 
-        def lin_out(mods, outs, resid):
+        def ksplit(m):  # fewer 32-row bands than half the CUs (wo, down): two blocks per band, each over half of K
+            return 2 if m.out_features // 32 <= 128 and os.environ.get("GQ_QTIP_KSPLIT", "1") != "0" else 1
+
+        def lin_out(mods, outs, resid, parts=1):
             arr = (_lib.GqQtipOut * len(mods))()
             for i, m in enumerate(mods):
-                arr[i] = _lib.GqQtipOut(st["y32"][i].data_ptr(), f32(m.SV, 32.0), resid, outs[i], m.out_features)
+                arr[i] = _lib.GqQtipOut(st["y32"][i].data_ptr(), f32(m.SV, 32.0), resid, outs[i], m.out_features, parts)
             return arr
 
         x, h, y, qkv = st["x"], st["h"], st["y"], st["qkv"]
@@ -385,9 +388,9 @@ class Transformer(nn.Module):
                 factor=factor,
                 qkv_in=lin_in([at.wq, at.wk, at.wv]),
                 qkv_out=lin_out([at.wq, at.wk, at.wv], [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e], None),
-                o_in=lin_in([at.wo]), o_out=lin_out([at.wo], [h.data_ptr()], x.data_ptr()),
+                o_in=lin_in([at.wo]), o_out=lin_out([at.wo], [h.data_ptr()], x.data_ptr(), ksplit(at.wo)), ks_o=ksplit(at.wo),
                 gu_in=lin_in([ff.w1, ff.w3]), gu_out=lin_out([ff.w1, ff.w3], [st["g"].data_ptr(), st["u"].data_ptr()], None),
-                d_in=lin_in([ff.w2]), d_out=lin_out([ff.w2], [x.data_ptr()], h.data_ptr()), R=at.wq.K))
+                d_in=lin_in([ff.w2]), d_out=lin_out([ff.w2], [x.data_ptr()], h.data_ptr(), ksplit(ff.w2)), ks_d=ksplit(ff.w2), R=at.wq.K))
         st["qtip_layers"] = layers
         st["qtip_keep"] = keep
 
@@ -413,16 +416,16 @@ class Transformer(nn.Module):
             at = blk.attention
             carry = fold and li > l0  # the hidden state is still the previous layer's untransformed down projection
             ck(L.gq_qtip_linear_in(x.data_ptr(), None, blk.input_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 3,
-                                   d["qkv_in"], 1 if carry else 0, b["qtip_layers"][li - 1]["d_out"] if carry else None, sp), "qtip qkv in")
+                                   d["qkv_in"], 1 if carry else 0, b["qtip_layers"][li - 1]["d_out"] if carry else None, 1, sp), "qtip qkv in")
             ck(L.gq_qtip_linear_out(3, d["qkv_out"], sp), "qtip qkv out")
             ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
                                 at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
                                 y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, sp), "attn")
-            ck(L.gq_qtip_linear_in(y.data_ptr(), None, None, 0.0, 0, c.dim, d["R"], 1, d["o_in"], 0, None, sp), "qtip o in")
+            ck(L.gq_qtip_linear_in(y.data_ptr(), None, None, 0.0, 0, c.dim, d["R"], 1, d["o_in"], 0, None, d["ks_o"], sp), "qtip o in")
             if not fold:
                 ck(L.gq_qtip_linear_out(1, d["o_out"], sp), "qtip o out")
             ck(L.gq_qtip_linear_in(h.data_ptr(), None, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 2,
-                                   d["gu_in"], 1 if fold else 0, d["o_out"] if fold else None, sp), "qtip gate/up in")
+                                   d["gu_in"], 1 if fold else 0, d["o_out"] if fold else None, 1, sp), "qtip gate/up in")
             fa = d["factor"]
             if fa is not None:
                 # MLP width = Kf * 2^p: gate/up outputs and the down input go through the factor transform kernels
@@ -430,14 +433,14 @@ class Transformer(nn.Module):
                 y32 = b["y32"]
                 ck(L.gq_qtip_transform(0, None, None, None, 0.0, 0, 2, fa["gu"], c.intermediate_size, fa["Kf"], 0, sp), "qtip gate/up out")
                 ck(L.gq_qtip_transform(1, g.data_ptr(), u.data_ptr(), None, 0.0, 2, 1, fa["d"], c.intermediate_size, fa["Kf"], 1, sp), "qtip down in")
-                ck(L.gq_qtip_matvec(y32[0].data_ptr(), ff.w2.trellis.data_ptr(), b["xs16"].data_ptr(), ff.w2.tlut.data_ptr(), c.dim,
-                                    c.intermediate_size, d["R"], sp), "qtip down matvec")
+                ck(L.gq_qtip_linear_in(b["xs16"].data_ptr(), None, None, 0.0, 3, c.intermediate_size, d["R"], 1, d["d_in"], 0, None, d["ks_d"], sp),
+                   "qtip down matvec")
                 ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
                 continue
             if not fold:
                 ck(L.gq_qtip_linear_out(2, d["gu_out"], sp), "qtip gate/up out")
             ck(L.gq_qtip_linear_in(g.data_ptr(), u.data_ptr(), None, 0.0, 2, c.intermediate_size, d["R"], 1, d["d_in"],
-                                   2 if fold else 0, d["gu_out"] if fold else None, sp), "qtip down in")
+                                   2 if fold else 0, d["gu_out"] if fold else None, d["ks_d"], sp), "qtip down in")
             if not fold or li == l1 - 1:
                 ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
 

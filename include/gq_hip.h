@@ -118,6 +118,8 @@ int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale
  *   x fp16 [K] (prologue SILU_MUL: x = gate, x2 = up), norm_weight fp16 [K];
  *   GqQtipIn : trellis u32 [R*M*K/32], SU f32 [K], tlut fp16 [1024], y32 f32 [M] (written);
  *   GqQtipOut: y32 f32 [M], SV32 f32 [M] (= SV * 32), resid fp16 [M] or NULL, out fp16 [M] (may alias resid).
+ * ksplit = 2: two blocks per 32-row band, each over half of K, partial sums to y32[0..M) and y32[M..2M) (y32 must hold
+ * 2 M floats; gq_qtip_linear_out with parts = 2 adds them): for launches with fewer bands than half the CUs (wo, down).
  * Folding: with n_prev = 1 (2 for SILU_MUL) the input vector(s) of gq_qtip_linear_in are NOT read from x / x2 but rebuilt
  * from prev[] -- the transform-out of the linear(s) that produce them (M == K), residual included -- by every block, and
  * stored to prev[i].out (if not NULL; must not alias prev[i].resid) once: gq_qtip_linear_out and its launch are saved for
@@ -126,6 +128,7 @@ int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale
 #define GQ_QPRO_NONE 0
 #define GQ_QPRO_RMSNORM 1
 #define GQ_QPRO_SILU_MUL 2
+#define GQ_QPRO_PRETRANSFORMED 3 /* x is the fp16 output of gq_qtip_transform(input_side): matvec only, any K % 32 == 0 */
 typedef struct GqQtipIn {
     const uint32_t *trellis;
     const float *SU;
@@ -139,9 +142,10 @@ typedef struct GqQtipOut {
     const void *resid;
     void *out;
     uint32_t M;
+    uint32_t parts; /* 0 / 1: y32 is [M]; 2: y32 is [2][M] split-K partial sums (ksplit = 2 of gq_qtip_linear_in) */
 } GqQtipOut;
 int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
-                      int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, void *stream);
+                      int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, void *stream);
 int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
 
 /*

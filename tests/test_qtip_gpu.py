@@ -149,7 +149,7 @@ def _fused_linear(lin, x16, pro=0, x2=None, normw=None, eps=1e-5, resid=None, gr
                                  outs[i].data_ptr(), m.out_features)
     st = _lib.current_stream_ptr()
     _lib.check(L.gq_qtip_linear_in(x16.data_ptr(), x2.data_ptr() if x2 is not None else None,
-                                   normw.data_ptr() if normw is not None else None, eps, pro, K, mods[0].K, len(mods), ain, 0, None, st), "in")
+                                   normw.data_ptr() if normw is not None else None, eps, pro, K, mods[0].K, len(mods), ain, 0, None, 1, st), "in")
     _lib.check(L.gq_qtip_linear_out(len(mods), aout, st), "out")
     torch.cuda.synchronize()
     return outs
@@ -235,7 +235,7 @@ def test_folded_transform_out_is_bit_identical():
     y32 = [torch.zeros(K, dtype=torch.float32, device=d) for _ in prod]
     pin = (_lib.GqQtipIn * 2)(*[_lib.GqQtipIn(m.trellis.data_ptr(), su_p[i].data_ptr(), m.tlut.data_ptr(), y32[i].data_ptr(), K)
                                 for i, m in enumerate(prod)])
-    _lib.check(L.gq_qtip_linear_in(xin.data_ptr(), None, None, 0.0, 0, 2048, R, 2, pin, 0, None, st), "producers")
+    _lib.check(L.gq_qtip_linear_in(xin.data_ptr(), None, None, 0.0, 0, 2048, R, 2, pin, 0, None, 1, st), "producers")
     su_c, sv_c = cons.SU.float().contiguous(), (cons.SV.float() * 32).contiguous()
     for pro, nprev in ((0, 1), (1, 1), (2, 2)):
         outs = [torch.zeros(K, dtype=torch.float16, device=d) for _ in prod]
@@ -246,15 +246,52 @@ def test_folded_transform_out_is_bit_identical():
         yc = [torch.zeros(1024, dtype=torch.float32, device=d) for _ in range(2)]
         cin = [(_lib.GqQtipIn * 1)(_lib.GqQtipIn(cons.trellis.data_ptr(), su_c.data_ptr(), cons.tlut.data_ptr(), yc[j].data_ptr(), 1024))
                for j in range(2)]
-        _lib.check(L.gq_qtip_linear_in(outs[0].data_ptr(), outs[1].data_ptr(), normw.data_ptr(), 1e-5, pro, K, R, 1, cin[0], 0, None, st), "two-launch")
+        _lib.check(L.gq_qtip_linear_in(outs[0].data_ptr(), outs[1].data_ptr(), normw.data_ptr(), 1e-5, pro, K, R, 1, cin[0], 0, None, 1, st), "two-launch")
         stored = [torch.full((K,), float("nan"), dtype=torch.float16, device=d) for _ in prod]
         pfold = (_lib.GqQtipOut * 2)(*[_lib.GqQtipOut(y32[i].data_ptr(), sv_p[i].data_ptr(), rs.data_ptr() if rs is not None else None,
                                                       stored[i].data_ptr(), K) for i in range(2)])
-        _lib.check(L.gq_qtip_linear_in(None, None, normw.data_ptr(), 1e-5, pro, K, R, 1, cin[1], nprev, pfold, st), "folded")
+        _lib.check(L.gq_qtip_linear_in(None, None, normw.data_ptr(), 1e-5, pro, K, R, 1, cin[1], nprev, pfold, 1, st), "folded")
         torch.cuda.synchronize()
         assert torch.equal(yc[0], yc[1]) and bool(torch.isfinite(yc[0]).all())
         for i in range(nprev):
             assert torch.equal(stored[i].view(torch.int16), outs[i].view(torch.int16))
+
+
+@pytest.mark.parametrize("M,K", [(4096, 4096), (2048, 8192), (1024, 1024)])
+def test_split_k_and_pretransformed_input(M, K):
+    """ksplit = 2 (two blocks per band, partial sums added by gq_qtip_linear_out with parts = 2) agrees with ksplit = 1 to
+    fp32 rounding of one extra addition; GQ_QPRO_PRETRANSFORMED on the fp16 vector the prologue would have produced is the
+    bare matvec (== gq_qtip_matvec, same block shape)"""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    lin = _rand_qlinear(K, M, 2, seed=M + K)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(K, generator=g).half().to(d)
+    su, sv = lin.SU.float().contiguous(), (lin.SV.float() * 32).contiguous()
+    res = []
+    for ks in (1, 2):
+        y32 = torch.full((2 * M,), float("nan"), dtype=torch.float32, device=d)
+        out = torch.zeros(M, dtype=torch.float16, device=d)
+        ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), su.data_ptr(), lin.tlut.data_ptr(), y32.data_ptr(), M))
+        aout = (_lib.GqQtipOut * 1)(_lib.GqQtipOut(y32.data_ptr(), sv.data_ptr(), None, out.data_ptr(), M, ks))
+        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 0, K, 2, 1, ain, 0, None, ks, None), "in")
+        _lib.check(L.gq_qtip_linear_out(1, aout, None), "out")
+        torch.cuda.synchronize()
+        res.append((y32.clone(), out.clone()))
+    y1 = res[0][0][:M]
+    y2 = res[1][0][:M] + res[1][0][M:]
+    assert bool(torch.isfinite(y2).all())
+    assert float((y1 - y2).abs().max()) <= 2e-6 * float(y1.abs().max()) + 1e-7
+    assert float((res[0][1].float() - res[1][1].float()).abs().max()) <= 2.0**-9 * float(res[0][1].float().abs().max())
+    # pre-transformed input: feed the matvec's own fp16 input
+    from guidedquant_amd.qtip import matmul_hadUt_cuda
+    xs = (matmul_hadUt_cuda(x.view(1, K).float() * lin.SU, None, 1) / 32).half().reshape(-1).contiguous()
+    y3 = torch.full((M,), float("nan"), dtype=torch.float32, device=d)
+    ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), None, lin.tlut.data_ptr(), y3.data_ptr(), M))
+    _lib.check(L.gq_qtip_linear_in(xs.data_ptr(), None, None, 0.0, 3, K, 2, 1, ain, 0, None, 1, None), "pre")
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y1)
 
 
 def test_fused_linear_validation():
@@ -264,10 +301,10 @@ def test_fused_linear_validation():
     x = torch.zeros(128, dtype=torch.float16, device="cuda:0")
     with pytest.raises(RuntimeError, match="power of two"):
         ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), lin.SU.float().data_ptr(), lin.tlut.data_ptr(), x.data_ptr(), 64))
-        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 0, 96, 2, 1, ain, 0, None, None), "in")
+        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 0, 96, 2, 1, ain, 0, None, 1, None), "in")
     with pytest.raises(RuntimeError, match="prologue operand"):
         ain = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(lin.trellis.data_ptr(), lin.SU.float().data_ptr(), lin.tlut.data_ptr(), x.data_ptr(), 64))
-        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 1, 128, 2, 1, ain, 0, None, None), "in")
+        _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 1, 128, 2, 1, ain, 0, None, 1, None), "in")
 
 
 @pytest.mark.parametrize("fold", ["1", "0"])

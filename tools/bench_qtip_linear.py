@@ -50,7 +50,7 @@ def main():
             if p == pro and pro == 0:
                 continue
             res[label + "_us"] = round(timed(lambda i: _lib.check(L.gq_qtip_linear_in(x.data_ptr(), x2.data_ptr(), nw.data_ptr(), 1e-5, p, K, R, len(Ms),
-                                                                                       descs[i], 0, None, st()), "A"), n), 2)
+                                                                                       descs[i], 0, None, 1, st()), "A"), n), 2)
         res["B_us"] = round(timed(lambda i: _lib.check(L.gq_qtip_linear_out(len(Ms), dout, st()), "B"), 1), 2)
         res["matvec_sum_us"] = round(timed(lambda i: [_lib.check(L.gq_qtip_matvec(y32[j].data_ptr(), tr[i][j].data_ptr(), x.data_ptr(), tl.data_ptr(), M, K, R, st()), "mv")
                                                       for j, M in enumerate(Ms)], n), 2)

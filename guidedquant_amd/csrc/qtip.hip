@@ -454,13 +454,14 @@ __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
     const u32 n = a.n, T = blockDim.x, tid = threadIdx.x;
     const u32 P = a.P, Kf = a.Kf, RB = a.RB, r0 = blockIdx.x * RB;
     float *v = reinterpret_cast<float *>(smem);  // [n]
-    float *hs = v + n;                           // [RB][Kf] rows (or columns) of the factor this block multiplies with
-    float *ps = hs + RB * Kf;                    // [KQ][RB * P] partial sums of the factor product
+    float *hs = v + n;                           // [Kf][4]: element k of the (up to 4) factor rows this block multiplies with
+    float *ps = hs + 4u * Kf;                    // [KQ][RB][P] partial sums of the factor product
     const QtipXfLin L = a.lin[blockIdx.y];
-    // this block's rows of hadK (columns for the transposed product), requested first
-    for (u32 e = tid; e < RB * Kf; e += T) {
-        const u32 rr = e / Kf, k = e % Kf, kr = r0 + rr;
-        hs[e] = kr < Kf ? (a.transpose ? L.hadK[(size_t)k * Kf + kr] : L.hadK[(size_t)kr * Kf + k]) : 0.f;
+    // this block's rows of hadK (columns for the transposed product), requested first; k-major so that one 16-byte LDS read
+    // serves the 4 rows
+    for (u32 e = tid; e < 4u * Kf; e += T) {
+        const u32 k = e >> 2, rr = e & 3u, kr = r0 + rr;
+        hs[e] = (rr < RB && kr < Kf) ? (a.transpose ? L.hadK[(size_t)k * Kf + kr] : L.hadK[(size_t)kr * Kf + k]) : 0.f;
     }
     if (a.in) {
         float rs = 0.f;
@@ -498,25 +499,32 @@ __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
     // hadamard() scales by n^-1/2 before the factor product (matmul_had.py:88-90): same rounding points here
     for (u32 i = tid; i < n; i += T) v[i] = v[i] * a.nscale;
     __syncthreads();
-    // factor product: the RB * P results of the block, the sum over k split over KQ thread groups (fixed order)
-    const u32 NO = RB * P, KQ = NO >= T ? 1u : T / NO, kper = (Kf + KQ - 1u) / KQ;
-    for (u32 ob = 0; ob < NO; ob += T) {
-        const u32 o = ob + tid % (NO < T ? NO : T), kq = NO < T ? tid / NO : 0u;
-        if (o < NO && kq < KQ) {
-            const u32 rr = o / P, p = o % P;
-            const float *hrow = hs + rr * Kf;
-            float acc = 0.f;
+    // factor product: thread (p, kq) adds its share of the k range into the (up to 4) rows of column p -- one LDS read of
+    // the activation and one 16-byte read of the 4 factor entries per 4 multiply-adds --; the KQ partial sums are added in
+    // a fixed order
+    const u32 KQ = T >= P ? T / P : 1u, kper = (Kf + KQ - 1u) / KQ, NO = RB * P;
+    for (u32 pb = 0; pb < P; pb += T) {
+        const u32 p = pb + (T >= P ? tid % P : tid), kq = T >= P ? tid / P : 0u;
+        if (p < P && kq < KQ) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
             const u32 k1 = min((kq + 1u) * kper, Kf);
-            for (u32 k = kq * kper; k < k1; k++) acc += hrow[k] * v[k * P + p];
-            ps[kq * NO + o] = acc;
+            for (u32 k = kq * kper; k < k1; k++) {
+                const float4 h4 = *reinterpret_cast<const float4 *>(hs + 4u * k);
+                const float xv = v[k * P + p];
+                acc[0] += h4.x * xv;
+                acc[1] += h4.y * xv;
+                acc[2] += h4.z * xv;
+                acc[3] += h4.w * xv;
+            }
+            for (u32 rr = 0; rr < RB; rr++) ps[(kq * RB + rr) * P + p] = acc[rr];
         }
     }
     __syncthreads();
     for (u32 o = tid; o < NO; o += T) {
-        const u32 kr = r0 + o / P, p = o % P;
+        const u32 rr = o / P, kr = r0 + rr, p = o % P;
         if (kr >= Kf) continue;
         float acc = 0.f;
-        for (u32 q = 0; q < KQ; q++) acc += ps[q * NO + o];
+        for (u32 q = 0; q < KQ; q++) acc += ps[(q * RB + rr) * P + p];
         const u32 i = kr * P + p;
         h16 y;
         if (a.in) y = (h16)(acc / 32.0f);
@@ -698,12 +706,13 @@ extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, 
     a.n = n;
     a.Kf = Kf;
     a.P = P;
-    a.RB = P >= 512u ? 1u : (P >= 128u ? 2u : 4u);  // >= 256 results per block
+    a.RB = (u32)gq_env_int("GQ_QTIP_XF_RB", P >= 256u ? 1 : (P >= 128u ? 2 : 4));  // rows of the result per block (<= 4)
+    if (a.RB < 1u || a.RB > 4u) a.RB = 1u;
     a.in = input_side ? 1u : 0u;
     a.pro = input_side ? (u32)prologue : 0u;
     a.transpose = transpose ? 1u : 0u;
-    const u32 NO = a.RB * P, KQ = NO >= 1024u ? 1u : 1024u / NO;
-    const size_t smem = ((size_t)n + (size_t)a.RB * Kf + (size_t)KQ * NO) * 4u;
+    const u32 KQ = P >= 1024u ? 1u : 1024u / P;
+    const size_t smem = ((size_t)n + 4u * (size_t)Kf + (size_t)KQ * a.RB * P) * 4u;
     if (smem > 150u * 1024u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n too large.");
     static bool set = false;
     if (!set) {

@@ -93,7 +93,11 @@ __device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uin
                     // sign of the low half folded in with one 3-input op
                     const u32 st = R == 2 ? __builtin_amdgcn_ubfe(comb32, 16u - 4u * i, 16u)
                                           : (u32)(comb >> (16 * R - 2 * R * i - 16)) & 0xFFFFu;
-                    const u32 idx = __umul24(st, st) + st;
+                    // st * (st + 1) as ONE 24-bit multiply-add.  Written in asm: the compiler knows that only bits 6..15 of the
+                    // result are used, drops the 16-bit mask of st and then needs a full-width v_mad_u64_u32 (quarter rate) for
+                    // the windows that are wider than 24 bits; v_mad_u32_u24 ignores the upper bits by itself.
+                    u32 idx;
+                    asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(idx) : "v"(st));
                     const u32 w2 = *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(tl) + ((idx >> 4) & 0x7FCu)) ^ (idx & 0x8000u);
                     const u32 xv = (i & 2u) ? x1 : x0;  // cc = i / 2
                     if (i & 1u)                        // d = i % 2

@@ -201,93 +201,117 @@ __device__ __forceinline__ u32 hash32(u32 x) {
 // bits, inverted index in the low bits so that ties go to the lowest index): nbits rounds of "count keys >= candidate"
 // (registers + one DPP wave reduction + one LDS combine per round) instead of K rounds of block-wide arg-max.
 __device__ __forceinline__ u32 ordered_key16(uint16_t h) { return (h & 0x8000u) ? (u32)(uint16_t)~h : ((u32)h | 0x8000u); }
+__device__ __forceinline__ uint16_t unordered_key16(u32 o) { return (o & 0x8000u) ? (uint16_t)(o & 0x7FFFu) : (uint16_t)~o; }
 
-template <int NW, int EPT, typename KeyT>
-__device__ __forceinline__ KeyT select_threshold(const KeyT (&key)[EPT], int nbits, int K, int *cnt_lds, u32 w, u32 l) {
-    // returns the K-th largest key (keys are unique, so exactly K keys are >= the result when >= K valid keys exist)
+// The K-th largest of the 64 * EPT keys of ONE wave by binary search on the key bits: the count of a round is EPT ballots +
+// scalar population counts -- no LDS, no barrier (the block-wide version above pays a 1024-thread barrier per bit: 13 us
+// for 33 bits).  Two levels of it replace a block-wide search: every wave keeps its own top K (a global top-K key is in
+// the top K of its wave), one wave then searches the survivors.
+// The low `lowbits` bits of a key are the tie-breaking position: they are searched only when the value bits leave more than
+// K keys at the threshold (rare), which halves the rounds.
+template <int EPT, typename KeyT>
+__device__ __forceinline__ KeyT wave_select_threshold(const KeyT (&key)[EPT], int nbits, int lowbits, int K) {
     KeyT t = 0;
+    int ct = 0x7FFFFFFF;  // count of keys >= t
     for (int bit = nbits - 1; bit >= 0; bit--) {
+        if (bit == lowbits - 1 && ct == K) break;  // exactly K keys carry a value >= the threshold value: no tie to break
         const KeyT cand = t | ((KeyT)1 << bit);
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < EPT; e++) c += key[e] >= cand ? 1 : 0;
-        float cf = wave_reduce<false>((float)c);  // counts <= 64 * EPT: exact in fp32
-        if (l == 0) cnt_lds[(bit & 1) * NW + w] = (int)cf;
-        __syncthreads();
-        int tot = 0;
-#pragma unroll
-        for (int i = 0; i < NW; i++) tot += cnt_lds[(bit & 1) * NW + i];
-        if (tot >= K) t = cand;
+        for (int e = 0; e < EPT; e++) c += __popcll(__builtin_amdgcn_ballot_w64(key[e] >= cand));
+        if (c >= K) {  // wave-uniform
+            t = cand;
+            ct = c;
+        }
     }
     return t;
+}
+// writes the keys >= t (and != 0) of the wave to dst[0 .. count) in lane order; returns the count (<= K for a threshold
+// from wave_select_threshold: keys are unique)
+template <int EPT, typename KeyT>
+__device__ __forceinline__ int wave_compact(const KeyT (&key)[EPT], KeyT t, KeyT *dst, int cap, u32 l) {
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const bool p = key[e] >= t && key[e] != 0;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(p);
+        const int pos = base + __popcll(b & ((1ull << l) - 1ull));
+        if (p && pos < cap) dst[pos] = key[e];
+        base += __popcll(b);
+    }
+    return base;
 }
 
 // stage 1: each of the 128 blocks selects the top-32 of its slice (<= 1024 logits, 4 per thread in registers)
 __global__ void __launch_bounds__(256) sample_stage1(const uint16_t *logits, u32 V, float *cand_val, int *cand_idx) {
-    __shared__ int cnt[8];
-    __shared__ int slot;
+    __shared__ u32 surv[4 * SAMP_K];
     const u32 per = (V + SAMP_BLOCKS - 1) / SAMP_BLOCKS;  // <= 1024
     const u32 lo = blockIdx.x * per, hi = min(lo + per, V);
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
     u32 key[4];
-    uint16_t raw[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const u32 li = tid * 4u + (u32)e, gi = lo + li;
-        raw[e] = gi < hi ? logits[gi] : (uint16_t)0xFC00;  // -inf padding
-        key[e] = gi < hi ? ((ordered_key16(raw[e]) << 10) | (1023u - li)) : 0u;
+        // key = (order-preserving image of the fp16 logit, position): unique, and both parts are recovered from it
+        key[e] = gi < hi ? ((ordered_key16(logits[gi]) << 10) | (1023u - li)) : 0u;
     }
-    if (tid == 0) slot = 0;
-    const u32 t = select_threshold<4, 4, u32>(key, 26, SAMP_K, cnt, w, l);
+    if (l < SAMP_K / 2) reinterpret_cast<unsigned long long *>(surv + w * SAMP_K)[l] = 0ull;  // (a wave's LDS ops are in order)
+    const u32 t = wave_select_threshold<4, u32>(key, 26, 10, SAMP_K);
+    wave_compact<4, u32>(key, t, surv + w * SAMP_K, SAMP_K, l);
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-        if (key[e] >= t && key[e] != 0u) {
-            const int sidx = atomicAdd(&slot, 1);
-            if (sidx < SAMP_K) {
-                cand_val[blockIdx.x * SAMP_K + sidx] = h2f(raw[e]);
-                cand_idx[blockIdx.x * SAMP_K + sidx] = (int)(lo + tid * 4u + (u32)e);
-            }
+    if (w == 0) {  // top K of the 4 * K survivors
+        u32 k2[2] = {surv[l], surv[64u + l]};
+        const u32 t2 = wave_select_threshold<2, u32>(k2, 26, 10, SAMP_K);
+        __shared__ u32 fin[SAMP_K];
+        if (l < SAMP_K) fin[l] = 0u;
+        const int n = wave_compact<2, u32>(k2, t2, fin, SAMP_K, l);
+        if (l < SAMP_K) {
+            const u32 k = fin[l];
+            const bool ok = (int)l < n && k != 0u;
+            const u32 li = 1023u - (k & 1023u);
+            cand_val[blockIdx.x * SAMP_K + l] = ok ? h2f(unordered_key16(k >> 10)) : -3.0e38f;  // slice shorter than K: padded
+            cand_idx[blockIdx.x * SAMP_K + l] = ok ? (int)(lo + li) : -1;
         }
-    __syncthreads();
-    for (int i = slot + (int)tid; i < SAMP_K; i += 256) {  // slice shorter than K: pad
-        cand_val[blockIdx.x * SAMP_K + i] = -3.0e38f;
-        cand_idx[blockIdx.x * SAMP_K + i] = -1;
     }
 }
 
 // stage 2: one block, 4096 candidates (4 per thread), select the global top-k, then the exponential-race draw
 __global__ void __launch_bounds__(1024) sample_stage2(const float *cand_val, const int *cand_idx, int top_k, float temperature,
                                                       u32 seed, int *counter, int *tok_io, int *pos_io, int *next_tok) {
-    __shared__ int cnt[32];
     __shared__ float selv[SAMP_K];
     __shared__ int seli[SAMP_K];
+    __shared__ unsigned long long surv[16 * SAMP_K];
+    __shared__ unsigned long long fin[SAMP_K];
     __shared__ int slot;
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
     unsigned long long key[4];
-    float val[4];
-    int idx[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const u32 c = tid * 4u + (u32)e;
-        val[e] = cand_val[c];
-        idx[e] = cand_idx[c];
-        const uint16_t hb = __builtin_bit_cast(uint16_t, (h16)val[e]);  // candidates are fp16 values: exact
-        key[e] = idx[e] >= 0 ? (((unsigned long long)ordered_key16(hb) << 17) | (unsigned long long)(131071u - (u32)idx[e])) : 0ull;
+        const float v = cand_val[c];
+        const int id = cand_idx[c];
+        const uint16_t hb = __builtin_bit_cast(uint16_t, (h16)v);  // candidates are fp16 values: exact
+        key[e] = id >= 0 ? (((unsigned long long)ordered_key16(hb) << 17) | (unsigned long long)(131071u - (u32)id)) : 0ull;
     }
-    if (tid == 0) slot = 0;
     const int K = top_k < 1 ? 1 : (top_k > SAMP_K ? SAMP_K : top_k);
-    const unsigned long long t = select_threshold<16, 4, unsigned long long>(key, 33, K, cnt, w, l);
+    if (l < SAMP_K) surv[w * SAMP_K + l] = 0ull;
+    const unsigned long long t = wave_select_threshold<4, unsigned long long>(key, 33, 17, K);
+    wave_compact<4, unsigned long long>(key, t, surv + w * SAMP_K, SAMP_K, l);
     __syncthreads();
+    if (w == 0) {
+        unsigned long long k8[8];
 #pragma unroll
-    for (int e = 0; e < 4; e++)
-        if (key[e] >= t && key[e] != 0ull) {
-            const int sidx = atomicAdd(&slot, 1);
-            if (sidx < SAMP_K) {
-                selv[sidx] = val[e];
-                seli[sidx] = idx[e];
-            }
+        for (int e = 0; e < 8; e++) k8[e] = surv[(u32)e * 64u + l];
+        const unsigned long long t2 = wave_select_threshold<8, unsigned long long>(k8, 33, 17, K);
+        if (l < SAMP_K) fin[l] = 0ull;
+        const int n2 = wave_compact<8, unsigned long long>(k8, t2, fin, SAMP_K, l);
+        if (l == 0) slot = n2;
+        if (l < SAMP_K) {
+            const unsigned long long k = fin[l];
+            selv[l] = h2f(unordered_key16((u32)(k >> 17)));
+            seli[l] = (int)(131071u - (u32)(k & 131071ull));
         }
+    }
     __syncthreads();
     if (w == 0) {
         const int n = min(slot, K);

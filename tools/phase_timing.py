@@ -8,17 +8,23 @@ L = _lib.lib(); L.gq_set_ap_mode(0)
 L.gq_debug_set_timing_buffer.argtypes = [ctypes.c_void_p]
 d = torch.device("cuda:0")
 SH = {"wqkv": (6144, 4096), "wo": (4096, 4096), "w1w3": (28672, 4096), "w2": (4096, 14336)}
+FUSED = os.environ.get("PT_FUSED", "0") != "0"
 bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for name in sys.argv[2:] or list(SH):
     N, K = SH[name]
     qs = [torch.randint(-2**31, 2**31 - 1, (bits, N, K // 32), dtype=torch.int32, device=d) for _ in range(max(2, (600 << 20) // (bits * N * K // 8)))]
     lut = (torch.randn(N, 1 << bits, device=d) * 0.02).half()
     x = torch.randn(1, 1, K, device=d).half(); out = torch.empty(1, 1, N, dtype=torch.float16, device=d)
+    nw = (1 + 0.1 * torch.randn(K, device=d)).half()
     dbg = torch.zeros(128 + 256, dtype=torch.int64, device=d)
     for i, q in enumerate(qs):
         if i == len(qs) - 1:
             L.gq_debug_set_timing_buffer(dbg.data_ptr())
-        L.gq_anyprec_gemv(x.data_ptr(), out.data_ptr(), q.data_ptr(), lut.data_ptr(), 1, N, K, bits, 0, None)
+        if FUSED:  # the decode step's own launch: RMSNorm prologue (+ gate/up pair epilogue for w1w3)
+            L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), q.data_ptr(), lut.data_ptr(), N, K, bits, nw.data_ptr(), 1e-5, None,
+                                    4 if name == "w1w3" else 0, None)
+        else:
+            L.gq_anyprec_gemv(x.data_ptr(), out.data_ptr(), q.data_ptr(), lut.data_ptr(), 1, N, K, bits, 0, None)
     torch.cuda.synchronize(); L.gq_debug_set_timing_buffer(None)
     raw = dbg.cpu().numpy()
     t = raw[:128].reshape(16, 8)[:, [0, 6, 7, 1, 2, 3, 4, 5]]

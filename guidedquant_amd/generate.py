@@ -250,13 +250,13 @@ def _get_model_size(model):
 
 
 def benchmark_decode(model: Transformer, device, num_samples=5, max_new_tokens=100, top_k=32, temperature=0.0, seed=1234,
-                     bos_id=128000):
+                     bos_id=128000, native_sampling=False):
     """tokens/s as the reference measures it (generate.py:344-389): BOS-only prompt, one warm-up generate, then
     `num_samples` timed generate() calls; mean/std of tokens/s and model-level bandwidth."""
     torch.manual_seed(seed)
     prompt = torch.tensor([bos_id % model.config.vocab_size], dtype=torch.int32, device=device)
     model.setup_caches(1, 1 + max_new_tokens)
-    graph = DecodeGraph(model, device, temperature=temperature, top_k=top_k)
+    graph = DecodeGraph(model, device, native_sampling=native_sampling, temperature=temperature, top_k=top_k)
     tps = []
     for i in range(-1, num_samples):
         torch.cuda.synchronize()

@@ -24,5 +24,6 @@ if inter & (inter - 1) and not os.environ.get("GQ_HADAMARD_TABLES"):
 gm.transformer_configs["llama2-7b-pow2"] = dict(model_name="Llama-2-7b" if inter == 11008 else "Llama-2-7b-pow2", block_size=4096, n_layer=layers, n_head=32, n_local_heads=32,
                                                 dim=4096, intermediate_size=inter, vocab_size=32000, rope_base=10000)
 m = load_model("llama2-7b-pow2", "cuda:0", "qtip", 2, random_init=True)
-r = benchmark_decode(m, torch.device("cuda:0"), num_samples=2, max_new_tokens=50)
+r = benchmark_decode(m, torch.device("cuda:0"), num_samples=2, max_new_tokens=50,
+                     native_sampling=os.environ.get("GQ_TORCH_SAMPLING", "0") == "0")  # fused HIP sampler, as bench.py
 print(json.dumps({"model": "Llama-2-7b" if inter == 11008 else "Llama-2-7b-pow2", "native": m._native_kind(), "intermediate": inter, "layers": layers, **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()}}))

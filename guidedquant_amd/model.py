@@ -352,10 +352,18 @@ class Transformer(nn.Module):
         st["xs16"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)  # transformed input of the down projection
         keep = []  # fp32 copies the descriptors point into
 
+        tables = {}  # one fp32 device copy per distinct Hadamard factor table (every layer's module holds its own buffer)
+
         def f32(t, mul=1.0):
             t = (t.detach().to(dev).float() * mul).contiguous()
             keep.append(t)
             return t.data_ptr()
+
+        def table(t):
+            key = (tuple(t.shape), hash(t.detach().float().cpu().numpy().tobytes()))
+            if key not in tables:
+                tables[key] = f32(t)
+            return tables[key]
 
         def lin_in(mods):
             arr = (_lib.GqQtipIn * len(mods))()
@@ -381,9 +389,9 @@ class Transformer(nn.Module):
             if ff.w2.K_left != 1:  # MLP width with a Hadamard factor: transform kernels on that side (gq_qtip_transform)
                 y32 = st["y32"]
                 factor = dict(Kf=ff.w2.K_left,
-                              gu=(_lib.GqQtipXf * 2)(_lib.GqQtipXf(y32[0].data_ptr(), f32(ff.w1.SV, 32.0), f32(ff.w1.had_right), None, st["g"].data_ptr()),
-                                                      _lib.GqQtipXf(y32[1].data_ptr(), f32(ff.w3.SV, 32.0), f32(ff.w3.had_right), None, st["u"].data_ptr())),
-                              d=(_lib.GqQtipXf * 1)(_lib.GqQtipXf(None, f32(ff.w2.SU), f32(ff.w2.had_left), None, st["xs16"].data_ptr())))
+                              gu=(_lib.GqQtipXf * 2)(_lib.GqQtipXf(y32[0].data_ptr(), f32(ff.w1.SV, 32.0), table(ff.w1.had_right), None, st["g"].data_ptr()),
+                                                      _lib.GqQtipXf(y32[1].data_ptr(), f32(ff.w3.SV, 32.0), table(ff.w3.had_right), None, st["u"].data_ptr())),
+                              d=(_lib.GqQtipXf * 1)(_lib.GqQtipXf(None, f32(ff.w2.SU), table(ff.w2.had_left), None, st["xs16"].data_ptr())))
             layers.append(dict(
                 factor=factor,
                 qkv_in=lin_in([at.wq, at.wk, at.wv]),

@@ -15,7 +15,7 @@ _lib = None
 EXPORTS = [
     "gq_version", "gq_last_error", "gq_device_count", "gq_anyprec_gemv", "gq_anyprec_dequant", "gq_lutgemm_gemv",
     "gq_qtip_matvec", "gq_hadamard", "gq_anyprec_gemv_fused", "gq_set_ap_mode", "gq_embed_lookup", "gq_attn_decode",
-    "gq_dense_gemv_f16", "gq_sample_topk", "gq_qtip_linear_in", "gq_qtip_linear_out", "gq_qtip_transform",
+    "gq_dense_gemv_f16", "gq_sample_topk", "gq_qtip_linear_in", "gq_qtip_linear_out", "gq_qtip_transform", "gq_lutgemm_gemv_ws",
 ]
 
 
@@ -58,6 +58,7 @@ def lib():
         L.gq_anyprec_gemv.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, i32, vp]
         L.gq_anyprec_dequant.argtypes = [vp, vp, vp, u32, u32, i32, vp]
         L.gq_lutgemm_gemv.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, i32, vp]
+        L.gq_lutgemm_gemv_ws.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, i32, vp, ctypes.c_uint64, vp]
         L.gq_qtip_matvec.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp]
         L.gq_hadamard.argtypes = [vp, vp, u32, u32, f32, vp]
         L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, ctypes.POINTER(GqQtipOut), i32, vp]

@@ -87,6 +87,12 @@ int gq_anyprec_dequant(const uint32_t *qweight, const void *lut, void *W, uint32
  */
 int gq_lutgemm_gemv(const void *x, void *out, const uint32_t *qweight, const void *alpha, const void *q_bias,
                     uint32_t N, uint32_t K, int bits, int group_size, void *stream);
+/* Same result (bit for bit), two launches: the 4 x 256 sign-sum tables of every 32-activation tile depend only on x, so
+ * they are built once per call into `workspace` (64 bytes per input feature, 16-byte aligned, caller-owned scratch) and
+ * the GEMV blocks copy them to LDS instead of rebuilding them 64..448 times. */
+int gq_lutgemm_gemv_ws(const void *x, void *out, const uint32_t *qweight, const void *alpha, const void *q_bias,
+                       uint32_t N, uint32_t K, int bits, int group_size, void *workspace, uint64_t workspace_bytes,
+                       void *stream);
 
 /*
  * QTIP trellis-decoded matvec.  out[m] = sum_k decode(compressed)[m][k] * x[k]

@@ -8,10 +8,14 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("ws", ["1", "0"])
 @pytest.mark.parametrize("bits", [1, 2, 3, 4])
 @pytest.mark.parametrize("N,K,g", [(64, 256, 128), (512, 4096, 4096), (300, 1024, 32), (4096, 4096, 128)])
-def test_lutgemm_bit_exact(oracle, bits, N, K, g):
+def test_lutgemm_bit_exact(oracle, bits, N, K, g, ws, monkeypatch):
+    """ws = 1: tables built once into the scratch buffer + GEMV (gq_lutgemm_gemv_ws); ws = 0: the single kernel that
+    rebuilds them per block (gq_lutgemm_gemv).  Both bit-identical to the oracle."""
     from guidedquant_amd.LUTGEMMLinear import LUTGEMMLinear
+    monkeypatch.setenv("GQ_LUTGEMM_WS", ws)
     d = torch.device("cuda:0")
     rng = np.random.default_rng(bits * 100 + N + K)
     q = rng.integers(-2**31, 2**31, (K // 32, bits, N), dtype=np.int64).astype(np.int32)

@@ -74,6 +74,11 @@ def main():
         us = timed(lambda i: _lib.check(L.gq_lutgemm_gemv(x.data_ptr(), y.data_ptr(), qw[i].data_ptr(), alpha.data_ptr(), qb.data_ptr(), N, K, bits, gs, st()), "lutgemm"), n)
         b = per + alpha.numel() * 2 + qb.numel() * 2 + 2 * K + 2 * N
         out.append({"kernel": "lutgemm_gemv", "N": N, "K": K, "bits": bits, "us": round(us, 3), "GBps": round(b / us / 1e3, 1), "frac_of_8TBps": round(b / us / 8e6, 4)})
+        ws = torch.empty(K * 64, dtype=torch.uint8, device=d)
+        us = timed(lambda i: _lib.check(L.gq_lutgemm_gemv_ws(x.data_ptr(), y.data_ptr(), qw[i].data_ptr(), alpha.data_ptr(), qb.data_ptr(), N, K, bits, gs,
+                                                            ws.data_ptr(), ws.numel(), st()), "lutgemm ws"), n)
+        out.append({"kernel": "lutgemm_gemv_ws (tables once + GEMV)", "N": N, "K": K, "bits": bits, "us": round(us, 3), "GBps": round(b / us / 1e3, 1),
+                    "frac_of_8TBps": round(b / us / 8e6, 4)})
     # AP dequant (write-bound: 2 bytes per weight out)
     for N, K in ((4096, 4096), (28672, 4096)):
         bits = 2

@@ -128,7 +128,8 @@ def _lutgemm_workspace(device, K):
     import os
     if os.environ.get("GQ_LUTGEMM_WS", "1") == "0":
         return None
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    # one buffer per (device, stream): the tables kernel and the GEMV that reads them are ordered by the stream only
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
     ws = _LG_WS.get(key)
     if ws is None or ws.numel() < K * 64:
         if torch.cuda.is_current_stream_capturing():

@@ -276,8 +276,8 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     __shared__ float redf[17];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 K = a.K, T = blockDim.x, tid = threadIdx.x;
-    float *v = reinterpret_cast<float *>(smem);                 // [K] fp32 transform buffer
-    uint16_t *xs = reinterpret_cast<uint16_t *>(v + K);         // [K] fp16 matvec input
+    float *v = reinterpret_cast<float *>(smem);                 // [K] fp32 transform buffer (none for a pre-transformed input)
+    uint16_t *xs = reinterpret_cast<uint16_t *>(v + (PRO == QPRO_PRE ? 0u : K));  // [K] fp16 matvec input
     float *part = reinterpret_cast<float *>(xs + K);            // [waves][32]
     const u32 bid = blockIdx.x / a.ksplit, ks = blockIdx.x % a.ksplit;
     u32 li = 0;
@@ -573,7 +573,7 @@ extern "C" int gq_qtip_matvec(float *out, const uint32_t *compressed, const void
         static bool set = false;                                                                                      \
         if (smem > 48u * 1024u && !set) {                                                                             \
             GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_matvec_kernel<RR>),                  \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); /* + 2 KiB static */ \
             set = true;                                                                                               \
         }                                                                                                             \
         hipLaunchKernelGGL(qtip_matvec_kernel<RR>, grid, block, smem, s, out, compressed, (const uint16_t *)x,         \
@@ -634,7 +634,7 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
         a.prev[i] = QtipOut{prev[i].y32, prev[i].SV32, (const uint16_t *)prev[i].resid, (uint16_t *)prev[i].out, K, (float)pow((double)K, -0.5),
                             prev[i].parts == 2u ? 2u : 1u};
     }
-    const size_t smem = (size_t)K * 6u + (size_t)waves * 32u * 4u + (size_t)n_prev * K * 2u;  // <= 130 KiB for K <= 16384
+    const size_t smem = (size_t)K * (prologue == GQ_QPRO_PRETRANSFORMED ? 2u : 6u) + (size_t)waves * 32u * 4u + (size_t)n_prev * K * 2u;  // <= 130 KiB for K <= 16384
     if (smem > 150u * 1024u) return gq_fail(GQ_ENOTSUP, "gq_qtip_linear_in: K too large.");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bands * (u32)ksplit), block(waves * 64u);

@@ -374,19 +374,20 @@ def test_factor_transform_goldens(name):
         np.testing.assert_allclose(out2.float().cpu().numpy(), want_t, rtol=4e-3, atol=4e-3 * np.abs(want_t).max())
 
 
-def test_qtip_native_decode_with_factor_width(tmp_path, monkeypatch):
-    """MLP width 11008 = 172 * 64 (Llama-2-7b's): the table comes from the caller (GQ_HADAMARD_TABLES; here the golden
+@pytest.mark.parametrize("inter,key", [(11008, "had172"), (28672, "had28")])
+def test_qtip_native_decode_with_factor_width(tmp_path, monkeypatch, inter, key):
+    """MLP width 11008 = 172 * 64 (Llama-2-7b's) / 28672 = 28 * 1024 (Llama-2-70b's): the table comes from the caller (GQ_HADAMARD_TABLES; here the golden
     fixture's copy).  Native decode (fused kernels on the power-of-two sides, gq_qtip_transform + gq_qtip_matvec on the
     factor side) against the module-by-module forward."""
     import os
     from guidedquant_amd import model as gm, qtip
     from guidedquant_amd.generate import load_model
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "had_n11008.npz"))
-    np.savez(tmp_path / "tables.npz", had172=g["hadK"])
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "had_n11008.npz" if key == "had172" else "had_n14336.npz"))
+    np.savez(tmp_path / "tables.npz", **{key: g["hadK"]})
     monkeypatch.setenv("GQ_HADAMARD_TABLES", str(tmp_path / "tables.npz"))
     qtip._tables = None
     gm.transformer_configs["qtip-factor-test"] = dict(model_name="llama-qtip-factor-test", block_size=128, vocab_size=512, n_layer=2,
-                                                      n_head=8, dim=1024, intermediate_size=11008, n_local_heads=8)
+                                                      n_head=8, dim=1024, intermediate_size=inter, n_local_heads=8)
     try:
         m = load_model("qtip-factor-test", "cuda:0", "qtip", 2, random_init=True)
     finally:

@@ -448,7 +448,7 @@ struct QtipXfLin {
 };
 struct QtipXfArgs {
     const uint16_t *x, *x2, *normw;
-    QtipXfLin lin[2];   // blockIdx.y (OUT: gate and up in one launch)
+    QtipXfLin lin[3];   // blockIdx.y (linears that share the source / the launch)
     float eps, nscale;  // nscale = (float)n^-1/2
     u32 n, Kf, P, RB, in, pro, transpose;
 };
@@ -691,8 +691,7 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
 
 extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, const void *norm_weight, float eps, int prologue,
                                  int n_lin, const GqQtipXf *lin, uint32_t n, uint32_t Kf, int transpose, void *stream) {
-    if (!lin || n_lin < 1 || n_lin > 2 || Kf < 2u || n == 0 || n % Kf) return gq_fail(GQ_EINVAL, "gq_qtip_transform: 1..2 linears; n a multiple of Kf.");
-    if (input_side && n_lin != 1) return gq_fail(GQ_EINVAL, "gq_qtip_transform: one linear on the input side.");
+    if (!lin || n_lin < 1 || n_lin > 3 || Kf < 2u || n == 0 || n % Kf) return gq_fail(GQ_EINVAL, "gq_qtip_transform: 1..3 linears; n a multiple of Kf.");
     const u32 P = n / Kf;
     if (!pow2(P) || P < 64u || n > 32768u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n / Kf must be a power of two >= 64, n <= 32768.");
     if (input_side && (!x || (prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2) || prologue < 0 || prologue > 2))

@@ -300,18 +300,17 @@ class Transformer(nn.Module):
 
             p2 = lambda n: n > 0 and (n & (n - 1)) == 0  # noqa: E731
 
-            def ok(m, factor_in=False, factor_out=False):
-                # model widths: power of two (fused transform), or -- the MLP width only -- Kf * 2^p with the caller's
-                # Hadamard factor table loaded (gq_qtip_transform; e.g. 11008 = 172 * 64)
-                def side(nf, K, had, allow):
-                    return p2(nf) if K == 1 else (allow and had is not None and p2(nf // K) and nf // K >= 64 and nf <= 32768)
+            def ok(m):
+                # widths: power of two (fused transform), or Kf * 2^p with the caller's Hadamard factor table loaded
+                # (gq_qtip_transform; e.g. 11008 = 172 * 64, 5120 = 20 * 256)
+                def side(nf, K, had):
+                    return p2(nf) if K == 1 else (had is not None and p2(nf // K) and nf // K >= 64 and nf <= 32768)
                 return (isinstance(m, QuantizedLinear) and m.bias is None and m.has_kernel and int(m.rcp.item()) == 0
-                        and side(m.in_features, m.K_left, m.had_left, factor_in) and side(m.out_features, m.K_right, m.had_right, factor_out)
+                        and side(m.in_features, m.K_left, m.had_left) and side(m.out_features, m.K_right, m.had_right)
                         and 32 <= m.in_features and (m.in_features <= 16384 or m.K_left != 1) and m.out_features <= 32768)
-            if self.config.head_dim in (64, 128) and p2(self.config.dim) and all(
-                    all(ok(m) for m in (b.attention.wq, b.attention.wk, b.attention.wv, b.attention.wo))
-                    and ok(b.feed_forward.w1, factor_out=True) and ok(b.feed_forward.w3, factor_out=True)
-                    and ok(b.feed_forward.w2, factor_in=True) for b in self.layers):
+            if self.config.head_dim in (64, 128) and all(
+                    ok(m) for b in self.layers for m in (b.attention.wq, b.attention.wk, b.attention.wv, b.attention.wo,
+                                                         b.feed_forward.w1, b.feed_forward.w3, b.feed_forward.w2)):
                 kind = "qtip"
         self._native_kind_cache = kind
         return kind or None
@@ -339,9 +338,11 @@ class Transformer(nn.Module):
         return self._native
 
     def _native_qtip_state(self, st):
-        """descriptor arrays of the fused QTIP linears (gq_qtip_linear_in / _out), per layer: (qkv in, qkv out, o in, o out,
-        gate/up in, gate/up out, down in, down out).  SU as fp32, SV * 32 as fp32 (the values BitshiftLinear.forward
-        multiplies with, bitshift.py:441,470); q/k/v land in the packed buffer the attention kernel reads."""
+        """launch plans of the QTIP linears, per layer four groups of linears that share an input -- (q, k, v), (o),
+        (gate, up), (down) -- each a list of (entry point name, argument tuple) built once: SU as fp32, SV * 32 as fp32 (the
+        values BitshiftLinear.forward multiplies with, bitshift.py:441,470), q/k/v landing in the packed buffer the
+        attention kernel reads.  Per side of a linear: power-of-two width -> the fused kernels (gq_qtip_linear_in / _out);
+        width with a Hadamard factor -> gq_qtip_transform around the bare matvec (GQ_QPRO_PRETRANSFORMED)."""
         c = self.config
         dev = self.output.weight.device
         kv = c.n_local_heads * c.head_dim
@@ -349,9 +350,8 @@ class Transformer(nn.Module):
         st["u"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
         mmax = max(c.dim, c.intermediate_size)
         st["y32"] = torch.zeros(3, 2 * mmax, dtype=torch.float32, device=dev)  # [linear][split-K part][M]
-        st["xs16"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)  # transformed input of the down projection
-        keep = []  # fp32 copies the descriptors point into
-
+        st["xs16"] = torch.zeros(3, mmax, dtype=torch.float16, device=dev)     # transformed inputs (factor widths)
+        keep = []    # fp32 copies and descriptor arrays the plans point into
         tables = {}  # one fp32 device copy per distinct Hadamard factor table (every layer's module holds its own buffer)
 
         def f32(t, mul=1.0):
@@ -365,92 +365,89 @@ class Transformer(nn.Module):
                 tables[key] = f32(t)
             return tables[key]
 
-        def lin_in(mods):
-            arr = (_lib.GqQtipIn * len(mods))()
-            for i, m in enumerate(mods):
-                arr[i] = _lib.GqQtipIn(m.trellis.data_ptr(), f32(m.SU), m.tlut.data_ptr(), st["y32"][i].data_ptr(), m.out_features)
-            return arr
-
         def ksplit(m):  # fewer 32-row bands than half the CUs (wo, down): two blocks per band, each over half of K
             return 2 if m.out_features // 32 <= 128 and os.environ.get("GQ_QTIP_KSPLIT", "1") != "0" else 1
 
-        def lin_out(mods, outs, resid, parts=1):
-            arr = (_lib.GqQtipOut * len(mods))()
-            for i, m in enumerate(mods):
-                arr[i] = _lib.GqQtipOut(st["y32"][i].data_ptr(), f32(m.SV, 32.0), resid, outs[i], m.out_features, parts)
-            return arr
+        y32, xs16 = st["y32"], st["xs16"]
+
+        def group(mods, xp, x2p, normw, pro, outs, resid):
+            """launches of one group: mods share the input vector xp (x2p for silu*mul); outs[i] fp16 destinations"""
+            R, K = mods[0].K, mods[0].in_features
+            plan = []
+            # split-K partial sums are added by the fused transform-out only: single linears with a power-of-two output width
+            ks = ksplit(mods[0]) if len(mods) == 1 and mods[0].K_right == 1 else 1
+            if mods[0].K_left == 1:  # fused transform-in + matvec, all linears in one launch
+                arr = (_lib.GqQtipIn * len(mods))(*[_lib.GqQtipIn(m.trellis.data_ptr(), f32(m.SU), m.tlut.data_ptr(), y32[i].data_ptr(), m.out_features)
+                                                    for i, m in enumerate(mods)])
+                keep.append(arr)
+                plan.append(("gq_qtip_linear_in", (xp, x2p, normw, c.norm_eps, pro, K, R, len(mods), arr, 0, None, ks)))
+            else:  # factor transform of the shared input (one launch), then the bare matvec per linear
+                xf = (_lib.GqQtipXf * len(mods))(*[_lib.GqQtipXf(None, f32(m.SU), table(m.had_left), None, xs16[i].data_ptr())
+                                                   for i, m in enumerate(mods)])
+                keep.append(xf)
+                plan.append(("gq_qtip_transform", (1, xp, x2p, normw, c.norm_eps, pro, len(mods), xf, K, mods[0].K_left, 1)))
+                for i, m in enumerate(mods):
+                    arr = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(m.trellis.data_ptr(), None, m.tlut.data_ptr(), y32[i].data_ptr(), m.out_features))
+                    keep.append(arr)
+                    plan.append(("gq_qtip_linear_in", (xs16[i].data_ptr(), None, None, 0.0, 3, K, R, 1, arr, 0, None, ks)))
+            p2 = [i for i, m in enumerate(mods) if m.K_right == 1]
+            fac = [i for i, m in enumerate(mods) if m.K_right != 1]
+            if p2:
+                arr = (_lib.GqQtipOut * len(p2))(*[_lib.GqQtipOut(y32[i].data_ptr(), f32(mods[i].SV, 32.0), resid, outs[i], mods[i].out_features, ks)
+                                                   for i in p2])
+                keep.append(arr)
+                plan.append(("gq_qtip_linear_out", (len(p2), arr)))
+            for Kf, M in sorted({(mods[i].K_right, mods[i].out_features) for i in fac}):
+                idx = [i for i in fac if (mods[i].K_right, mods[i].out_features) == (Kf, M)]
+                xf = (_lib.GqQtipXf * len(idx))(*[_lib.GqQtipXf(y32[i].data_ptr(), f32(mods[i].SV, 32.0), table(mods[i].had_right), resid, outs[i])
+                                                  for i in idx])
+                keep.append(xf)
+                plan.append(("gq_qtip_transform", (0, None, None, None, 0.0, 0, len(idx), xf, M, Kf, 0)))
+            return plan
 
         x, h, y, qkv = st["x"], st["h"], st["y"], st["qkv"]
         e = qkv.element_size()
         layers = []
         for b in self.layers:
             at, ff = b.attention, b.feed_forward
-            factor = None
-            if ff.w2.K_left != 1:  # MLP width with a Hadamard factor: transform kernels on that side (gq_qtip_transform)
-                y32 = st["y32"]
-                factor = dict(Kf=ff.w2.K_left,
-                              gu=(_lib.GqQtipXf * 2)(_lib.GqQtipXf(y32[0].data_ptr(), f32(ff.w1.SV, 32.0), table(ff.w1.had_right), None, st["g"].data_ptr()),
-                                                      _lib.GqQtipXf(y32[1].data_ptr(), f32(ff.w3.SV, 32.0), table(ff.w3.had_right), None, st["u"].data_ptr())),
-                              d=(_lib.GqQtipXf * 1)(_lib.GqQtipXf(None, f32(ff.w2.SU), table(ff.w2.had_left), None, st["xs16"].data_ptr())))
             layers.append(dict(
-                factor=factor,
-                qkv_in=lin_in([at.wq, at.wk, at.wv]),
-                qkv_out=lin_out([at.wq, at.wk, at.wv], [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e], None),
-                o_in=lin_in([at.wo]), o_out=lin_out([at.wo], [h.data_ptr()], x.data_ptr(), ksplit(at.wo)), ks_o=ksplit(at.wo),
-                gu_in=lin_in([ff.w1, ff.w3]), gu_out=lin_out([ff.w1, ff.w3], [st["g"].data_ptr(), st["u"].data_ptr()], None),
-                d_in=lin_in([ff.w2]), d_out=lin_out([ff.w2], [x.data_ptr()], h.data_ptr(), ksplit(ff.w2)), ks_d=ksplit(ff.w2), R=at.wq.K))
+                qkv=group([at.wq, at.wk, at.wv], x.data_ptr(), None, b.input_layernorm.weight.data_ptr(), 1,
+                          [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e], None),
+                o=group([at.wo], y.data_ptr(), None, None, 0, [h.data_ptr()], x.data_ptr()),
+                gu=group([ff.w1, ff.w3], h.data_ptr(), None, b.post_attention_layernorm.weight.data_ptr(), 1,
+                         [st["g"].data_ptr(), st["u"].data_ptr()], None),
+                d=group([ff.w2], st["g"].data_ptr(), st["u"].data_ptr(), None, 2, [x.data_ptr()], h.data_ptr())))
         st["qtip_layers"] = layers
         st["qtip_keep"] = keep
 
     def _native_layers_qtip(self, x: Tensor, pos: Tensor, l0: int, l1: int, slot: int = 0):
         """one decode step of layers [l0, l1) of an unfused QTIP model (A = transform-in + trellis matvec, B = transform-out):
         A(q,k,v | RMSNorm) B(q,k,v) attention A(o) B(o + residual) A(gate,up | RMSNorm) B(gate,up) A(down | silu*mul)
-        B(down + residual) -- 9 launches per layer, 6 with the B of o, gate/up and down folded into the A that consumes
-        it (GQ_NATIVE_QTIP_FOLD; bit-identical, measured slower, default off)"""
+        B(down + residual) -- 9 launches per layer with power-of-two widths; a width with a Hadamard factor replaces the A / B
+        on its side by gq_qtip_transform (+ the bare matvec): 11 launches for Llama-2-7b / 70b (MLP width only)."""
         L = _lib.lib()
         sp = _lib.current_stream_ptr()
         c = self.config
         b = self._native_state()
-        assert x.data_ptr() == b["x"].data_ptr(), "the QTIP descriptors are bound to the model's own hidden-state buffer"
-        h, y, qkv, g, u = b["h"], b["y"], b["qkv"], b["g"], b["u"]
+        assert x.data_ptr() == b["x"].data_ptr(), "the QTIP launch plans are bound to the model's own hidden-state buffer"
+        y, qkv = b["y"], b["qkv"]
         ck = _lib.check
         scale = 1.0 / math.sqrt(c.head_dim)
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2
-        # transform-out folded into the consuming kernel: bit-identical, 3 launches per layer fewer, but every block repeats
-        # the producer's transform -- measured slower (222 vs 243 tokens/s on the 7B-like model), so off by default
-        fold = os.environ.get("GQ_NATIVE_QTIP_FOLD", "0") != "0" and all(d["factor"] is None for d in b["qtip_layers"])
+
+        def run(plan):
+            for name, args in plan:
+                ck(getattr(L, name)(*args, sp), name)
+
         for li in range(l0, l1):
-            blk, d = self.layers[li], b["qtip_layers"][li]
-            at = blk.attention
-            carry = fold and li > l0  # the hidden state is still the previous layer's untransformed down projection
-            ck(L.gq_qtip_linear_in(x.data_ptr(), None, blk.input_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 3,
-                                   d["qkv_in"], 1 if carry else 0, b["qtip_layers"][li - 1]["d_out"] if carry else None, 1, sp), "qtip qkv in")
-            ck(L.gq_qtip_linear_out(3, d["qkv_out"], sp), "qtip qkv out")
+            d, at = b["qtip_layers"][li], self.layers[li].attention
+            run(d["qkv"])
             ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
                                 at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
                                 y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, sp), "attn")
-            ck(L.gq_qtip_linear_in(y.data_ptr(), None, None, 0.0, 0, c.dim, d["R"], 1, d["o_in"], 0, None, d["ks_o"], sp), "qtip o in")
-            if not fold:
-                ck(L.gq_qtip_linear_out(1, d["o_out"], sp), "qtip o out")
-            ck(L.gq_qtip_linear_in(h.data_ptr(), None, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, 1, c.dim, d["R"], 2,
-                                   d["gu_in"], 1 if fold else 0, d["o_out"] if fold else None, 1, sp), "qtip gate/up in")
-            fa = d["factor"]
-            if fa is not None:
-                # MLP width = Kf * 2^p: gate/up outputs and the down input go through the factor transform kernels
-                ff = blk.feed_forward
-                y32 = b["y32"]
-                ck(L.gq_qtip_transform(0, None, None, None, 0.0, 0, 2, fa["gu"], c.intermediate_size, fa["Kf"], 0, sp), "qtip gate/up out")
-                ck(L.gq_qtip_transform(1, g.data_ptr(), u.data_ptr(), None, 0.0, 2, 1, fa["d"], c.intermediate_size, fa["Kf"], 1, sp), "qtip down in")
-                ck(L.gq_qtip_linear_in(b["xs16"].data_ptr(), None, None, 0.0, 3, c.intermediate_size, d["R"], 1, d["d_in"], 0, None, d["ks_d"], sp),
-                   "qtip down matvec")
-                ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
-                continue
-            if not fold:
-                ck(L.gq_qtip_linear_out(2, d["gu_out"], sp), "qtip gate/up out")
-            ck(L.gq_qtip_linear_in(g.data_ptr(), u.data_ptr(), None, 0.0, 2, c.intermediate_size, d["R"], 1, d["d_in"],
-                                   2 if fold else 0, d["gu_out"] if fold else None, d["ks_d"], sp), "qtip down in")
-            if not fold or li == l1 - 1:
-                ck(L.gq_qtip_linear_out(1, d["d_out"], sp), "qtip down out")
+            run(d["o"])
+            run(d["gu"])
+            run(d["d"])
 
     def native_embed(self, tok: Tensor, x: Tensor):
         _lib.check(_lib.lib().gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), self.config.dim,

@@ -160,7 +160,8 @@ int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
  * view, then hadK @ rows (transpose != 0: hadK^T @, matmul_hadUt).  Such a linear runs transform -> gq_qtip_matvec ->
  * transform (the Kf x Kf product is too much to repeat in every block of the fused kernel).
  *   input_side != 0:  out fp16 [n] = half(H(pro(x) * vec) * n^-1/2 / 32),  vec = SU f32 [n], pro as GQ_QPRO_* (x2 / norm_weight)
- *   input_side == 0:  out fp16 [n] = half(H(y32) * n^-1/2 * vec) (+ resid),  vec = SV * 32 f32 [n]; up to 2 linears per launch
+ *   input_side == 0:  out fp16 [n] = half(H(y32) * n^-1/2 * vec) (+ resid),  vec = SV * 32 f32 [n]
+ * Up to 3 linears per launch (same n, Kf; input side: same x, their own SU / table / out).
  * hadK f32 [Kf][Kf] is the caller's table (the reference's data, not shipped here); P a power of two >= 64.
  */
 typedef struct GqQtipXf {

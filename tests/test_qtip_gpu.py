@@ -307,12 +307,10 @@ def test_fused_linear_validation():
         _lib.check(L.gq_qtip_linear_in(x.data_ptr(), None, None, 0.0, 1, 128, 2, 1, ain, 0, None, 1, None), "in")
 
 
-@pytest.mark.parametrize("fold", ["1", "0"])
-def test_qtip_native_decode_matches_module_forward(fold, monkeypatch):
-    """the native QTIP decode step (Transformer.decode_native; 6 launches per layer folded, 9 unfolded) against the
-    module-by-module forward of the same model: logits agree to fp16 rounding noise, greedy tokens agree"""
+def test_qtip_native_decode_matches_module_forward():
+    """the native QTIP decode step (Transformer.decode_native; 9 launches per layer) against the module-by-module forward
+    of the same model: logits agree to fp16 rounding noise, greedy tokens agree"""
     import os
-    monkeypatch.setenv("GQ_NATIVE_QTIP_FOLD", fold)
     from guidedquant_amd import model as gm
     from guidedquant_amd.generate import load_model
     gm.transformer_configs["qtip-native-test"] = dict(model_name="llama-qtip-native-test", block_size=128, vocab_size=512, n_layer=3,
@@ -397,6 +395,44 @@ def test_qtip_native_decode_with_factor_width(tmp_path, monkeypatch, inter, key)
         m.setup_caches(max_batch_size=1, max_seq_length=64)
     assert m._native_kind() == "qtip"
     toks = [3, 77, 401]
+    ref = []
+    with torch.no_grad():
+        for p, t in enumerate(toks):
+            ref.append(m(torch.tensor([[t]], dtype=torch.int32, device="cuda:0"), torch.tensor([p], dtype=torch.int32, device="cuda:0"))
+                       .float().reshape(-1).clone())
+        for b in m.layers:
+            b.attention.kv_cache.k_cache.zero_()
+            b.attention.kv_cache.v_cache.zero_()
+        for p, t in enumerate(toks):
+            got = m.decode_native(torch.tensor([t], dtype=torch.int32, device="cuda:0"),
+                                  torch.tensor([p], dtype=torch.int32, device="cuda:0")).float().reshape(-1)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(got).all())
+            err = float(torch.abs(got - ref[p]).max()) / (float(torch.abs(ref[p]).max()) + 1e-9)
+            assert err < 2e-2, err
+
+
+def test_qtip_native_decode_with_factor_hidden_size(tmp_path, monkeypatch):
+    """hidden size AND MLP width with Hadamard factors (the Llama-2-13b pattern: 5120 = 40 * 128, 13824 = 108 * 128; here
+    2560 = 40 * 64 and 6912 = 108 * 64): every linear runs transform -> bare matvec -> transform.  The tables are the
+    caller's data; any +-1 matrix exercises the arithmetic, so the test makes its own."""
+    from guidedquant_amd import model as gm, qtip
+    from guidedquant_amd.generate import load_model
+    rng = np.random.default_rng(3)
+    np.savez(tmp_path / "tables.npz", had40=rng.choice([-1, 1], (40, 40)).astype(np.int8), had108=rng.choice([-1, 1], (108, 108)).astype(np.int8))
+    monkeypatch.setenv("GQ_HADAMARD_TABLES", str(tmp_path / "tables.npz"))
+    qtip._tables = None
+    gm.transformer_configs["qtip-factor13-test"] = dict(model_name="llama-qtip-factor13-test", block_size=128, vocab_size=512, n_layer=2,
+                                                        n_head=20, dim=2560, intermediate_size=6912, n_local_heads=20)
+    try:
+        m = load_model("qtip-factor13-test", "cuda:0", "qtip", 2, random_init=True)
+    finally:
+        del gm.transformer_configs["qtip-factor13-test"]
+        qtip._tables = None
+    with torch.device("cuda:0"):
+        m.setup_caches(max_batch_size=1, max_seq_length=64)
+    assert m._native_kind() == "qtip"
+    toks = [9, 100]
     ref = []
     with torch.no_grad():
         for p, t in enumerate(toks):

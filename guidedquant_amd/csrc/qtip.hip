@@ -311,19 +311,20 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     // The input vectors are requested first (registers), the first tile blocks of the band behind them, and the prologue
     // runs while those are on their way from HBM (vector memory returns in order: requested the other way round, the
     // first use of x would wait for the tiles).
-    constexpr u32 NX = 8;
-    const bool inreg = !a.nprev && K <= NX * T && PRO != QPRO_PRE;
-    uint16_t xr[NX], x2r[NX], nwr[NX];
-    float sur[NX];
+    constexpr u32 NU = 2;  // 8-element units per thread held in registers (K <= 16 T)
+    const bool inreg = !a.nprev && K <= 8u * NU * T && PRO != QPRO_PRE && !(((uintptr_t)xg | (uintptr_t)x2g | (uintptr_t)a.normw | (uintptr_t)L.SU) & 15u);
+    uint4 xq[NU], x2q[NU], nwq[NU];
+    float4 su0[NU], su1[NU];
     if (inreg) {
 #pragma unroll
-        for (u32 k = 0; k < NX; k++) {
-            const u32 i = tid + k * T;
-            const bool ok = i < K;
-            xr[k] = ok ? xg[i] : (uint16_t)0;
-            sur[k] = ok ? L.SU[i] : 0.f;
-            if constexpr (PRO == QPRO_RMSNORM) nwr[k] = ok ? a.normw[i] : (uint16_t)0;
-            if constexpr (PRO == QPRO_SILUMUL) x2r[k] = ok ? x2g[i] : (uint16_t)0;
+        for (u32 k = 0; k < NU; k++) {
+            const u32 u = tid + k * T;
+            const bool ok = u < K / 8u;
+            xq[k] = ok ? reinterpret_cast<const uint4 *>(xg)[u] : make_uint4(0u, 0u, 0u, 0u);
+            su0[k] = ok ? reinterpret_cast<const float4 *>(L.SU)[2u * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            su1[k] = ok ? reinterpret_cast<const float4 *>(L.SU)[2u * u + 1u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PRO == QPRO_RMSNORM) nwq[k] = ok ? reinterpret_cast<const uint4 *>(a.normw)[u] : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (PRO == QPRO_SILUMUL) x2q[k] = ok ? reinterpret_cast<const uint4 *>(x2g)[u] : make_uint4(0u, 0u, 0u, 0u);
         }
     }
     auto prologue = [&]() {
@@ -339,15 +340,21 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
             float ss = 0.f;
             if (inreg) {
 #pragma unroll
-                for (u32 k = 0; k < NX; k++) {  // (elements beyond K are zero)
-                    const float f = (float)__builtin_bit_cast(h16, xr[k]);
-                    ss += f * f;
+                for (u32 k = 0; k < NU; k++) {  // (units beyond K are zero)
+                    const u32 w4[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float f = (float)__builtin_bit_cast(h16, (uint16_t)(w4[e >> 1] >> (16 * (e & 1))));
+                        ss += f * f;
+                    }
                 }
-            } else {
-                for (u32 i = tid; i < K; i += T) {
-                    const float f = (float)__builtin_bit_cast(h16, xg[i]);
-                    ss += f * f;
-                }
+            } else {  // same elements per thread, same order (the two forms give the same sum bit for bit)
+                for (u32 u = tid; u < K / 8u; u += T)
+#pragma unroll
+                    for (u32 e = 0; e < 8; e++) {
+                        const float f = (float)__builtin_bit_cast(h16, xg[8u * u + e]);
+                        ss += f * f;
+                    }
             }
             for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
             if ((tid & 63u) == 0) redf[tid >> 6] = ss;
@@ -371,9 +378,23 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         };
         if (inreg) {
 #pragma unroll
-            for (u32 k = 0; k < NX; k++) {
-                const u32 i = tid + k * T;
-                if (i < K) v[i] = elem(xr[k], PRO == QPRO_SILUMUL ? x2r[k] : (uint16_t)0, PRO == QPRO_RMSNORM ? nwr[k] : (uint16_t)0, sur[k]);
+            for (u32 k = 0; k < NU; k++) {
+                const u32 u = tid + k * T;
+                if (u < K / 8u) {
+                    const u32 xw[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
+                    const u32 x2w[4] = {PRO == QPRO_SILUMUL ? x2q[k].x : 0u, PRO == QPRO_SILUMUL ? x2q[k].y : 0u, PRO == QPRO_SILUMUL ? x2q[k].z : 0u,
+                                        PRO == QPRO_SILUMUL ? x2q[k].w : 0u};
+                    const u32 nw[4] = {PRO == QPRO_RMSNORM ? nwq[k].x : 0u, PRO == QPRO_RMSNORM ? nwq[k].y : 0u, PRO == QPRO_RMSNORM ? nwq[k].z : 0u,
+                                       PRO == QPRO_RMSNORM ? nwq[k].w : 0u};
+                    const float su[8] = {su0[k].x, su0[k].y, su0[k].z, su0[k].w, su1[k].x, su1[k].y, su1[k].z, su1[k].w};
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        o[e] = elem((uint16_t)(xw[e >> 1] >> (16 * (e & 1))), (uint16_t)(x2w[e >> 1] >> (16 * (e & 1))),
+                                    (uint16_t)(nw[e >> 1] >> (16 * (e & 1))), su[e]);
+                    reinterpret_cast<float4 *>(v)[2u * u] = make_float4(o[0], o[1], o[2], o[3]);
+                    reinterpret_cast<float4 *>(v)[2u * u + 1u] = make_float4(o[4], o[5], o[6], o[7]);
+                }
             }
         } else {
             for (u32 i = tid; i < K; i += T)
@@ -486,23 +507,36 @@ __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
             __syncthreads();
             rs = redf[16];
         }
-        for (u32 i = tid; i < n; i += T) {
-            h16 xh = __builtin_bit_cast(h16, a.x[i]);
-            if (a.pro == QPRO_RMSNORM) xh = (h16)gq_pin_f32((float)xh * rs) * __builtin_bit_cast(h16, a.normw[i]);
-            if (a.pro == QPRO_SILUMUL) {
-                const float g = (float)xh;
-                xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, a.x2[i]);
+        for (u32 u = tid; u < n / 8u; u += T) {  // 8 activations per 16-byte load
+            const uint4 xq = reinterpret_cast<const uint4 *>(a.x)[u];
+            uint4 x2q = make_uint4(0u, 0u, 0u, 0u), nwq = x2q;
+            if (a.pro == QPRO_SILUMUL) x2q = reinterpret_cast<const uint4 *>(a.x2)[u];
+            if (a.pro == QPRO_RMSNORM) nwq = reinterpret_cast<const uint4 *>(a.normw)[u];
+            const float4 s0 = reinterpret_cast<const float4 *>(L.vec)[2u * u], s1 = reinterpret_cast<const float4 *>(L.vec)[2u * u + 1u];
+            const u32 xw[4] = {xq.x, xq.y, xq.z, xq.w}, x2w[4] = {x2q.x, x2q.y, x2q.z, x2q.w}, nw[4] = {nwq.x, nwq.y, nwq.z, nwq.w};
+            const float su[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                h16 xh = __builtin_bit_cast(h16, (uint16_t)(xw[e >> 1] >> (16 * (e & 1))));
+                if (a.pro == QPRO_RMSNORM)
+                    xh = (h16)gq_pin_f32((float)xh * rs) * __builtin_bit_cast(h16, (uint16_t)(nw[e >> 1] >> (16 * (e & 1))));
+                if (a.pro == QPRO_SILUMUL) {
+                    const float g = (float)xh;
+                    xh = (h16)(g / (1.0f + __expf(-g))) * __builtin_bit_cast(h16, (uint16_t)(x2w[e >> 1] >> (16 * (e & 1))));
+                }
+                o[e] = (float)xh * su[e];
             }
-            v[i] = (float)xh * L.vec[i];
+            reinterpret_cast<float4 *>(v)[2u * u] = make_float4(o[0], o[1], o[2], o[3]);
+            reinterpret_cast<float4 *>(v)[2u * u + 1u] = make_float4(o[4], o[5], o[6], o[7]);
         }
     } else {
-        for (u32 i = tid; i < n; i += T) v[i] = L.y32[i];
+        for (u32 i = tid; i < n / 4u; i += T) reinterpret_cast<float4 *>(v)[i] = reinterpret_cast<const float4 *>(L.y32)[i];
     }
     __syncthreads();
     fwht_lds(v, n, P);  // every row of the [Kf][P] view
-    // hadamard() scales by n^-1/2 before the factor product (matmul_had.py:88-90): same rounding points here
-    for (u32 i = tid; i < n; i += T) v[i] = v[i] * a.nscale;
-    __syncthreads();
+    // (hadamard() scales by n^-1/2 before the factor product, matmul_had.py:88-90; here the factor entries are +-1, the
+    // scale is applied to the sum -- one rounding less, one pass over the vector less)
     // factor product: thread (p, kq) adds its share of the k range into the (up to 4) rows of column p -- one LDS read of
     // the activation and one 16-byte read of the 4 factor entries per 4 multiply-adds --; the KQ partial sums are added in
     // a fixed order
@@ -529,6 +563,7 @@ __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
         if (kr >= Kf) continue;
         float acc = 0.f;
         for (u32 q = 0; q < KQ; q++) acc += ps[(q * RB + rr) * P + p];
+        acc *= a.nscale;
         const u32 i = kr * P + p;
         h16 y;
         if (a.in) y = (h16)(acc / 32.0f);
@@ -696,11 +731,13 @@ extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, 
     if (!pow2(P) || P < 64u || n > 32768u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n / Kf must be a power of two >= 64, n <= 32768.");
     if (input_side && (!x || (prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2) || prologue < 0 || prologue > 2))
         return gq_fail(GQ_EINVAL, "gq_qtip_transform: source operand missing.");
+    if (((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)norm_weight) & 15u) return gq_fail(GQ_EINVAL, "gq_qtip_transform: buffers must be 16-byte aligned.");
     QtipXfArgs a{};
     a.x = (const uint16_t *)x;
     a.x2 = (const uint16_t *)x2;
     a.normw = (const uint16_t *)norm_weight;
     for (int i = 0; i < n_lin; i++) {
+        if (((uintptr_t)lin[i].y32 | (uintptr_t)lin[i].vec) & 15u) return gq_fail(GQ_EINVAL, "gq_qtip_transform: buffers must be 16-byte aligned.");
         if (!lin[i].vec || !lin[i].out || !lin[i].hadK || (!input_side && !lin[i].y32)) return gq_fail(GQ_EINVAL, "gq_qtip_transform: null pointer argument.");
         a.lin[i] = QtipXfLin{lin[i].y32, lin[i].vec, lin[i].hadK, (const uint16_t *)lin[i].resid, (uint16_t *)lin[i].out};
     }

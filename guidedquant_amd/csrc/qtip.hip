@@ -418,19 +418,29 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     float *v = reinterpret_cast<float *>(smem);
     const QtipOut L = a.lin[blockIdx.x];
     const u32 T = blockDim.x, tid = threadIdx.x, M = L.M;
-    for (u32 i = tid; i < M; i += T) v[i] = L.parts == 2u ? L.y32[i] + L.y32[M + i] : L.y32[i];
-    // the scale and residual vectors are requested before the transform (one block: nothing else hides their latency)
-    constexpr u32 PRE = 8;  // M <= 8192 at 1024 threads
-    float svr[PRE];
-    uint16_t rsr[PRE];
-    const bool pre = M <= PRE * T;
+    // 4 consecutive outputs per thread and step: 16-byte loads of the sums, the scales and (8 bytes) the residual, all
+    // requested before the transform (one block: nothing else hides their latency)
+    constexpr u32 PRE = 2;  // M <= 8192 at 1024 threads
+    const bool vec = !(((uintptr_t)L.y32 | (uintptr_t)L.SV32) & 15u) && !(((uintptr_t)L.resid | (uintptr_t)L.out) & 7u);
+    const bool pre = vec && M <= 4u * PRE * T;
+    float4 svr[PRE];
+    uint2 rsr[PRE];
     if (pre) {
 #pragma unroll
         for (u32 k = 0; k < PRE; k++) {
-            const u32 i = tid + k * T;
-            svr[k] = i < M ? L.SV32[i] : 0.f;
-            rsr[k] = (i < M && L.resid) ? L.resid[i] : (uint16_t)0;
+            const u32 u = tid + k * T;
+            const bool ok = u < M / 4u;
+            float4 y = ok ? reinterpret_cast<const float4 *>(L.y32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && L.parts == 2u) {
+                const float4 y2 = reinterpret_cast<const float4 *>(L.y32 + M)[u];
+                y = make_float4(y.x + y2.x, y.y + y2.y, y.z + y2.z, y.w + y2.w);
+            }
+            if (ok) reinterpret_cast<float4 *>(v)[u] = y;
+            svr[k] = ok ? reinterpret_cast<const float4 *>(L.SV32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rsr[k] = (ok && L.resid) ? reinterpret_cast<const uint2 *>(L.resid)[u] : make_uint2(0u, 0u);
         }
+    } else {
+        for (u32 i = tid; i < M; i += T) v[i] = L.parts == 2u ? L.y32[i] + L.y32[M + i] : L.y32[i];
     }
     __syncthreads();
     fwht_lds(v, M);
@@ -438,11 +448,19 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     if (pre) {
 #pragma unroll
         for (u32 k = 0; k < PRE; k++) {
-            const u32 i = tid + k * T;
-            if (i < M) {
-                h16 y = (h16)gq_pin_f32((v[i] * sc) * svr[k]);
-                if (L.resid) y = __builtin_bit_cast(h16, rsr[k]) + y;
-                L.out[i] = __builtin_bit_cast(uint16_t, y);
+            const u32 u = tid + k * T;
+            if (u < M / 4u) {
+                const float4 f = reinterpret_cast<const float4 *>(v)[u];
+                const float fv[4] = {f.x, f.y, f.z, f.w}, sv[4] = {svr[k].x, svr[k].y, svr[k].z, svr[k].w};
+                const u32 rw[2] = {rsr[k].x, rsr[k].y};
+                uint16_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    h16 y = (h16)gq_pin_f32((fv[e] * sc) * sv[e]);
+                    if (L.resid) y = __builtin_bit_cast(h16, (uint16_t)(rw[e >> 1] >> (16 * (e & 1)))) + y;
+                    o[e] = __builtin_bit_cast(uint16_t, y);
+                }
+                reinterpret_cast<uint2 *>(L.out)[u] = make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16));
             }
         }
         return;

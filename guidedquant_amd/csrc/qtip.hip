@@ -403,7 +403,16 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         __syncthreads();
         fwht_lds(v, K);
         const float sc = a.kscale;
-        for (u32 i = tid; i < K; i += T) xs[i] = __builtin_bit_cast(uint16_t, (h16)((v[i] * sc) / 32.0f));
+        for (u32 u = tid; u < K / 8u; u += T) {  // 8 values per step: two 16-byte LDS reads, one 16-byte write
+            const float4 f0 = reinterpret_cast<const float4 *>(v)[2u * u], f1 = reinterpret_cast<const float4 *>(v)[2u * u + 1u];
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            u32 o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = (u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e] * sc) / 32.0f)) |
+                       ((u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e + 1] * sc) / 32.0f)) << 16);
+            reinterpret_cast<uint4 *>(xs)[u] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
         __syncthreads();
     };
     const u32 nK2 = K / 32u, khalf = (nK2 + a.ksplit - 1u) / a.ksplit;

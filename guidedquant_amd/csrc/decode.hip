@@ -52,7 +52,7 @@ constexpr int ATTN_WAVES = 8;  // 8 waves x 4 positions x 4 in flight = 128 posi
 template <int HD>
 __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint16_t *qkv, const int *pos_ptr, const uint16_t *cos_t,
                                                           const uint16_t *sin_t, uint16_t *kc, uint16_t *vc, uint16_t *out,
-                                                          u32 H, u32 Hkv, u32 max_seq, float scale) {
+                                                          u32 H, u32 Hkv, u32 max_seq, float scale, u32 nsplit, float *ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 NW = ATTN_WAVES;
     float *sc = reinterpret_cast<float *>(smem);  // [2 * NW * 64 / (HD / 8)] running max / sum of the position streams
@@ -81,6 +81,21 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
     if (pos >= max_seq) pos = max_seq - 1;
     uint16_t *kcg = kc + (size_t)g * max_seq * HD;
     uint16_t *vcg = vc + (size_t)g * max_seq * HD;
+    // split-KV (long contexts): block (head, sp) takes the positions [p0, p1) of the pos + 1 cached ones, in whole passes
+    // of the block (NW waves x 64 / (HD / 8) positions x 4 in flight); one head per block leaves all but H CUs idle and
+    // is bound by what H CUs can stream (51 us at 4096 positions)
+    constexpr u32 PASS = NW * (64u / (HD / 8u)) * 4u;
+    const u32 sp = blockIdx.y;
+    // a short context (up to two passes) is not worth splitting: split 0 does it all and writes the result itself, the
+    // other blocks and the combine launch return at once
+    const bool solo = nsplit > 1u && pos + 1u <= 2u * PASS;
+    if (solo) {
+        if (sp > 0u) return;
+        nsplit = 1u;
+    }
+    const u32 per = nsplit > 1u ? (((pos + nsplit) / nsplit + PASS - 1u) / PASS) * PASS : pos + 1u;
+    const u32 p0 = sp * per, p1 = min(pos + 1u, p0 + per);  // (p0 >= p1: nothing to do, a neutral partial result is written)
+    const bool has_cur = p0 <= pos && pos < p1;             // the split that covers the current token
     if (tid < HD) {
         const u32 d = tid;
         const h16 c = u2h(cos_t[(size_t)pos * HD + d]), s = u2h(sin_t[(size_t)pos * HD + d]);
@@ -92,7 +107,7 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
         qs[d] = (float)qe;
         kcur[d] = (float)ke;
         vcur[d] = h2f(vd_b);
-        if (h % group == 0) {
+        if (h % group == 0 && has_cur) {
             kcg[(size_t)pos * HD + d] = h2u(ke);
             vcg[(size_t)pos * HD + d] = vd_b;
         }
@@ -113,13 +128,14 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
     float m_run = -3.0e38f, s_run = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    for (u32 t0 = w * PPW * U; t0 <= pos; t0 += NW * PPW * U) {
+    for (u32 t0 = p0 + w * PPW * U; t0 < p1; t0 += NW * PPW * U) {
         uint4 kv[U], vv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const u32 t = t0 + (u32)u * PPW + sub;
-            kv[u] = t < pos ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
-            vv[u] = t < pos ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+            const bool cached = t < pos && t < p1;
+            kv[u] = cached ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+            vv[u] = cached ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -146,7 +162,7 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
             p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
             p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
             if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
-            if (t <= pos) {
+            if (t < p1) {
                 p *= scale;
                 const float m_new = fmaxf(m_run, p);
                 const float resc = __expf(m_run - m_new), wgt = __expf(p - m_new);
@@ -178,8 +194,39 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
             sum += sc[NS + i] * f;
             o += red2[i * HD + tid] * f;
         }
-        out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
+        if (nsplit > 1u) {  // partial result of this split: weighted sum and sum relative to its own maximum M
+            float *wp = ws + ((size_t)h * nsplit + sp) * (HD + 2u);
+            wp[tid] = o;
+            if (tid == 0) {
+                wp[HD] = M;
+                wp[HD + 1] = sum;
+            }
+        } else {
+            out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
+        }
     }
+}
+
+// split-KV combine: out[h] = sum_s o_s e^(M_s - M) / sum_s l_s e^(M_s - M)
+template <int HD>
+__global__ void __launch_bounds__(HD) attn_combine_kernel(const float *ws, uint16_t *out, u32 nsplit, const int *pos_ptr, u32 max_seq) {
+    const u32 h = blockIdx.x, tid = threadIdx.x;
+    {   // (the same rule as in attn_decode_kernel: a short context was finished by split 0)
+        constexpr u32 PASS = ATTN_WAVES * (64u / (HD / 8u)) * 4u;
+        u32 pos = (u32)pos_ptr[0];
+        if (pos >= max_seq) pos = max_seq - 1;
+        if (pos + 1u <= 2u * PASS) return;
+    }
+    const float *wp = ws + (size_t)h * nsplit * (HD + 2u);
+    float M = -3.0e38f;
+    for (u32 s = 0; s < nsplit; s++) M = fmaxf(M, wp[s * (HD + 2u) + HD]);
+    float o = 0.f, sum = 0.f;
+    for (u32 s = 0; s < nsplit; s++) {
+        const float f = __expf(wp[s * (HD + 2u) + HD] - M);  // empty splits: M_s = -3e38, l_s = 0, o_s = 0
+        sum += wp[s * (HD + 2u) + HD + 1] * f;
+        o += wp[s * (HD + 2u) + tid] * f;
+    }
+    out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
 }
 
 // ------------------------------------------------------------------------------------------------ sampling
@@ -441,15 +488,17 @@ extern "C" int gq_embed_lookup(const int *token, const void *table, void *out, u
     return GQ_OK;
 }
 
-extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
-                              void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
-                              float scale, void *stream) {
+extern "C" int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                                    void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                                    float scale, uint32_t n_split, float *workspace, void *stream) {
     if (!qkv || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (n_kv_head == 0 || n_head % n_kv_head) return gq_fail(GQ_EINVAL, "n_head must be a multiple of n_kv_head.");
     if (head_dim != 64 && head_dim != 128) return gq_fail(GQ_ENOTSUP, "head_dim must be 64 or 128.");
+    if (n_split < 1u || n_split > 64u || (n_split > 1u && !workspace)) return gq_fail(GQ_EINVAL, "n_split in 1..64, with a workspace when > 1.");
     const u32 nstreams = (u32)ATTN_WAVES * 64u / (head_dim / 8u);
     const size_t smem = ((size_t)2u * nstreams + 7u * head_dim + 2u * ATTN_WAVES + 16u + (size_t)nstreams * head_dim) * 4u;
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(n_head, n_split);
     if (head_dim == 128) {
         static bool set = false;
         if (smem > 48u * 1024u && !set) {
@@ -457,9 +506,10 @@ extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_t
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             set = true;
         }
-        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(n_head), dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
+        hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
-                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale);
+                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
+        if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(n_head), dim3(128), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
     } else {
         static bool set = false;
         if (smem > 48u * 1024u && !set) {
@@ -467,12 +517,20 @@ extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_t
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             set = true;
         }
-        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(n_head), dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
+        hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
-                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale);
+                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
+        if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(n_head), dim3(64), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
     }
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
+}
+
+extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                              void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                              float scale, void *stream) {
+    return gq_attn_decode_split(qkv, pos, cos_table, sin_table, k_cache, v_cache, out, n_head, n_kv_head, head_dim, max_seq, scale, 1u,
+                                nullptr, stream);
 }
 
 extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint32_t K, const void *norm_weight,

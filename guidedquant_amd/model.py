@@ -324,6 +324,13 @@ class Transformer(nn.Module):
                 x=torch.zeros(c.dim, **f16), h=torch.zeros(c.dim, **f16), y=torch.zeros(c.dim, **f16),
                 qkv=torch.zeros((c.n_head + 2 * c.n_local_heads) * c.head_dim, **f16),
                 gu=torch.zeros(2 * c.intermediate_size, **f16), logits=torch.zeros(1, 1, c.vocab_size, **f16))
+            # long caches: split-KV attention (gq_attn_decode_split), n_split blocks per head + a combine launch; a context of
+            # up to 256 positions is still finished by one block per head at run time
+            S = self.max_seq_length
+            ns = 1 if S <= 1024 else (4 if S <= 2048 else 8)
+            ns = int(os.environ.get("GQ_ATTN_SPLIT", ns))
+            self._native["attn_split"] = ns
+            self._native["attn_ws"] = torch.zeros(c.n_head * ns * (c.head_dim + 2), dtype=torch.float32, device=dev) if ns > 1 else None
             # Gate/up pairing (GQ_EPI_SILU_PAIRS): a row-interleaved copy (gate_0, up_0, gate_1, up_1, ..) of every fused
             # w1w3 tensor lets the w1w3 GEMV write silu(gate) * up directly (model.py:266 of the reference), so w2 reads a
             # plain vector.  The module buffers keep the reference layout [w1; w3] (state-dict contract, prefill path).
@@ -442,9 +449,10 @@ class Transformer(nn.Module):
         for li in range(l0, l1):
             d, at = b["qtip_layers"][li], self.layers[li].attention
             run(d["qkv"])
-            ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
-                                at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
-                                y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, sp), "attn")
+            ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
+                                      at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
+                                      y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
+                                      b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, sp), "attn")
             run(d["o"])
             run(d["gu"])
             run(d["d"])
@@ -471,9 +479,10 @@ class Transformer(nn.Module):
             ck(L.gq_anyprec_gemv_fused(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
                                        at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
                                        c.norm_eps, None, 0, st), "wqkv")
-            ck(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
-                                at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
-                                y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, st), "attn")
+            ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
+                                      at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
+                                      y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
+                                      b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, st), "attn")
             ck(L.gq_anyprec_gemv_fused(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
                                        at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, st), "wo")
             if pairs is not None:

@@ -203,6 +203,13 @@ int gq_embed_lookup(const int *token, const void *table, void *out, uint32_t dim
 int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
                    void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
                    float scale, void *stream);
+/* Split-KV form for long contexts: n_split blocks per head, each over a contiguous range of the cached positions (whole
+ * passes of 128 positions at head_dim 128), partial (max, sum, weighted V) results in `workspace` (f32
+ * [n_head][n_split][head_dim + 2]) combined by a second small launch.  One block per head keeps only n_head CUs
+ * streaming the cache: 51 us per layer at 4096 positions.  n_split = 1 is gq_attn_decode (no workspace, one launch). */
+int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                         void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                         float scale, uint32_t n_split, float *workspace, void *stream);
 
 /* out[n] = sum_k rmsnorm?(x)[k] * W[n][k]      dense fp16 GEMV (lm_head `output`, model.py:94,128-129); fp32
  * accumulation, fp16 output; norm_weight == NULL skips the RMSNorm prologue.  K % 512 == 0. */

@@ -267,10 +267,12 @@ def test_silu_pairs_epilogue_matches_separate_ops(mode, N, K):
     assert L.gq_anyprec_gemv_fused(x.data_ptr(), o.data_ptr(), qp.data_ptr(), lp.data_ptr(), N, K, 2, None, 0.0, y.data_ptr(), 5, None) != 0
 
 
+@pytest.mark.parametrize("nsplit", [1, 2, 8, 5])
 @pytest.mark.parametrize("hd,H,Hkv", [(128, 32, 8), (64, 8, 2)])
-def test_attention_kernel_long_context(hd, H, Hkv):
+def test_attention_kernel_long_context(hd, H, Hkv, nsplit):
     """several passes of the position loop (128 positions per pass at head_dim 128) and a context far beyond what a
-    score buffer in LDS would hold: pre-filled caches, decode at positions up to 5000"""
+    score buffer in LDS would hold: pre-filled caches, decode at positions up to 5000; nsplit > 1: the split-KV form
+    (gq_attn_decode_split: blocks over position ranges + combine), including splits that get no position at all"""
     from guidedquant_amd import _lib
     from guidedquant_amd.model import apply_rotary_pos_emb, rope_tables
     d = _dev()
@@ -282,12 +284,14 @@ def test_attention_kernel_long_context(hd, H, Hkv):
     kc = (torch.randn(1, Hkv, max_seq, hd, device=d, generator=g) * 0.5).half()
     vc = (torch.randn(1, Hkv, max_seq, hd, device=d, generator=g)).half()
     out = torch.zeros(H * hd, dtype=torch.float16, device=d)
-    for p in (127, 128, 129, 1000, 4999):
+    for p in (0, 5, 127, 128, 129, 1000, 4999):
         kc_ref, vc_ref = kc.clone(), vc.clone()
         qkv = torch.randn((H + 2 * Hkv) * hd, device=d, generator=g).half()
         pos = torch.tensor([p], dtype=torch.int32, device=d)
-        _lib.check(L.gq_attn_decode(qkv.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(),
-                                    out.data_ptr(), H, Hkv, hd, max_seq, 1.0 / math.sqrt(hd), _lib.current_stream_ptr()), "attn")
+        ws = torch.full((H * nsplit * (hd + 2),), float("nan"), dtype=torch.float32, device=d)
+        _lib.check(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                          out.data_ptr(), H, Hkv, hd, max_seq, 1.0 / math.sqrt(hd), nsplit, ws.data_ptr() if nsplit > 1 else None,
+                                          _lib.current_stream_ptr()), "attn")
         q, k, v = qkv.split([H * hd, Hkv * hd, Hkv * hd])
         q = q.view(1, 1, H, hd).transpose(1, 2)
         k = k.view(1, 1, Hkv, hd).transpose(1, 2)
@@ -301,3 +305,33 @@ def test_attention_kernel_long_context(hd, H, Hkv):
         torch.cuda.synchronize()
         assert torch.equal(kc[:, :, p], kc_ref[:, :, p]) and torch.equal(vc[:, :, p], vc_ref[:, :, p])
         assert (out.float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_decode_native_split_kv_attention_long_cache():
+    """a cache long enough for the split-KV attention (max_seq_length 2048 -> 4 blocks per head + combine): the native
+    step against the module forward while the context grows past the 256 positions one block per head still handles
+    (head_dim 64: 2 x 256 positions per pass -> the switch is at 512)"""
+    d = _dev()
+    m = _tiny_model(2, 64)
+    m.setup_caches(1, 2048)
+    assert m.native_ready() and m._native_state()["attn_split"] == 4
+    n = 540
+    g = torch.Generator(device="cpu").manual_seed(3)
+    toks = torch.randint(0, 1024, (n,), generator=g).tolist()
+    check = {0, 1, 255, 256, 511, 512, 513, n - 1}
+    ref = {}
+    with torch.no_grad():
+        for p, t in enumerate(toks):
+            lg = m(torch.tensor([[t]], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d))
+            if p in check:
+                ref[p] = lg.float().view(-1).clone()
+        for b in m.layers:
+            b.attention.kv_cache.k_cache.zero_()
+            b.attention.kv_cache.v_cache.zero_()
+        for p, t in enumerate(toks):
+            lg = m.decode_native(torch.tensor([t], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d))
+            if p in check:
+                torch.cuda.synchronize()
+                a, r = lg.float().view(-1), ref[p]
+                assert torch.isfinite(a).all()
+                assert (a - r).abs().max().item() <= TOL * r.abs().max().item(), (p, (a - r).abs().max().item())

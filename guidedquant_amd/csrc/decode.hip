@@ -137,24 +137,27 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
             kv[u] = cached ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
             vv[u] = cached ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
         }
+        // the U positions of the batch share one rescale of the running (max, sum, weighted V): scores first, then one
+        // exp for the old maximum and one per position
+        float pu[U], vfu[U][8];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const u32 t = t0 + (u32)u * PPW + sub;
             const u32 kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w}, vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
-            float p = 0.f, vf[8];
+            float p = 0.f;
             if (t == pos) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     p += qreg[e] * kcur[ld * 8 + e];
-                    vf[e] = vcur[ld * 8 + e];
+                    vfu[u][e] = vcur[ld * 8 + e];
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     p += qreg[2 * e] * h2f((uint16_t)(kw[e] & 0xFFFF));
                     p += qreg[2 * e + 1] * h2f((uint16_t)(kw[e] >> 16));
-                    vf[2 * e] = h2f((uint16_t)(vw[e] & 0xFFFF));
-                    vf[2 * e + 1] = h2f((uint16_t)(vw[e] >> 16));
+                    vfu[u][2 * e] = h2f((uint16_t)(vw[e] & 0xFFFF));
+                    vfu[u][2 * e + 1] = h2f((uint16_t)(vw[e] >> 16));
                 }
             }
             // sum over the LPP lanes of this position (xor butterflies inside a 16-lane DPP row): every lane gets the score
@@ -162,16 +165,23 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
             p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
             p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
             if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
-            if (t < p1) {
-                p *= scale;
-                const float m_new = fmaxf(m_run, p);
-                const float resc = __expf(m_run - m_new), wgt = __expf(p - m_new);
-                s_run = s_run * resc + wgt;
-#pragma unroll
-                for (int e = 0; e < 8; e++) acc[e] = acc[e] * resc + wgt * vf[e];
-                m_run = m_new;
-            }
+            pu[u] = t < p1 ? p * scale : -3.0e38f;
         }
+        float m_new = m_run;
+#pragma unroll
+        for (int u = 0; u < U; u++) m_new = fmaxf(m_new, pu[u]);
+        const float resc = __expf(m_run - m_new);
+        s_run *= resc;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] *= resc;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float wgt = pu[u] > -2.0e38f ? __expf(pu[u] - m_new) : 0.f;
+            s_run += wgt;
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += wgt * vfu[u][e];
+        }
+        m_run = m_new;
     }
     // combine the streams: red2[stream][HD] weighted sums, sc[stream] = running max, sc[NS + stream] = running sum
     constexpr u32 NS = NW * PPW;

@@ -1,7 +1,8 @@
 """ctypes binding of libgq_hip.so (the C ABI declared in include/gq_hip.h).
 
 The product path has NO fallback: if the shared library is missing or a kernel call fails, a RuntimeError is
-raised.  Nothing here imports the CPU oracle.
+raised (the CPU twins of the Any-Precision ops are entry points of the same library, not a Python fallback).  Nothing here
+imports the CPU oracle.
 """
 import ctypes
 import os
@@ -16,7 +17,9 @@ EXPORTS = [
     "gq_version", "gq_last_error", "gq_device_count", "gq_anyprec_gemv", "gq_anyprec_dequant", "gq_lutgemm_gemv",
     "gq_qtip_matvec", "gq_hadamard", "gq_anyprec_gemv_fused", "gq_set_ap_mode", "gq_embed_lookup", "gq_attn_decode",
     "gq_dense_gemv_f16", "gq_sample_topk", "gq_qtip_linear_in", "gq_qtip_linear_out", "gq_qtip_transform", "gq_lutgemm_gemv_ws", "gq_attn_decode_split",
+    "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_reset_env_cache", "gq_debug_set_timing_buffer",
 ]
+_VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer")
 
 
 class GqQtipIn(ctypes.Structure):  # include/gq_hip.h
@@ -49,7 +52,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built (python -c 'import __graft_entry__ as g; "
-                "g.build()' or make -C guidedquant_amd/csrc).  There is no CPU fallback.")
+                "g.build()' or make -C guidedquant_amd/csrc).  There is no fallback: the CPU twins live in the same library.")
         L = ctypes.CDLL(LIB_PATH)
         vp, u32, i32, f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
         L.gq_version.restype = i32
@@ -71,8 +74,13 @@ def lib():
         L.gq_attn_decode_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp]
         L.gq_dense_gemv_f16.argtypes = [vp, vp, vp, u32, u32, vp, f32, vp]
         L.gq_sample_topk.argtypes = [vp, u32, i32, f32, u32, vp, vp, vp, vp, vp, vp, vp]
+        L.gq_anyprec_gemv_cpu.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, i32, i32]
+        L.gq_anyprec_dequant_cpu.argtypes = [vp, vp, vp, u32, u32, i32, i32]
+        L.gq_debug_set_timing_buffer.argtypes = [vp]
         for name in EXPORTS:
-            if name not in ("gq_last_error", ):
+            if name in _VOID:
+                getattr(L, name).restype = None
+            elif name not in ("gq_last_error", ):
                 getattr(L, name).restype = i32
         L.gq_last_error.restype = ctypes.c_char_p
         _lib = L

@@ -6,7 +6,12 @@
 
 Same argument order, same validation (messages follow inference/ap_gemv/gemv.cu:64-90,180-211; failures raise
 RuntimeError like TORCH_CHECK), work enqueued on the current torch stream of the tensors' device
-(gemv.cu:103-105).  The arithmetic runs in libgq_hip.so through the C ABI; there is no CPU fallback.
+(gemv.cu:103-105).  The arithmetic runs in libgq_hip.so through the C ABI; without the library every call raises.
+
+Device dispatch (BASELINE.json configs[0], "CPU reference APLinear path via generate.py"): when ALL tensors of a call live
+in host memory, `anyprec_gemv` / `anyprec_dequant` run the library's CPU twins (`gq_anyprec_gemv_cpu` /
+`gq_anyprec_dequant_cpu`, csrc/cpu_twins.cpp: packed planes read directly, fp32 accumulation) -- the reference has no CPU
+kernel and raises here.  Mixed placements raise with the reference's messages.
 
 One deliberate relaxation: `qweight.size(0) >= bitwidth` is accepted (the reference demands equality,
 gemv.cu:76) because the kernel's plane stride is N*K/32 regardless (anyprec.cu:446) -- this lets a
@@ -43,8 +48,10 @@ def anyprec_gemv(input, output, qweight, lut, bitwidth):
          f"{output.size(2)}, {input.size(2) // 32}), got ({', '.join(str(s) for s in qweight.shape)}).")
     _chk(input.size(1) == 1, "Only sequence length of 1 is supported.")
     _chk(output.size(1) == 1, "Only sequence length of 1 is supported.")
-    _chk(input.is_cuda and output.is_cuda, "input and output tensors must be on GPU.")
-    _chk(qweight.is_cuda and lut.is_cuda, "qweight and lut tensors must be on GPU.")
+    on_cpu = not (input.is_cuda or output.is_cuda or qweight.is_cuda or lut.is_cuda)
+    if not on_cpu:
+        _chk(input.is_cuda and output.is_cuda, "input and output tensors must be on GPU.")
+        _chk(qweight.is_cuda and lut.is_cuda, "qweight and lut tensors must be on GPU.")
     _chk(input.is_contiguous(), "input tensor must be contiguous.")
     _chk(output.is_contiguous(), "output tensor must be contiguous.")
     _chk(qweight.is_contiguous(), "qweight tensor must be contiguous.")
@@ -54,6 +61,11 @@ def anyprec_gemv(input, output, qweight, lut, bitwidth):
     M, K, N = input.size(0), input.size(2), output.size(2)
     _chk(1 <= M <= 8, "batch size must be between 1 and 8.")
     _chk(K % 32 == 0, "input_feat must be a multiple of 32.")
+    if on_cpu:
+        rc = _lib.lib().gq_anyprec_gemv_cpu(input.data_ptr(), output.data_ptr(), qweight.data_ptr(), lut.data_ptr(), M, N, K,
+                                            bitwidth, 0, torch.get_num_threads())
+        _lib.check(rc, "anyprec_gemv (cpu)")
+        return
     with _dev_guard(qweight):
         rc = _lib.lib().gq_anyprec_gemv(input.data_ptr(), output.data_ptr(), qweight.data_ptr(), lut.data_ptr(), M, N, K,
                                         bitwidth, 0, _lib.current_stream_ptr())
@@ -67,10 +79,17 @@ def anyprec_dequant(qweight, lut, bitwidth):
     _chk(qweight.size(0) >= bitwidth, "qweight holds fewer planes than bitwidth.")
     _chk(lut.dtype == torch.float16 and lut.dim() == 2 and lut.size(0) == qweight.size(1)
          and lut.size(1) == (1 << bitwidth), "lut tensor must be float16 of shape (output_feat, 2 ** bitwidth).")
-    _chk(qweight.is_cuda and lut.is_cuda, "qweight and lut tensors must be on GPU.")
+    on_cpu = not (qweight.is_cuda or lut.is_cuda)
+    if not on_cpu:
+        _chk(qweight.is_cuda and lut.is_cuda, "qweight and lut tensors must be on GPU.")
     _chk(qweight.is_contiguous() and lut.is_contiguous(), "qweight and lut tensors must be contiguous.")
     N, K = qweight.size(1), qweight.size(2) * 32
     weight = torch.empty((N, K), dtype=torch.float16, device=qweight.device)  # gemv.cu:121-122
+    if on_cpu:
+        rc = _lib.lib().gq_anyprec_dequant_cpu(qweight.data_ptr(), lut.data_ptr(), weight.data_ptr(), N, K, bitwidth,
+                                               torch.get_num_threads())
+        _lib.check(rc, "anyprec_dequant (cpu)")
+        return weight
     with _dev_guard(qweight):
         rc = _lib.lib().gq_anyprec_dequant(qweight.data_ptr(), lut.data_ptr(), weight.data_ptr(), N, K, bitwidth,
                                            _lib.current_stream_ptr())
@@ -120,6 +139,7 @@ def lutgemm_gemv(input, output, q_weight, alpha, q_bias, bitwidth, group_size):
 
 
 _LG_WS = {}
+_LG_WS_RETIRED = []
 
 
 def _lutgemm_workspace(device, K):
@@ -134,6 +154,8 @@ def _lutgemm_workspace(device, K):
     if ws is None or ws.numel() < K * 64:
         if torch.cuda.is_current_stream_capturing():
             return None
+        if ws is not None:
+            _LG_WS_RETIRED.append(ws)  # a captured graph may still replay launches that point at the smaller buffer
         ws = torch.empty(max(K, 16384) * 64, dtype=torch.uint8, device=device)
         _LG_WS[key] = ws
     return ws

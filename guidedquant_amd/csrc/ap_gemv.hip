@@ -407,18 +407,7 @@ struct QuadCfg {
     size_t smem;
 };
 
-int g_num_cus = 0;
-int num_cus() {
-    if (!g_num_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_num_cus = n;
-        else
-            g_num_cus = 256;
-    }
-    return g_num_cus;
-}
+int num_cus() { return gq_cu_count(); }
 
 bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
     if (K % 128u) return false;
@@ -466,12 +455,11 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
 
 template <int BITS, int D, int PRO>
 int launch_quad_inst(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
-    static size_t attr_set = 0;
+    static GqPerDeviceOnce once;
     auto kern = ap_gemv_quad_kernel<BITS, D, PRO>;
-    if (c.smem > 48u * 1024u && c.smem > attr_set) {
+    if (once.first_use()) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(160u * 1024u)));
-        attr_set = 160u * 1024u;
     }
     dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);

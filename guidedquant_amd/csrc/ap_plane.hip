@@ -907,18 +907,7 @@ struct PlaneCfg {
     size_t smem;
 };
 
-int g_cus = 0;
-int cus() {
-    if (!g_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_cus = n;
-        else
-            g_cus = 256;
-    }
-    return g_cus;
-}
+int cus() { return gq_cu_count(); }
 
 bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     if (K % 256u || K > 16384u) return false;
@@ -1000,12 +989,11 @@ bool pick_local_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
 
 template <int BITS, int PRO, int NC>
 int launch_local_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
-    static bool attr_set = false;
+    static GqPerDeviceOnce once;
     auto kern = ap_plane_local_kernel<BITS, PRO, NC>;
-    if (!attr_set) {
+    if (once.first_use()) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(160u * 1024u)));
-        attr_set = true;
     }
     dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
@@ -1027,12 +1015,11 @@ int launch_local(const PlaneArgs &a, const PlaneCfg &c, u32 M, int pro, hipStrea
 
 template <int BITS, int PRO, int NI>
 int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
-    static bool attr_set = false;
+    static GqPerDeviceOnce once;
     auto kern = ap_plane_kernel<BITS, PRO, NI>;
-    if (!attr_set) {
+    if (once.first_use()) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(160u * 1024u)));
-        attr_set = true;
     }
     dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);

@@ -35,6 +35,16 @@ int gq_env_int(const char *name, int dflt) {
     return r;
 }
 
+int gq_cu_count() {
+    static int cached[256];
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return 256;
+    if (cached[dev]) return cached[dev];
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+    return n;
+}
+
 extern "C" int gq_version(void) { return 100; }
 
 extern "C" const char *gq_last_error(void) { return g_last_error.c_str(); }

@@ -78,7 +78,10 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
         vd_b = v[d];
     }
     u32 pos = (u32)pos_ptr[0];
-    if (pos >= max_seq) pos = max_seq - 1;
+    if (pos >= max_seq) {  // decoding past the cache: nothing is written to it, the head's output is poisoned (NaN logits)
+        if (blockIdx.y == 0 && tid < HD) out[(size_t)h * HD + tid] = 0x7e00u;
+        return;
+    }
     uint16_t *kcg = kc + (size_t)g * max_seq * HD;
     uint16_t *vcg = vc + (size_t)g * max_seq * HD;
     // split-KV (long contexts): block (head, sp) takes the positions [p0, p1) of the pos + 1 cached ones, in whole passes
@@ -224,8 +227,7 @@ __global__ void __launch_bounds__(HD) attn_combine_kernel(const float *ws, uint1
     {   // (the same rule as in attn_decode_kernel: a short context was finished by split 0)
         constexpr u32 PASS = ATTN_WAVES * (64u / (HD / 8u)) * 4u;
         u32 pos = (u32)pos_ptr[0];
-        if (pos >= max_seq) pos = max_seq - 1;
-        if (pos + 1u <= 2u * PASS) return;
+        if (pos >= max_seq || pos + 1u <= 2u * PASS) return;
     }
     const float *wp = ws + (size_t)h * nsplit * (HD + 2u);
     float M = -3.0e38f;
@@ -475,17 +477,7 @@ __global__ void __launch_bounds__(256) dense_gemv_kernel(const uint16_t *x, cons
     }
 }
 
-int g_cu = 0;
-int cu_count() {
-    if (!g_cu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_cu = n;
-        else
-            g_cu = 256;
-    }
-    return g_cu;
-}
+int cu_count() { return gq_cu_count(); }
 
 }  // namespace
 
@@ -510,22 +502,20 @@ extern "C" int gq_attn_decode_split(const void *qkv, const int *pos, const void 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(n_head, n_split);
     if (head_dim == 128) {
-        static bool set = false;
-        if (smem > 48u * 1024u && !set) {
+        static GqPerDeviceOnce once;
+        if (once.first_use()) {
             GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_decode_kernel<128>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            set = true;
         }
         hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
                            (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
         if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(n_head), dim3(128), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
     } else {
-        static bool set = false;
-        if (smem > 48u * 1024u && !set) {
+        static GqPerDeviceOnce once;
+        if (once.first_use()) {
             GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_decode_kernel<64>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            set = true;
         }
         hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
@@ -556,11 +546,10 @@ extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32
     u32 rpb = (N + ncu * 4u - 1u) / (ncu * 4u);
     rpb = ((rpb + 4u * RW - 1u) / (4u * RW)) * (4u * RW);
     const u32 grid = (N + rpb - 1u) / rpb;
-    static bool set = false;
-    if (smem > 48u * 1024u && !set) {
+    static GqPerDeviceOnce once;
+    if (once.first_use()) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dense_gemv_kernel<RW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        set = true;
     }
     hipLaunchKernelGGL(dense_gemv_kernel<RW>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const uint16_t *)x,
                        (const uint16_t *)W, (uint16_t *)out, N, K, (const uint16_t *)norm_weight, eps, rpb);

@@ -632,11 +632,10 @@ extern "C" int gq_qtip_matvec(float *out, const uint32_t *compressed, const void
     dim3 grid(M / 32u), block(waves * 64u);
 #define GQ_LAUNCH_QTIP(RR)                                                                                            \
     do {                                                                                                              \
-        static bool set = false;                                                                                      \
-        if (smem > 48u * 1024u && !set) {                                                                             \
+        static GqPerDeviceOnce once;                                                                                      \
+        if (once.first_use()) {                                                                             \
             GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_matvec_kernel<RR>),                  \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); /* + 2 KiB static */ \
-            set = true;                                                                                               \
         }                                                                                                             \
         hipLaunchKernelGGL(qtip_matvec_kernel<RR>, grid, block, smem, s, out, compressed, (const uint16_t *)x,         \
                            (const uint16_t *)codebook, M, K);                                                         \
@@ -702,11 +701,10 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
     dim3 grid(bands * (u32)ksplit), block(waves * 64u);
 #define GQ_LAUNCH_QIN(RR, PP)                                                                                         \
     do {                                                                                                              \
-        static bool set = false;                                                                                      \
-        if (!set) {                                                                                                   \
+        static GqPerDeviceOnce once;                                                                                      \
+        if (once.first_use()) {                                                                                                   \
             GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_in_kernel<RR, PP>),           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); /* + static */ \
-            set = true;                                                                                               \
         }                                                                                                             \
         hipLaunchKernelGGL((qtip_linear_in_kernel<RR, PP>), grid, block, smem, s, a);                                 \
     } while (0)
@@ -740,11 +738,10 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
         if (lin[i].M > maxM) maxM = lin[i].M;
     }
     const size_t smem = (size_t)maxM * 4u;
-    static bool set = false;
-    if (!set) {
+    static GqPerDeviceOnce once;
+    if (once.first_use()) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
-        set = true;
     }
     hipLaunchKernelGGL(qtip_linear_out_kernel, dim3((u32)n), dim3(1024), smem, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
@@ -781,11 +778,10 @@ extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, 
     const u32 KQ = P >= 1024u ? 1u : 1024u / P;
     const size_t smem = ((size_t)n + 4u * (size_t)Kf + (size_t)KQ * a.RB * P) * 4u;
     if (smem > 150u * 1024u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n too large.");
-    static bool set = false;
-    if (!set) {
+    static GqPerDeviceOnce once;
+    if (once.first_use()) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_transform_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          156 * 1024));
-        set = true;
     }
     hipLaunchKernelGGL(qtip_transform_kernel, dim3((Kf + a.RB - 1u) / a.RB, (u32)n_lin), dim3(1024), smem, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
@@ -798,11 +794,10 @@ extern "C" int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, 
     if (rows == 0) return GQ_OK;
     const size_t smem = (size_t)n * 4u;
     if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "hadamard: n too large (<= 32768).");
-    static bool set = false;
-    if (smem > 48u * 1024u && !set) {
+    static GqPerDeviceOnce once;
+    if (once.first_use()) {
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fwht_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
-        set = true;
     }
     const u32 T = n / 2u >= 1024u ? 1024u : (n / 2u >= 64u ? n / 2u : 64u);
     hipLaunchKernelGGL(fwht_kernel, dim3(rows), dim3(T), smem, (hipStream_t)stream, x, y, n, scale);

@@ -90,6 +90,22 @@ class DecodeGraph:
         with torch.cuda.graph(self.graph):
             self._step()
         torch.cuda.synchronize()
+        self._bound = self._signature()
+
+    def _signature(self):
+        """what the captured launches point at: the graph bakes in raw pointers (KV caches, RoPE tables, the native step's
+        buffers) and max_seq_length; `setup_caches` with a longer length re-allocates all of them"""
+        m = self.model
+        sig = [m.max_seq_length, m.max_batch_size, m.rope_cos.data_ptr(), m.rope_sin.data_ptr()]
+        sig += [b.attention.kv_cache.k_cache.data_ptr() for b in m.layers]
+        if m._native is not None:
+            sig += [m._native["x"].data_ptr(), m._native["logits"].data_ptr()]
+        return tuple(sig)
+
+    def check_bound(self):
+        if self._signature() != self._bound:
+            raise RuntimeError("the captured decode graph is bound to caches / buffers that have since been re-allocated "
+                               "(setup_caches with a longer max_seq_length?): capture a new DecodeGraph")
 
     def _step(self):
         if self.native_sampling:
@@ -108,6 +124,7 @@ class DecodeGraph:
 
     def step(self, advance=True):
         """replay one token step; by default feeds the sampled token back and advances the position on device"""
+        self.check_bound()
         self.graph.replay()
         if advance and not self.native_sampling:
             self.tok.copy_(self.next_tok)
@@ -134,7 +151,8 @@ def decode_n_tokens(model: Transformer, cur_token: torch.Tensor, input_pos: torc
             callback(new_tokens[-1])
             new_probs.append(next_prob.clone())
             cur_token = next_token.clone().view(1, 1)
-    torch.cuda.synchronize()
+    if cur_token.is_cuda:
+        torch.cuda.synchronize()
     return new_tokens, new_probs
 
 

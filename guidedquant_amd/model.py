@@ -76,17 +76,47 @@ transformer_configs = {
     "meta-llama/Llama-2-7b": dict(model_name="Llama-2-7b", block_size=4096, n_layer=32, n_head=32, n_local_heads=32, dim=4096, intermediate_size=11008, vocab_size=32000, rope_base=10000),
     "meta-llama/Llama-2-13b": dict(model_name="Llama-2-13b", block_size=4096, n_layer=40, n_head=40, n_local_heads=40, dim=5120, intermediate_size=13824, vocab_size=32000, rope_base=10000),
     "meta-llama/Llama-2-70b": dict(model_name="Llama-2-70b", block_size=4096, n_layer=80, n_head=64, n_local_heads=8, dim=8192, intermediate_size=28672, vocab_size=32000, rope_base=10000),
-    # not in the reference table: public HF configs
-    "meta-llama/Llama-3.2-1B-Instruct": dict(model_name="Llama-3.2-1B-Instruct", block_size=8192, n_layer=16, n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192, vocab_size=128256, rope_base=500000),
-    "meta-llama/Llama-3.3-70B-Instruct": dict(model_name="Llama-3.3-70B-Instruct", block_size=8192, n_layer=80, n_head=64, n_local_heads=8, dim=8192, intermediate_size=28672, vocab_size=128256, rope_base=500000),
+    # not in the reference table: public HF configs, with the llama3 rope_scaling their config.json
+    # carries (the reference's own 3.1 entries above have none and are kept as the reference has them)
+    "meta-llama/Llama-3.2-1B-Instruct": dict(model_name="Llama-3.2-1B-Instruct", block_size=8192, n_layer=16, n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192, vocab_size=128256, rope_base=500000,
+                                             rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)),
+    "meta-llama/Llama-3.3-70B-Instruct": dict(model_name="Llama-3.3-70B-Instruct", block_size=8192, n_layer=80, n_head=64, n_local_heads=8, dim=8192, intermediate_size=28672, vocab_size=128256, rope_base=500000,
+                                              rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)),
 }
 
 
-def rope_tables(head_dim: int, max_seq: int, base: float, device, dtype=torch.float16):
-    """cos/sin [max_seq, head_dim] as LlamaRotaryEmbedding.forward produces them for rope_type "default"
-    (model.py:343-405): inv_freq = base^-(2i/d) in fp32, freqs = pos * inv_freq, emb = cat(freqs, freqs),
-    cos/sin in fp32, then cast to the activation dtype (attention_scaling == 1)."""
+def rope_inv_freq(head_dim: int, base: float, rope_scaling: Optional[dict], device):
+    """fp32 inverse frequencies of the rotary embedding for the `rope_scaling` section of a Llama config.json:
+    None / "default": base^-(2i/d);  "linear": the same divided by `factor`;  "llama3" (Llama-3.1 / 3.2 / 3.3 checkpoints,
+    inference/model.py:288-305 `apply_rope_scaling`): components whose wavelength exceeds original_max_position_embeddings /
+    low_freq_factor are divided by `factor`, those shorter than original / high_freq_factor are kept, the band between is
+    blended linearly in original / wavelength.  Any other type raises: decoding with the wrong frequencies would differ
+    from the HF path that produced and evaluated the checkpoint at every position, silently."""
     inv_freq = 1.0 / (base**(torch.arange(0, head_dim, 2, dtype=torch.int64).to(dtype=torch.float32, device=device) / head_dim))
+    if not rope_scaling:
+        return inv_freq
+    kind = rope_scaling.get("rope_type", rope_scaling.get("type", "default"))
+    if kind == "default":
+        return inv_freq
+    if kind == "linear":
+        return inv_freq / float(rope_scaling["factor"])
+    if kind != "llama3":
+        raise NotImplementedError(f"rope_scaling type {kind!r} is not implemented (default, linear, llama3 are)")
+    factor = float(rope_scaling["factor"])
+    lo, hi = float(rope_scaling["low_freq_factor"]), float(rope_scaling["high_freq_factor"])
+    old_len = float(rope_scaling["original_max_position_embeddings"])
+    wavelen = 2.0 * math.pi / inv_freq
+    blend = ((old_len / wavelen - lo) / (hi - lo)).clamp(0.0, 1.0)  # 0: long wavelengths (scaled), 1: short ones (kept)
+    scaled = inv_freq / factor
+    out = torch.where(wavelen > old_len / lo, scaled, torch.where(wavelen < old_len / hi, inv_freq, (1.0 - blend) * scaled + blend * inv_freq))
+    return out.to(torch.float32)
+
+
+def rope_tables(head_dim: int, max_seq: int, base: float, device, dtype=torch.float16, rope_scaling: Optional[dict] = None):
+    """cos/sin [max_seq, head_dim] as LlamaRotaryEmbedding.forward produces them (model.py:343-405): inv_freq in fp32
+    (`rope_inv_freq`), freqs = pos * inv_freq, emb = cat(freqs, freqs), cos/sin in fp32, then cast to the activation dtype
+    (attention_scaling == 1 for default / linear / llama3)."""
+    inv_freq = rope_inv_freq(head_dim, base, rope_scaling, device)
     pos = torch.arange(max_seq, device=device, dtype=torch.float32)
     freqs = torch.outer(pos, inv_freq)
     emb = torch.cat((freqs, freqs), dim=-1)
@@ -189,6 +219,9 @@ class FeedForward(nn.Module):
         self.fuse_linears = fuse_linears
         if fuse_linears:
             self.w1w3 = linear_class(config.dim, config.intermediate_size * 2, bias=False, **(linear_kwargs or {}))
+            if hasattr(self.w1w3, "lut"):  # Any-Precision linear: the fused decode step may pair its rows in place
+                self.w1w3._register_state_dict_hook(_unpair_on_export)
+                self.w1w3._register_load_state_dict_pre_hook(_incoming_is_reference_layout, with_module=True)
         else:
             self.w1 = linear_class(config.dim, config.intermediate_size, bias=False, **(linear_kwargs or {}))
             self.w3 = linear_class(config.dim, config.intermediate_size, bias=False, **(linear_kwargs or {}))
@@ -196,13 +229,48 @@ class FeedForward(nn.Module):
         self.act_fn = F.silu
 
     def forward(self, x: Tensor) -> Tensor:
-        if self.fuse_linears:
+        if self.fuse_linears and getattr(self.w1w3, "gq_row_pairs", False):
+            # the fused decode step re-ordered this tensor's rows to (gate_0, up_0, gate_1, up_1, ..) in place
+            # (`pair_gate_up_rows_`): the module forward (prefill, tests) reads the interleaved output back
+            y = self.w1w3(x)
+            w1_out, w3_out = y[..., 0::2], y[..., 1::2]
+        elif self.fuse_linears:
             # .clone(): the quantized linears return their persistent output buffer by reference
             w1_out, w3_out = self.w1w3(x).split([self.config.intermediate_size, self.config.intermediate_size], dim=-1)
         else:
             w1_out = self.w1(x).clone()
             w3_out = self.w3(x)
         return self.w2(self.act_fn(w1_out) * w3_out)
+
+
+def _pair_perm(inter: int, device):
+    """row order (gate_0, up_0, gate_1, up_1, ..) of a fused [w1; w3] tensor"""
+    return torch.stack((torch.arange(inter, device=device), torch.arange(inter, 2 * inter, device=device)), dim=1).reshape(-1)
+
+
+def pair_gate_up_rows_(m) -> None:
+    """Re-order the rows of a fused gate/up Any-Precision linear IN PLACE to interleaved (gate_i, up_i) pairs, the layout
+    the GQ_EPI_SILU_PAIRS epilogue consumes (the w1w3 GEMV then writes silu(gate) * up directly).  No second copy of the
+    tensor is kept (round 1 held one: +0.94 GB at 8B 2-bit, +3.8 GB at 70B).  The state-dict contract is unchanged:
+    `state_dict()` exports the reference layout [w1; w3] (hook below) and `load_state_dict` takes it."""
+    if getattr(m, "gq_row_pairs", False):
+        return
+    perm = _pair_perm(m.out_features // 2, m.qweight.device)
+    m.qweight.data = m.qweight.data[:, perm, :].contiguous()
+    m.lut.data = m.lut.data[perm].contiguous()
+    m.gq_row_pairs = True
+
+
+def _unpair_on_export(module, state_dict, prefix, local_metadata):
+    if getattr(module, "gq_row_pairs", False):
+        inter = module.out_features // 2
+        inv = torch.argsort(_pair_perm(inter, state_dict[prefix + "lut"].device))
+        state_dict[prefix + "qweight"] = state_dict[prefix + "qweight"][:, inv, :].contiguous()
+        state_dict[prefix + "lut"] = state_dict[prefix + "lut"][inv].contiguous()
+
+
+def _incoming_is_reference_layout(module, *args, **kwargs):
+    module.gq_row_pairs = False  # load_state_dict brings [w1; w3]; the native state is rebuilt (and re-paired) lazily
 
 
 class TransformerBlock(nn.Module):
@@ -242,6 +310,12 @@ class Transformer(nn.Module):
         self.cache_initialized = False
         self.fuse_linears = fuse_linears
         self._native = None
+        # new weights (copied in place or assigned): the native step's buffers / launch plans / row pairing are rebuilt lazily
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._reset_native())
+
+    def _reset_native(self):
+        self._native = None
+        self._native_kind_cache = None
 
     @classmethod
     def from_name(cls, dtype, name: str, linear_class=nn.Linear, linear_kwargs=None, halve_layers=False,
@@ -261,7 +335,8 @@ class Transformer(nn.Module):
         for b in self.layers:
             b.attention.kv_cache = KVCache(max_batch_size, max_seq_length, self.config.n_local_heads, head_dim, dtype, device)
         self.causal_mask = torch.tril(torch.ones(self.max_seq_length, self.max_seq_length, dtype=torch.bool, device=device))
-        self.rope_cos, self.rope_sin = rope_tables(head_dim, max_seq_length, self.config.rope_base, device, dtype)
+        self.rope_cos, self.rope_sin = rope_tables(head_dim, max_seq_length, self.config.rope_base, device, dtype,
+                                                   rope_scaling=self.config.rope_scaling)
         self.cache_initialized = True
         self._native = None
         self._native_kind_cache = None
@@ -331,17 +406,19 @@ class Transformer(nn.Module):
             ns = int(os.environ.get("GQ_ATTN_SPLIT", ns))
             self._native["attn_split"] = ns
             self._native["attn_ws"] = torch.zeros(c.n_head * ns * (c.head_dim + 2), dtype=torch.float32, device=dev) if ns > 1 else None
-            # Gate/up pairing (GQ_EPI_SILU_PAIRS): a row-interleaved copy (gate_0, up_0, gate_1, up_1, ..) of every fused
-            # w1w3 tensor lets the w1w3 GEMV write silu(gate) * up directly (model.py:266 of the reference), so w2 reads a
-            # plain vector.  The module buffers keep the reference layout [w1; w3] (state-dict contract, prefill path).
-            self._native["pairs"] = None
+            # Gate/up pairing (GQ_EPI_SILU_PAIRS): every fused w1w3 tensor is re-ordered in place to (gate_0, up_0, gate_1,
+            # up_1, ..) rows so that the w1w3 GEMV writes silu(gate) * up directly (model.py:266 of the reference) and w2
+            # reads a plain vector; state_dict() still exports the reference layout (pair_gate_up_rows_).
+            self._native["pairs"] = False
             if self._native_kind() == "qtip":
                 self._native_qtip_state(self._native)
             elif os.environ.get("GQ_NATIVE_PAIRS", "1") != "0":
-                inter = c.intermediate_size
-                perm = torch.stack((torch.arange(inter, device=dev), torch.arange(inter, 2 * inter, device=dev)), dim=1).reshape(-1)
-                self._native["pairs"] = [(b.feed_forward.w1w3.qweight[:b.feed_forward.w1w3.bitwidth, perm, :].contiguous(),
-                                          b.feed_forward.w1w3.lut[perm].contiguous()) for b in self.layers]
+                for b in self.layers:
+                    pair_gate_up_rows_(b.feed_forward.w1w3)
+                self._native["pairs"] = True
+            else:
+                assert not any(getattr(b.feed_forward.w1w3, "gq_row_pairs", False) for b in self.layers), \
+                    "GQ_NATIVE_PAIRS=0 on a model whose gate/up rows were already paired"
         return self._native
 
     def _native_qtip_state(self, st):
@@ -485,9 +562,8 @@ class Transformer(nn.Module):
                                       b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, st), "attn")
             ck(L.gq_anyprec_gemv_fused(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
                                        at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, st), "wo")
-            if pairs is not None:
-                pq, pl = pairs[l0 + li]
-                ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), pq.data_ptr(), pl.data_ptr(), 2 * c.intermediate_size, c.dim,
+            if pairs:
+                ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(), 2 * c.intermediate_size, c.dim,
                                            ff.w1w3.bitwidth, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 4, st),
                    "w1w3")
                 ck(L.gq_anyprec_gemv_fused(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,

@@ -80,6 +80,20 @@ int gq_anyprec_dequant(const uint32_t *qweight, const void *lut, void *W, uint32
                        void *stream);
 
 /*
+ * Host (CPU) twins of the two Any-Precision entry points: same arguments with HOST pointers, no stream; `nthreads` <= 0
+ * uses the OpenMP default.  They serve BASELINE.json configs[0] ("CPU reference APLinear path via generate.py"): the module
+ * semantics of inference/APLinear.py:35-60 with the tensors in host memory (the reference hard-codes 'cuda',
+ * APLinear.py:17,22,33, and has no CPU kernel).  Read the packed planes directly (pack.py:304-321).
+ * gq_anyprec_gemv_cpu: exact fp16 x fp16 products, fp32 accumulation, one rounding to fp16:
+ *     |out - exact| <= 2^-11 |exact| + 1e-5 * sum_k |w_k x_k|      (any M >= 1, bits 2..8, K % 32 == 0)
+ * gq_anyprec_dequant_cpu: bit-exact table lookup, W fp16 [N][K].
+ */
+int gq_anyprec_gemv_cpu(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N,
+                        uint32_t K, int bits, int dtype, int nthreads);
+int gq_anyprec_dequant_cpu(const uint32_t *qweight, const void *lut, void *W, uint32_t N, uint32_t K, int bits,
+                           int nthreads);
+
+/*
  * LUT-GEMM (BCQ) GEMV.  Replaces ap_gemv.lutgemm_gemv -> nqmv_bias
  * (bindings.cpp:16, gemv.cu:140-228, lutgemm.cu:24-149).
  *   x fp16 [K], out fp16 [N] (ACCUMULATED INTO, caller zeroes it as LUTGEMMLinear.py:74 does),
@@ -197,6 +211,8 @@ int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *qweight, con
 int gq_embed_lookup(const int *token, const void *table, void *out, uint32_t dim, uint32_t vocab, void *stream);
 
 /* RoPE(q,k) at *pos, KV-cache update at *pos, softmax(q k^T / sqrt(d)) v over positions 0..*pos.
+ * *pos >= max_seq (decoding past the cache): nothing is written to the caches and `out` is filled with NaN, so the step's
+ * logits are NaN -- a loud failure instead of silently overwriting the last slot.
  *   qkv fp16 [(n_head + 2 n_kv_head) * head_dim] (fused wqkv output: q | k | v, model.py:211)
  *   cos/sin fp16 [max_seq][head_dim] (LlamaRotaryEmbedding tables, model.py:379-405)
  *   k_cache, v_cache fp16 [n_kv_head][max_seq][head_dim] (KVCache, model.py:63-79);  out fp16 [n_head * head_dim] */
@@ -222,6 +238,12 @@ int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint3
  * *pos_io is incremented, so a captured decode graph advances by itself.  top_k <= 32. */
 int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
                    float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, void *stream);
+
+/* Test / tuning hooks (not part of the reference's surface).  gq_reset_env_cache: drop the cached GQ_* environment
+ * knobs so that a test can flip them between calls.  gq_debug_set_timing_buffer: device buffer the plane kernels write
+ * s_memtime phase stamps into (tools/phase_timing.py); NULL (default) disables it. */
+void gq_reset_env_cache(void);
+void gq_debug_set_timing_buffer(void *device_buffer);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,121 @@
+"""Shared helpers of the Any-Precision GEMV GPU parity tests (fast / plane-MFMA mode envelopes, reference-rounding
+restatements of the decode step's element-wise ops, LNQ-like synthetic layers)."""
+import os
+
+import numpy as np
+
+
+def _fast(force_plane=True, local=1):
+    """Fast mode.  By default the dispatcher sends only the shapes on which the plane-MFMA kernel wins to it
+    (DESIGN.md section 7); the parity tests of that kernel lift the thresholds so that every shape runs on it.
+    local = 0 keeps the shapes that would run the local-image variant (<= 16 rows per CU, 2/3-bit, no RMSNorm) on the
+    shared-image kernel, so both are checked on the same inputs."""
+    from guidedquant_amd import _lib
+    _lib.check(_lib.lib().gq_set_ap_mode(0), "gq_set_ap_mode")
+    if force_plane:
+        os.environ["GQ_PL_MIN_MWEIGHTS"] = "0"
+        os.environ["GQ_PL_MAX_BITS"] = "4"
+        os.environ["GQ_PL_LOCAL"] = str(local)
+        _lib.lib().gq_reset_env_cache()
+
+
+def _check_fast(got, x, q, lut, bits, oracle, rows=None):
+    """Fast (plane-MFMA) mode.  The reference kernel accumulates in fp16 and is itself ~1e-3 (rms, relative) away
+    from the exact product, so a kernel that is MORE accurate cannot be elementwise within 1e-3 of it.  What is
+    asserted instead, per element:
+      (a) accuracy: |got - exact| <= one fp16 rounding of the exact value + 1e-5 * sum|w||x|  (fp32-class);
+      (b) parity:   got is as close to the reference-order result as the correctly rounded exact result is,
+                    |got - ref| <= |fp16(exact) - ref| + 2 ulp + 1e-5 * sum|w||x|, and normwise
+                    ||got - ref|| <= 1.05 * ||fp16(exact) - ref|| (+eps): all of the distance to the reference is
+                    the reference's own fp16 accumulation error (anyprec.cu:495-512);
+      (c) shapes the fast path does not serve (K % 256 != 0 or K > 32768) fall back to the exact kernels: bit-identical;
+          16384 < K <= 32768 runs as two K-halves chained through the residual epilogue (two fp16 roundings)."""
+    if rows is not None:
+        q = np.ascontiguousarray(q[:, rows, :])
+        lut = lut[rows]
+        got = got[rows]
+    K = q.shape[2] * 32
+    ref16h = oracle.ap_gemv_f16(x, q, lut, bits)[0]
+    if K % 256 or K > 32768:
+        assert np.array_equal(got.view(np.uint16), ref16h.view(np.uint16))
+        return
+    # 16384 < K <= 32768 is served as two K-halves, the second added to the fp16 result of the first: two roundings
+    nround = 2.0 if K > 16384 else 1.0
+    y64 = oracle.ap_gemv_f64(x, q, lut, bits)[0]
+    ref16 = ref16h.astype(np.float64)
+    W = np.abs(oracle.ap_dequant(q, lut, bits).astype(np.float64))
+    scale = W @ np.abs(np.asarray(x, dtype=np.float64).reshape(-1))
+    g = got.astype(np.float64)
+    err_exact = np.abs(g - y64)
+    assert (err_exact <= nround * 2.0**-11 * np.abs(y64) * 1.001 + 1e-5 * scale + 1e-7).all(), (err_exact / (scale + 1e-30)).max()
+    e16 = y64.astype(np.float16).astype(np.float64)
+    ulp = np.maximum(np.abs(np.spacing(y64.astype(np.float16))).astype(np.float64), 2.0**-24)
+    assert (np.abs(g - ref16) <= np.abs(e16 - ref16) + 2 * nround * ulp + 1e-5 * scale).all()
+    assert np.linalg.norm(g - ref16) <= (1.05 if nround == 1.0 else 1.15) * np.linalg.norm(e16 - ref16) + 1e-6 * np.linalg.norm(scale) + 1e-7
+
+
+
+
+# ----------------------------------------------------------------------------- the decode step's element-wise ops, restated
+def rmsnorm_ref(x16, w16, eps):
+    """RMSNorm.forward of the reference (inference/model.py:281-292) with its rounding points: fp32 x * rsqrt(mean(x^2) +
+    eps), rounded to fp32, cast to fp16 (`type_as`), then an fp16 multiply by the fp16 weight."""
+    xf = np.asarray(x16, dtype=np.float16).astype(np.float32)
+    r = np.float32(1.0 / np.sqrt(np.mean(xf.astype(np.float64)**2) + np.float64(eps)))
+    n = (xf * r).astype(np.float16)
+    return (n.astype(np.float32) * np.asarray(w16, dtype=np.float16).astype(np.float32)).astype(np.float16)
+
+
+def silu_mul_ref(gate16, up16):
+    """F.silu(w1_out) * w3_out on fp16 tensors (inference/model.py:259-266): silu evaluated in fp32 and rounded to fp16,
+    then an fp16 multiply."""
+    g = np.asarray(gate16, dtype=np.float16).astype(np.float32)
+    s = (g / (np.float32(1.0) + np.exp(-g))).astype(np.float16)
+    return (s.astype(np.float32) * np.asarray(up16, dtype=np.float16).astype(np.float32)).astype(np.float16)
+
+
+def half_add(a16, b16):
+    """fp16 + fp16 -> fp16 (the residual adds of inference/model.py:311-313): the fp32 sum of two halves is exact"""
+    return (np.asarray(a16, dtype=np.float16).astype(np.float32) + np.asarray(b16, dtype=np.float16).astype(np.float32)).astype(np.float16)
+
+
+def lnq_like_layer(N, K, bits, seed, oracle=None):
+    """A layer shaped like what LNQ + GuidedQuant emits rather than uniform noise: a skewed code histogram (the inner
+    centroids carry most of the mass), per-row centroids spread like a weight row's quantiles with a few rows holding
+    outlier centroids 8-40x larger, and a heavy-tailed activation vector (Student-t, plus a handful of massive-activation
+    channels as Llama hidden states have).  Returns (qweight, lut, x)."""
+    from guidedquant_amd import pack
+    rng = np.random.default_rng(seed)
+    L = 1 << bits
+    centre = (L - 1) / 2.0
+    p = np.exp(-0.5 * ((np.arange(L) - centre) / (0.28 * L))**2)
+    p /= p.sum()
+    codes = rng.choice(L, size=(N, K), p=p).astype(np.uint8)
+    q = pack.pack_codes(codes, bits)
+    base = np.sort(rng.normal(0, 0.02, (N, L)), axis=1)
+    out_rows = rng.random(N) < 0.01
+    base[out_rows, 0] *= rng.uniform(8, 40, out_rows.sum())
+    base[out_rows, -1] *= rng.uniform(8, 40, out_rows.sum())
+    lut = base.astype(np.float16)
+    x = rng.standard_t(3, K) * 0.5
+    hot = rng.choice(K, 6, replace=False)
+    x[hot] *= rng.uniform(60, 300, 6)
+    return q, lut, np.clip(x, -6e4, 6e4).astype(np.float16)
+
+
+def run_fused(x, q, lut, bits, norm_weight=None, eps=1e-5, residual=None, flags=0, out_elems=None):
+    """gq_anyprec_gemv_fused through the C ABI on cuda:0 (numpy in, numpy out); out is pre-filled with NaN"""
+    import torch
+    from guidedquant_amd import _lib
+    d = torch.device("cuda:0")
+    N, K = q.shape[1], q.shape[2] * 32
+    t = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(d)  # noqa: E731
+    xt, qt, lt = t(x, np.float16), torch.from_numpy(np.ascontiguousarray(q)).to(d), t(lut, np.float16)
+    nw, rs = t(norm_weight, np.float16), t(residual, np.float16)
+    out = torch.full((out_elems or N, ), float("nan"), dtype=torch.float16, device=d)
+    rc = _lib.lib().gq_anyprec_gemv_fused(xt.data_ptr(), out.data_ptr(), qt.data_ptr(), lt.data_ptr(), N, K, bits,
+                                          nw.data_ptr() if nw is not None else None, eps, rs.data_ptr() if rs is not None else None,
+                                          flags, _lib.current_stream_ptr())
+    _lib.check(rc, "gq_anyprec_gemv_fused")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()

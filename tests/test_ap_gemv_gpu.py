@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+from ap_helpers import _check_fast, _fast
 from conftest import golden_files
 
 torch = pytest.importorskip("torch")
@@ -24,55 +25,6 @@ def _exact_mode():
     for k in ("GQ_PL_MIN_MWEIGHTS", "GQ_PL_MAX_BITS", "GQ_PL_LOCAL"):
         os.environ.pop(k, None)
     _lib.lib().gq_reset_env_cache()
-
-
-def _fast(force_plane=True, local=1):
-    """Fast mode.  By default the dispatcher sends only the shapes on which the plane-MFMA kernel wins to it
-    (DESIGN.md section 7); the parity tests of that kernel lift the thresholds so that every shape runs on it.
-    local = 0 keeps the shapes that would run the local-image variant (<= 16 rows per CU, 2/3-bit, no RMSNorm) on the
-    shared-image kernel, so both are checked on the same inputs."""
-    from guidedquant_amd import _lib
-    _lib.check(_lib.lib().gq_set_ap_mode(0), "gq_set_ap_mode")
-    if force_plane:
-        os.environ["GQ_PL_MIN_MWEIGHTS"] = "0"
-        os.environ["GQ_PL_MAX_BITS"] = "4"
-        os.environ["GQ_PL_LOCAL"] = str(local)
-        _lib.lib().gq_reset_env_cache()
-
-
-def _check_fast(got, x, q, lut, bits, oracle, rows=None):
-    """Fast (plane-MFMA) mode.  The reference kernel accumulates in fp16 and is itself ~1e-3 (rms, relative) away
-    from the exact product, so a kernel that is MORE accurate cannot be elementwise within 1e-3 of it.  What is
-    asserted instead, per element:
-      (a) accuracy: |got - exact| <= one fp16 rounding of the exact value + 1e-5 * sum|w||x|  (fp32-class);
-      (b) parity:   got is as close to the reference-order result as the correctly rounded exact result is,
-                    |got - ref| <= |fp16(exact) - ref| + 2 ulp + 1e-5 * sum|w||x|, and normwise
-                    ||got - ref|| <= 1.05 * ||fp16(exact) - ref|| (+eps): all of the distance to the reference is
-                    the reference's own fp16 accumulation error (anyprec.cu:495-512);
-      (c) shapes the fast path does not serve (K % 256 != 0 or K > 32768) fall back to the exact kernels: bit-identical;
-          16384 < K <= 32768 runs as two K-halves chained through the residual epilogue (two fp16 roundings)."""
-    if rows is not None:
-        q = np.ascontiguousarray(q[:, rows, :])
-        lut = lut[rows]
-        got = got[rows]
-    K = q.shape[2] * 32
-    ref16h = oracle.ap_gemv_f16(x, q, lut, bits)[0]
-    if K % 256 or K > 32768:
-        assert np.array_equal(got.view(np.uint16), ref16h.view(np.uint16))
-        return
-    # 16384 < K <= 32768 is served as two K-halves, the second added to the fp16 result of the first: two roundings
-    nround = 2.0 if K > 16384 else 1.0
-    y64 = oracle.ap_gemv_f64(x, q, lut, bits)[0]
-    ref16 = ref16h.astype(np.float64)
-    W = np.abs(oracle.ap_dequant(q, lut, bits).astype(np.float64))
-    scale = W @ np.abs(np.asarray(x, dtype=np.float64).reshape(-1))
-    g = got.astype(np.float64)
-    err_exact = np.abs(g - y64)
-    assert (err_exact <= nround * 2.0**-11 * np.abs(y64) * 1.001 + 1e-5 * scale + 1e-7).all(), (err_exact / (scale + 1e-30)).max()
-    e16 = y64.astype(np.float16).astype(np.float64)
-    ulp = np.maximum(np.abs(np.spacing(y64.astype(np.float16))).astype(np.float64), 2.0**-24)
-    assert (np.abs(g - ref16) <= np.abs(e16 - ref16) + 2 * nround * ulp + 1e-5 * scale).all()
-    assert np.linalg.norm(g - ref16) <= (1.05 if nround == 1.0 else 1.15) * np.linalg.norm(e16 - ref16) + 1e-6 * np.linalg.norm(scale) + 1e-7
 
 
 def _dev():

@@ -50,5 +50,5 @@ def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     from guidedquant_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    with pytest.raises(RuntimeError, match="no fallback"):
         _lib.lib()

@@ -335,3 +335,34 @@ def test_decode_native_split_kv_attention_long_cache():
                 a, r = lg.float().view(-1), ref[p]
                 assert torch.isfinite(a).all()
                 assert (a - r).abs().max().item() <= TOL * r.abs().max().item(), (p, (a - r).abs().max().item())
+
+
+@pytest.mark.parametrize("nsplit", [1, 4])
+def test_attention_past_the_cache_poisons_the_output(nsplit):
+    """*pos >= max_seq: nothing is written to the caches and the heads' output is NaN (a loud failure downstream) instead of
+    silently overwriting the last slot (include/gq_hip.h)"""
+    from guidedquant_amd import _lib
+    from guidedquant_amd.model import rope_tables
+    d = _dev()
+    L = _lib.lib()
+    H, Hkv, hd, max_seq = 8, 2, 128, 64
+    cos, sin = rope_tables(hd, max_seq, 500000.0, d)
+    kc = torch.ones(1, Hkv, max_seq, hd, dtype=torch.float16, device=d)
+    vc = torch.ones_like(kc)
+    out = torch.zeros(H * hd, dtype=torch.float16, device=d)
+    qkv = torch.randn((H + 2 * Hkv) * hd, device=d).half()
+    ws = torch.zeros(H * nsplit * (hd + 2), dtype=torch.float32, device=d)
+    for p in (max_seq, max_seq + 7):
+        pos = torch.tensor([p], dtype=torch.int32, device=d)
+        _lib.check(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                          out.data_ptr(), H, Hkv, hd, max_seq, 0.1, nsplit, ws.data_ptr() if nsplit > 1 else None,
+                                          _lib.current_stream_ptr()), "attn")
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(out.float()).all())
+        assert bool((kc == 1).all()) and bool((vc == 1).all())
+    pos = torch.tensor([max_seq - 1], dtype=torch.int32, device=d)
+    _lib.check(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                      out.data_ptr(), H, Hkv, hd, max_seq, 0.1, nsplit, ws.data_ptr() if nsplit > 1 else None,
+                                      _lib.current_stream_ptr()), "attn")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())

@@ -42,18 +42,26 @@ def test_module_surfaces_on_cpu_device():
         h.set_precision(4)
 
 
-def test_validation_raises_on_cpu_tensors():
+def test_validation_on_cpu_tensors():
+    """all tensors in host memory: served by the library's CPU twins (configs[0]); the reference's validation still applies;
+    LUT-GEMM has no CPU twin and keeps the reference's placement error"""
     from guidedquant_amd import ap_gemv
     x = torch.zeros(1, 1, 128, dtype=torch.float16)
-    out = torch.zeros(1, 1, 8, dtype=torch.float16)
+    out = torch.ones(1, 1, 8, dtype=torch.float16)
     q = torch.zeros(2, 8, 4, dtype=torch.int32)
     lut = torch.zeros(8, 4, dtype=torch.float16)
-    with pytest.raises(RuntimeError, match="must be on GPU"):
-        ap_gemv.anyprec_gemv(x, out, q, lut, 2)
+    ap_gemv.anyprec_gemv(x, out, q, lut, 2)
+    assert float(out.abs().max()) == 0.0
+    assert ap_gemv.anyprec_dequant(q, lut, 2).shape == (8, 128)
     with pytest.raises(RuntimeError, match="Bitwidth must be between 2 and 8"):
         ap_gemv.anyprec_gemv(x, out, q, lut, 1)
+    with pytest.raises(RuntimeError, match="lut tensor must be of shape"):
+        ap_gemv.anyprec_gemv(x, out, q, lut, 3)
+    with pytest.raises(RuntimeError, match="Only sequence length of 1"):
+        ap_gemv.anyprec_gemv(torch.zeros(1, 2, 128, dtype=torch.float16), out, q, lut, 2)
     with pytest.raises(RuntimeError, match="must be on GPU"):
-        ap_gemv.anyprec_dequant(q, lut, 2)
+        ap_gemv.lutgemm_gemv(x, out, torch.zeros(4, 2, 8, dtype=torch.int32), torch.zeros(1, 2, 8, dtype=torch.float16),
+                             torch.zeros(1, 8, dtype=torch.float16), 2, 128)
 
 
 def test_model_tree_and_state_dict_contract():
@@ -200,3 +208,88 @@ def test_hf_anyprec_loader(tmp_path):
     assert torch.equal(m.output.weight, sd["model.embed_tokens.weight"])  # tied
     with pytest.raises(ValueError):
         load_anyprec_hf(str(tmp_path), bitwidth=4, device="cpu")
+
+
+def test_llama3_rope_scaling_formula():
+    """rope_inv_freq against the scalar statement of apply_rope_scaling (inference/model.py:288-305) for the 3.1/3.3
+    (factor 8) and 3.2 (factor 32) configs; `linear`; unsupported types raise instead of decoding with wrong frequencies"""
+    import math
+    torch = pytest.importorskip("torch")
+    from guidedquant_amd.model import ModelArgs, Transformer, rope_inv_freq, rope_tables
+    for hd, factor in ((128, 8.0), (64, 32.0)):
+        rs = dict(rope_type="llama3", factor=factor, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+        base = 1.0 / (500000.0**(torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+        want = []
+        for f in base:
+            wl = 2 * math.pi / f
+            if wl < 8192 / 4.0:
+                want.append(f)
+            elif wl > 8192 / 1.0:
+                want.append(f / factor)
+            else:
+                sm = (8192 / wl - 1.0) / (4.0 - 1.0)
+                want.append((1 - sm) * f / factor + sm * f)
+        want = torch.tensor(want, dtype=torch.float32)
+        got = rope_inv_freq(hd, 500000.0, rs, "cpu")
+        assert torch.equal(got, want)
+        assert int((got != base).sum()) > hd // 8 and torch.equal(got[:4], base[:4])  # high frequencies untouched
+        cos, sin = rope_tables(hd, 64, 500000.0, "cpu", torch.float16, rope_scaling=rs)
+        cos0, _ = rope_tables(hd, 64, 500000.0, "cpu", torch.float16)
+        assert cos.shape == (64, hd) and not torch.equal(cos, cos0)
+    assert torch.equal(rope_inv_freq(64, 1e4, dict(type="linear", factor=2.0), "cpu"), rope_inv_freq(64, 1e4, None, "cpu") / 2.0)
+    with pytest.raises(NotImplementedError):
+        rope_inv_freq(64, 1e4, dict(rope_type="yarn", factor=2.0), "cpu")
+    # the model applies it: the tables of a Transformer built from a config with rope_scaling differ from the default ones
+    cfg = ModelArgs(block_size=64, vocab_size=32, n_layer=1, n_head=2, dim=128, intermediate_size=256, n_local_heads=2,
+                    rope_base=500000, model_name="llama-t", rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0,
+                                                                              high_freq_factor=4.0, original_max_position_embeddings=32))
+    m = Transformer(torch.float32, cfg)
+    m.setup_caches(1, 64)
+    c0, _ = rope_tables(64, 64, 500000.0, "cpu", torch.float32)
+    assert not torch.equal(m.rope_cos, c0)
+
+
+def test_gate_up_rows_are_paired_in_place_and_exported_in_reference_layout():
+    """pair_gate_up_rows_: the fused decode step re-orders w1w3 rows to (gate_i, up_i) pairs in place (no second copy);
+    state_dict() still exports [w1; w3] (inference/sqllm_llama_convert_fuse.py:97-103 layout), load_state_dict takes it,
+    and the module forward (prefill path) de-interleaves the paired output"""
+    torch = pytest.importorskip("torch")
+    from guidedquant_amd.APLinear import APLinear
+    from guidedquant_amd.model import FeedForward, ModelArgs, Transformer, pair_gate_up_rows_
+    cfg = ModelArgs(block_size=64, vocab_size=32, n_layer=1, n_head=2, dim=128, intermediate_size=256, n_local_heads=2, model_name="llama-t")
+    m = Transformer(torch.float16, cfg, linear_class=APLinear, linear_kwargs=dict(bitwidth=2, device="cpu"))
+    w = m.layers[0].feed_forward.w1w3
+    g = torch.Generator().manual_seed(0)
+    w.qweight.copy_(torch.randint(-2**31, 2**31 - 1, w.qweight.shape, dtype=torch.int32, generator=g))
+    w.lut.copy_(torch.randn(w.lut.shape, generator=g).half())
+    kq, kl = "layers.0.feed_forward.w1w3.qweight", "layers.0.feed_forward.w1w3.lut"
+    q0, l0 = w.qweight.clone(), w.lut.clone()
+    pair_gate_up_rows_(w)
+    pair_gate_up_rows_(w)  # idempotent
+    assert w.gq_row_pairs and not torch.equal(w.qweight, q0)
+    assert torch.equal(w.qweight[:, 0::2], q0[:, :256]) and torch.equal(w.qweight[:, 1::2], q0[:, 256:])
+    assert torch.equal(w.lut[0::2], l0[:256]) and torch.equal(w.lut[1::2], l0[256:])
+    sd = m.state_dict()
+    assert torch.equal(sd[kq], q0) and torch.equal(sd[kl], l0)
+    m._native = {"stale": True}
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+    assert w.gq_row_pairs is False and torch.equal(w.qweight, q0) and m._native is None
+
+    # module forward on a paired tensor: a stand-in linear whose output is its row index shows the de-interleave
+    class Rows(torch.nn.Module):
+        def __init__(self, i, o, bias=False):
+            super().__init__()
+            self.o = o
+            self.lut = None
+
+        def forward(self, x):
+            return torch.arange(self.o, dtype=torch.float32).expand(*x.shape[:-1], self.o)
+    ff = FeedForward(cfg, linear_class=Rows)
+    ff.act_fn = lambda t: t
+    ff.w2 = torch.nn.Identity()
+    x = torch.zeros(1, 1, 128)
+    plain = ff(x)  # gate_i * up_i = i * (256 + i)
+    assert torch.equal(plain.view(-1), torch.arange(256.0) * (256 + torch.arange(256.0)))
+    ff.w1w3.gq_row_pairs = True  # rows now (gate_0, up_0, ..): output index 2i is gate_i, 2i+1 is up_i
+    paired = ff(x)
+    assert torch.equal(paired.view(-1), (2 * torch.arange(256.0)) * (2 * torch.arange(256.0) + 1))

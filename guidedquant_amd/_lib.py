@@ -53,6 +53,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built (python -c 'import __graft_entry__ as g; "
                 "g.build()' or make -C guidedquant_amd/csrc).  There is no fallback: the CPU twins live in the same library.")
+        # torch first: it ships its own libamdhip64; the extension must bind to the HIP runtime torch has already loaded, or
+        # the process ends up with two runtimes and the extension's sees no device ("no ROCm-capable device is detected")
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         vp, u32, i32, f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
         L.gq_version.restype = i32

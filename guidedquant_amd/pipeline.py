@@ -2,13 +2,25 @@
 sharding of qtip/lib/utils/shard_model.py:30-68 and accelerate's device_map="auto",
 any_precision/modules/AnyPrecisionForCausalLM.py:76-82 -- both single-process `tensor.to(device)` hops).
 
-MI355X-native form: one process per GPU, stage g owns layers [l0, l1) (embedding on stage 0, final norm + lm_head on the
-last stage) and the KV caches of those layers; the only data-path exchange is the point-to-point hop of the fp16
-hidden state [dim] (16 KiB for dim = 8192) to the next stage and of the sampled token id back to stage 0, issued with
-torch.distributed send/recv (backend "nccl" = RCCL over xGMI; "gloo" on CPU for the tests).  No collective is needed.
+MI355X-native form: one process per GPU, stage g owns layers [l0, l1) (embedding on stage 0, final norm + lm_head +
+sampling on the last stage) and the KV caches of those layers.  The only data-path exchange is point to point: the fp16
+hidden state [dim] (16 KiB for dim = 8192) hops g -> g+1, the sampled token id hops from the last stage back to stage 0
+(torch.distributed isend / irecv; backend "nccl" = RCCL over one xGMI link per hop, "gloo" on CPU for the tests).  No
+collective is on the data path.
 
 A single bs=1 stream cannot go faster than on one GPU (strict layer dependency); with S = world_size independent
-sequences in flight every stage is busy every tick and the aggregate rate approaches S x the per-stage rate.
+sequences ("slots") in flight every stage is busy every tick and the aggregate rate approaches S x the per-stage rate.
+
+What one stage tick is on the GPU (native path):
+  * ONE hipGraph replay per (stage, slot): [embedding lookup] + the stage's layers on that slot's KV caches + the position
+    increment [+ final norm, lm_head, top-k sampling], captured once per slot at start-up -- no per-launch host work;
+  * token position per slot in DEVICE memory (`pos_dev[slot]`, incremented inside the graph), nothing is filled from the host;
+  * every slot has its own hidden-state buffer, so the receive of slot s+1 is POSTED before slot s is computed and lands
+    while the stage computes (the hop latency hides under ~0.5 ms of layers); sends are asynchronous; a buffer is reused S
+    ticks later, after its send has completed;
+  * forward hops and the token feedback use two process groups: with one communicator per rank pair, posted-ahead receives
+    and sends of the two directions between the same pair (world = 2) would wait for each other in stream order.
+`stage_ranges(.., head_cost_layers=measure_head_cost(model))` balances the stages with the measured cost of the head.
 `PipelinedDecoder.run(n_tokens)` decodes n_tokens for each of the S sequences and returns them (on every rank).
 """
 from typing import List, Optional
@@ -30,40 +42,117 @@ def stage_ranges(n_layer: int, world: int, head_cost_layers: float = 0.0) -> Lis
     return [range(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+def measure_head_cost(model, reps: int = 20) -> float:
+    """cost of the last stage's extra work (final norm + lm_head GEMV + sampling) in units of one decoder layer, measured
+    with events on this GPU (native path); averaged over the ranks when a process group is up, so that every rank derives
+    the same stage ranges.  Replaces round 1's guessed constant."""
+    assert model.native_ready(), "measure_head_cost needs the native decode step"
+    dev = model.output.weight.device
+    st = model._native_state()
+    x = st["x"]
+    pos = torch.zeros(1, dtype=torch.int32, device=dev)
+    n = min(4, len(model.layers))
+    s = torch.cuda.current_stream()
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            fn()
+        e1.record(s)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    with torch.no_grad():
+        t_layers = timed(lambda: model.native_layers(x, pos, 0, n)) / n
+        t_head = timed(lambda: model.native_head(x)) + 0.02  # + the sampler (~16-20 us)
+    x.zero_()
+    ratio = torch.tensor([t_head / max(t_layers, 1e-6)], dtype=torch.float64, device=dev)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(ratio)
+        ratio /= dist.get_world_size()
+    return round(float(ratio.item()), 1)
+
+
 class PipelinedDecoder:
 
     def __init__(self, model, rank: int, world: int, layers: range, n_seq: Optional[int] = None, max_new_tokens: int = 100,
-                 temperature: float = 0.0, top_k: Optional[int] = 32, bos_id: int = 1, native: Optional[bool] = None, group=None):
+                 temperature: float = 0.0, top_k: Optional[int] = 32, bos_id: int = 1, native: Optional[bool] = None, group=None,
+                 feedback_group=None, use_graphs: Optional[bool] = None, seed: int = 1234):
         self.model, self.rank, self.world, self.layers = model, rank, world, layers
-        self.n_seq = n_seq or world
+        self.n_seq = S = n_seq or world
         self.group = group
+        # a second communicator for the token feedback (see module docstring); the caller may pass one, else it is created
+        # collectively here (every rank constructs the decoder)
+        self.fb_group = feedback_group
+        if self.fb_group is None and world > 1:
+            self.fb_group = dist.new_group(ranks=list(range(world)))
         self.first, self.last = rank == 0, rank == world - 1
-        self.temperature, self.top_k, self.bos_id = temperature, top_k, bos_id
+        self.temperature, self.top_k, self.bos_id, self.seed = temperature, top_k, bos_id, seed
         dev = model.output.weight.device
         self.dev = dev
-        model.setup_caches(self.n_seq, 1 + max_new_tokens)
+        model.setup_caches(S, 1 + max_new_tokens)
         self.native = model.native_ready() if native is None else native
         c = model.config
-        self.hidden = torch.zeros(c.dim, dtype=model.output.weight.dtype, device=dev)
-        self.tok = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.pos = [0] * self.n_seq
-        self.pos_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        dt = model.output.weight.dtype
+        self.h = torch.zeros(S, c.dim, dtype=dt, device=dev)          # per-slot hidden state (received into / computed in place / sent)
+        self.tok = torch.zeros(S, dtype=torch.int32, device=dev)      # per-slot input token (stage 0)
+        self.tok_out = torch.zeros(S, dtype=torch.int32, device=dev)  # per-slot sampled token (last stage)
+        self.pos_dev = torch.zeros(S, dtype=torch.int32, device=dev)  # per-slot position, advanced on the device
+        self.pos = [0] * S                                            # host mirror (eager path only)
+        self.use_graphs = (self.native and dev.type == "cuda") if use_graphs is None else use_graphs
+        self.graphs = None
+        if self.native and self.last:
+            self.rng_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.work_val = torch.zeros(128 * 32, dtype=torch.float32, device=dev)
+            self.work_idx = torch.zeros(128 * 32, dtype=torch.int32, device=dev)
+        if self.native:
+            # the QTIP launch plans are bound to the model's own hidden-state buffer: compute there, copy in / out
+            self._x = model._native_state()["x"] if model._native_kind() == "qtip" else None
+        if self.use_graphs:
+            self._capture()
 
     # -- stage compute -------------------------------------------------------------------------------------------
-    def _embed(self):
-        if self.native:
-            self.model.native_embed(self.tok, self.hidden)
-        else:
-            self.hidden.copy_(self.model.tok_embeddings(self.tok.long()).view(-1))
-
-    def _layers(self, slot: int):
+    def _tick_native(self, slot: int):
+        """everything stage `rank` does for one token of sequence `slot`, on the current stream, no host work besides the
+        launches (captured once per slot)"""
         m = self.model
-        self.pos_t.fill_(self.pos[slot])
-        if self.native:
-            m.native_layers(self.hidden, self.pos_t, self.layers.start, self.layers.stop, slot)
-            return
-        x = self.hidden.view(1, 1, -1)
-        ip = self.pos_t.long()
+        h = self.h[slot]
+        pos = self.pos_dev[slot:slot + 1]
+        x = h if self._x is None else self._x
+        if self.first:
+            m.native_embed(self.tok[slot:slot + 1], x)
+        elif self._x is not None:
+            x.copy_(h)
+        m.native_layers(x, pos, self.layers.start, self.layers.stop, slot)
+        pos.add_(1)
+        if self.last:
+            self._sample_native(m.native_head(x), slot)
+        elif self._x is not None:
+            h.copy_(x)
+
+    def _sample_native(self, logits, slot):
+        from . import _lib
+        if self.top_k is not None and self.top_k <= 32:
+            _lib.check(_lib.lib().gq_sample_topk(logits.data_ptr(), self.model.config.vocab_size, int(self.top_k), float(self.temperature),
+                                                int(self.seed), self.rng_counter.data_ptr(), self.work_val.data_ptr(),
+                                                self.work_idx.data_ptr(), None, None, self.tok_out[slot:slot + 1].data_ptr(),
+                                                _lib.current_stream_ptr()), "gq_sample_topk")
+        else:
+            from .generate import sample
+            idx, _ = sample(logits.view(1, 1, -1), temperature=self.temperature, top_k=self.top_k)
+            self.tok_out[slot:slot + 1].copy_(idx.view(1))
+
+    def _tick_eager(self, slot: int):
+        """the same stage tick through the module-by-module forward (any linear class, CPU): reference semantics"""
+        from .generate import sample
+        m = self.model
+        if self.first:
+            self.h[slot].copy_(m.tok_embeddings(self.tok[slot:slot + 1].long()).view(-1))
+        x = self.h[slot].view(1, 1, -1)
+        ip = torch.tensor([self.pos[slot]], dtype=torch.long, device=self.dev)
         mask = m.causal_mask[None, None, ip]
         for li in self.layers:
             blk = m.layers[li]
@@ -74,54 +163,98 @@ class PipelinedDecoder:
                 x = blk(x, ip, mask, m.rope_cos, m.rope_sin)
             finally:
                 kv.k_cache, kv.v_cache = full_k, full_v
-        self.hidden.copy_(x.reshape(-1))
+        self.h[slot].copy_(x.reshape(-1))
+        self.pos[slot] += 1
+        if self.last:
+            logits = m.output(m.norm(self.h[slot].view(1, 1, -1)))
+            idx, _ = sample(logits.view(1, 1, -1), temperature=self.temperature, top_k=self.top_k)
+            self.tok_out[slot:slot + 1].copy_(idx.view(1).to(torch.int32))
 
-    def _head_and_sample(self) -> torch.Tensor:
-        from .generate import sample
-        m = self.model
-        if self.native:
-            logits = m.native_head(self.hidden)
+    def _capture(self):
+        """one hipGraph per slot (the slot selects the KV caches, buffers and position word the launches point at)"""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for slot in range(self.n_seq):  # warm-up: lazy kernel attributes, allocator
+                self._tick_native(slot)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graphs = []
+        for slot in range(self.n_seq):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                self._tick_native(slot)
+            self.graphs.append(g)
+        torch.cuda.synchronize()
+        self.reset()
+
+    def reset(self):
+        """start new sequences: positions to 0 (the caches are overwritten as the positions advance)"""
+        self.pos_dev.zero_()
+        self.pos = [0] * self.n_seq
+        if self.native and self.last:
+            self.rng_counter.zero_()
+
+    def _tick(self, slot: int):
+        if self.graphs is not None:
+            self.graphs[slot].replay()
+        elif self.native:
+            self._tick_native(slot)
+            self.pos[slot] += 1
         else:
-            logits = m.output(m.norm(self.hidden.view(1, 1, -1)))
-        idx, _ = sample(logits.view(1, 1, -1), temperature=self.temperature, top_k=self.top_k)
-        return idx.view(1).to(torch.int32)
+            self._tick_eager(slot)
 
     # -- schedule ------------------------------------------------------------------------------------------------
     def run(self, n_tokens: int) -> torch.Tensor:
         """returns int32 [n_seq, n_tokens] (valid on every rank: broadcast from the last stage at the end)"""
         w, r, S = self.world, self.rank, self.n_seq
         out = torch.zeros(S, n_tokens, dtype=torch.int32, device=self.dev)
-        pending = []  # outstanding isend requests (with their buffers): sends never block the stage loop
+        recv_req = [None] * S  # the posted receive of each slot's next input
+        send_req = [None] * S  # the last send out of each slot's buffer
 
-        def post(t, dst):
-            buf = t.clone()
-            pending.append((dist.isend(buf, dst=dst, group=self.group), buf))
-            while len(pending) > 4 * S:
-                pending.pop(0)[0].wait()
+        def post_recv(step, slot):
+            """post the receive of tick (step, slot)'s input, if it comes from another rank"""
+            if step >= n_tokens or recv_req[slot] is not None:
+                return
+            if self.first:
+                if step > 0 and w > 1:
+                    recv_req[slot] = dist.irecv(self.tok[slot:slot + 1], src=w - 1, group=self.fb_group)
+            else:
+                if send_req[slot] is not None:  # the buffer's previous content must have left before it is overwritten
+                    send_req[slot].wait()
+                    send_req[slot] = None
+                recv_req[slot] = dist.irecv(self.h[slot], src=r - 1, group=self.group)
 
+        def nxt(step, slot):
+            return (step, slot + 1) if slot + 1 < S else (step + 1, 0)
+
+        post_recv(0, 0)
         for step in range(n_tokens):
             for slot in range(S):
-                if self.first:
-                    if step == 0:
-                        self.tok.fill_(self.bos_id)
-                    elif w > 1:
-                        dist.recv(self.tok, src=w - 1, group=self.group)
-                    else:
-                        self.tok.copy_(out[slot, step - 1:step])
-                    self._embed()
-                else:
-                    dist.recv(self.hidden, src=r - 1, group=self.group)
-                self._layers(slot)
-                self.pos[slot] += 1
+                post_recv(*nxt(step, slot))  # lands while this tick computes
+                if self.first and step == 0:
+                    self.tok[slot:slot + 1].fill_(self.bos_id)
+                elif self.first and w == 1:
+                    self.tok[slot:slot + 1].copy_(self.tok_out[slot:slot + 1])
+                if recv_req[slot] is not None:
+                    recv_req[slot].wait()
+                    recv_req[slot] = None
+                if self.first and send_req[slot] is not None:  # stage 0 computes in place in the buffer it sent from
+                    send_req[slot].wait()
+                    send_req[slot] = None
+                self._tick(slot)
                 if not self.last:
-                    post(self.hidden, r + 1)
+                    send_req[slot] = dist.isend(self.h[slot], dst=r + 1, group=self.group)
                 else:
-                    t = self._head_and_sample()
-                    out[slot, step] = t[0]
+                    out[slot, step:step + 1].copy_(self.tok_out[slot:slot + 1])
                     if w > 1 and step + 1 < n_tokens:
-                        post(t, 0)
-        for req, _ in pending:
-            req.wait()
+                        if send_req[slot] is not None:
+                            send_req[slot].wait()
+                        # the token leaves from the output row (stable storage: tok_out[slot] is rewritten next step)
+                        send_req[slot] = dist.isend(out[slot, step:step + 1], dst=0, group=self.fb_group)
+        for req in send_req:
+            if req is not None:
+                req.wait()
         if w > 1:
             dist.broadcast(out, src=w - 1, group=self.group)
         return out

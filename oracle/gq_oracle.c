@@ -288,6 +288,52 @@ int gq_oracle_ap_gemv_f16(const uint16_t *x, const uint32_t *qweight, const uint
     return 0;
 }
 
+/* Native-float GEMV: what a CPU runs when it is NOT asked to emulate binary16 -- the "packed C/OpenMP GEMV" CPU
+ * baseline of BASELINE.md section 4.  Same packed format (closed form above), products of the two halves exact in float,
+ * float accumulation in 8 interleaved partial sums per row (weight e goes to sum e % 8), one rounding to half.  Walks the
+ * planes word by word: no code buffer, so it streams the matrix once like the GPU kernels do.  NOT order-faithful to
+ * anyprec.cu; used as the honest CPU timing baseline and as a second, independent fp32-class value check. */
+static float h2f_native(uint16_t h) { return (float)h2d(h); }
+
+int gq_oracle_ap_gemv_f32(const uint16_t *x, const uint32_t *qweight, const uint16_t *lut, uint32_t M, uint32_t N,
+                          uint32_t K, int bits, uint16_t *y) {
+    if (K % 32u || bits < 2 || bits > 8 || M < 1) return -1;
+    const uint32_t wpr = K / 32u, nc = 1u << bits;
+    const uint32_t nfull = K / 1024u, tail = K % 1024u;
+    float *xf = (float *)malloc(sizeof(float) * (size_t)M * K);
+    if (!xf) return -2;
+    for (size_t i = 0; i < (size_t)M * K; i++) xf[i] = h2f_native(x[i]);
+#pragma omp parallel for schedule(static, 16)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        float lv[256];
+        for (uint32_t c = 0; c < nc; c++) lv[c] = h2f_native(lut[(size_t)n * nc + c]);
+        for (uint32_t m = 0; m < M; m++) {
+            const float *xm = xf + (size_t)m * K;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t i = 0; i < nfull + (tail ? 1u : 0u); i++) {
+                const uint32_t tpw = i < nfull ? 32u : tail / 32u;
+                for (uint32_t t = 0; t < tpw; t++) {
+                    uint32_t w[8];
+                    for (int p = 0; p < bits; p++) w[p] = qweight[((size_t)p * N + (size_t)n) * wpr + 32u * i + t];
+                    for (uint32_t c = 0; c < 4; c++) {
+                        const float *xp = xm + 1024u * i + 8u * tpw * c + 8u * t;
+                        for (uint32_t j = 0; j < 8; j++) {
+                            const uint32_t bp = 31u - (8u * c + j);
+                            uint32_t code = 0;
+                            for (int p = 0; p < bits; p++) code = (code << 1) | ((w[p] >> bp) & 1u);
+                            acc[j] += lv[code] * xp[j];
+                        }
+                    }
+                }
+            }
+            const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            y[(size_t)m * N + n] = d2h((double)s);
+        }
+    }
+    free(xf);
+    return 0;
+}
+
 void gq_oracle_set_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

@@ -50,6 +50,7 @@ def lib():
         L.gq_oracle_ap_dequant.argtypes = [u32p, u16p, u32, u32, i32, u16p]
         L.gq_oracle_ap_gemv_f64.argtypes = [u16p, u32p, u16p, u32, u32, u32, i32, f64p]
         L.gq_oracle_ap_gemv_f16.argtypes = [u16p, u32p, u16p, u32, u32, u32, i32, u16p]
+        L.gq_oracle_ap_gemv_f32.argtypes = [u16p, u32p, u16p, u32, u32, u32, i32, u16p]
         L.gq_oracle_set_threads.argtypes = [i32]
         L.gq_oracle_max_threads.restype = i32
         L.gq_oracle_lutgemm_f16.argtypes = [u16p, u32p, u16p, u16p, u32, u32, i32, i32, u16p]
@@ -150,6 +151,23 @@ def ap_gemv_f16(x, qweight, lut, bits):
     y = np.zeros((M, N), dtype=np.uint16)
     rc = lib().gq_oracle_ap_gemv_f16(_p(x16, ctypes.c_uint16), _p(q, ctypes.c_uint32), _p(l16, ctypes.c_uint16), M,
                                      N, K, bits, _p(y, ctypes.c_uint16))
+    assert rc == 0, rc
+    return y.view(np.float16)
+
+
+def ap_gemv_f32(x, qweight, lut, bits):
+    """Native-float GEMV (float accumulation, no binary16 emulation): the packed CPU baseline of BASELINE.md section 4.
+    x fp16[M,K] -> fp16[M,N]."""
+    q = _c(qweight, np.int32).view(np.uint32)
+    _, N, wpr = q.shape
+    K = wpr * 32
+    x16 = _u16(x).reshape(-1, K)
+    M = x16.shape[0]
+    l16 = _u16(lut)
+    assert l16.shape == (N, 1 << bits)
+    y = np.zeros((M, N), dtype=np.uint16)
+    rc = lib().gq_oracle_ap_gemv_f32(_p(x16, ctypes.c_uint16), _p(q, ctypes.c_uint32), _p(l16, ctypes.c_uint16), M, N, K, bits,
+                                     _p(y, ctypes.c_uint16))
     assert rc == 0, rc
     return y.view(np.float16)
 

@@ -19,7 +19,7 @@ def _fast(force_plane=True, local=1):
         _lib.lib().gq_reset_env_cache()
 
 
-def _check_fast(got, x, q, lut, bits, oracle, rows=None):
+def _check_fast(got, x, q, lut, bits, oracle, rows=None, dyn_range_slack=False):
     """Fast (plane-MFMA) mode.  The reference kernel accumulates in fp16 and is itself ~1e-3 (rms, relative) away
     from the exact product, so a kernel that is MORE accurate cannot be elementwise within 1e-3 of it.  What is
     asserted instead, per element:
@@ -29,7 +29,12 @@ def _check_fast(got, x, q, lut, bits, oracle, rows=None):
                     ||got - ref|| <= 1.05 * ||fp16(exact) - ref|| (+eps): all of the distance to the reference is
                     the reference's own fp16 accumulation error (anyprec.cu:495-512);
       (c) shapes the fast path does not serve (K % 256 != 0 or K > 32768) fall back to the exact kernels: bit-identical;
-          16384 < K <= 32768 runs as two K-halves chained through the residual epilogue (two fp16 roundings)."""
+          16384 < K <= 32768 runs as two K-halves chained through the residual epilogue (two fp16 roundings);
+      (d) dyn_range_slack (LNQ-like inputs with massive-activation channels only): the matrix cores align the 128 products of
+        one dot-product group to the largest exponent and keep a window of ~17 bits (measured, tools/
+        plane_dynrange_probe.py -> profiles/r02_plane_dynrange.txt), so the group mates of a channel that is 2^10 .. 2^14
+        times larger lose low bits: the envelope gets + 2^-11 * max|lut_n| * sum over groups of the group max|x|, about one
+        fp16 ulp of the hot activations themselves."""
     if rows is not None:
         q = np.ascontiguousarray(q[:, rows, :])
         lut = lut[rows]
@@ -47,11 +52,23 @@ def _check_fast(got, x, q, lut, bits, oracle, rows=None):
     scale = W @ np.abs(np.asarray(x, dtype=np.float64).reshape(-1))
     g = got.astype(np.float64)
     err_exact = np.abs(g - y64)
-    assert (err_exact <= nround * 2.0**-11 * np.abs(y64) * 1.001 + 1e-5 * scale + 1e-7).all(), (err_exact / (scale + 1e-30)).max()
+    dyn = 0.0
+    if dyn_range_slack:
+        assert K % 1024 == 0
+        ax = np.abs(np.asarray(x, dtype=np.float64).reshape(-1))
+        e = np.arange(K)
+        r = e % 1024
+        t, j = (r % 256) // 8, r % 8
+        gid = (e // 1024) * 8 + ((7 - j) & 3) * 2 + ((t >> 2) & 1)  # plane_core.h locate_x4: (chunk, b, h) = one 128-element MFMA group
+        gmax = np.zeros(K // 128)
+        np.maximum.at(gmax, gid, ax)
+        dyn = 2.0**-11 * np.abs(lut.astype(np.float64)).max(axis=1) * gmax.sum()
+    assert (err_exact <= nround * 2.0**-11 * np.abs(y64) * 1.001 + 1e-5 * scale + dyn + 1e-7).all(), (err_exact / (scale + 1e-30)).max()
     e16 = y64.astype(np.float16).astype(np.float64)
     ulp = np.maximum(np.abs(np.spacing(y64.astype(np.float16))).astype(np.float64), 2.0**-24)
-    assert (np.abs(g - ref16) <= np.abs(e16 - ref16) + 2 * nround * ulp + 1e-5 * scale).all()
-    assert np.linalg.norm(g - ref16) <= (1.05 if nround == 1.0 else 1.15) * np.linalg.norm(e16 - ref16) + 1e-6 * np.linalg.norm(scale) + 1e-7
+    assert (np.abs(g - ref16) <= np.abs(e16 - ref16) + 2 * nround * ulp + 1e-5 * scale + dyn).all()
+    if not dyn_range_slack:
+        assert np.linalg.norm(g - ref16) <= (1.05 if nround == 1.0 else 1.15) * np.linalg.norm(e16 - ref16) + 1e-6 * np.linalg.norm(scale) + 1e-7
 
 
 

@@ -96,3 +96,16 @@ def test_gemv_f16_multi_m_is_per_row(oracle):
     for m in range(3):
         y1 = oracle.ap_gemv_f16(X[m:m + 1], g["qweight"], g["lut"], bits)
         assert np.array_equal(Y[m].view(np.uint16), y1[0].view(np.uint16))
+
+
+@pytest.mark.parametrize("path", golden_files("ap_b"))
+def test_native_float_gemv_against_goldens(oracle, path):
+    """the native-float CPU baseline (oracle.ap_gemv_f32) is within fp32-accumulation distance of the reference-generated
+    exact product on every fixture, and agrees with the oracle's own fp64 statement"""
+    g = np.load(path)
+    bits = int(g["bits"])
+    got = oracle.ap_gemv_f32(g["x"], g["qweight"], g["lut"], bits)[0].astype(np.float64)
+    scale = np.abs(g["W"].astype(np.float64)) @ np.abs(g["x"].astype(np.float64))
+    assert (np.abs(got - g["y64"]) <= 2.0**-11 * 1.001 * np.abs(g["y64"]) + 1e-5 * scale + 1e-7).all()
+    y64 = oracle.ap_gemv_f64(g["x"], g["qweight"], g["lut"], bits)[0]
+    assert (np.abs(got - y64) <= 2.0**-11 * 1.001 * np.abs(y64) + 1e-5 * scale + 1e-7).all()

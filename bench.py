@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on its config: bs=1 decode tokens/sec of Llama-3.1-8B-Instruct, 2-bit
-Any-Precision weights, fused QKV / Up-Gate, on MI355X -- plus the AP-GEMV roofline figure and a CPU baseline.
+Any-Precision weights, fused QKV / Up-Gate, on MI355X -- plus the AP-GEMV roofline figures and CPU baselines.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (driver contract)
+    python bench.py --backend qtip                               (BASELINE configs[3]: Llama-2-7b QTIP 2-bit)
+    python bench.py --bits 3 | --bits 4                          (configs[2])
+    python bench.py --model meta-llama/Llama-3.3-70B-Instruct    (configs[4] on one GPU; N > 1 adds the pipeline record)
 
-A "step" is one decoded token (bs = 1): embedding, 32 x (RMSNorm->wqkv GEMV, RoPE+KV+attention, wo GEMV+residual,
-RMSNorm->w1w3 GEMV, SiLU*up->w2 GEMV+residual), final norm + fp16 lm_head GEMV, top-k sampling -- the reference's
+A "step" is one decoded token (bs = 1): embedding, n_layer x (RMSNorm->wqkv GEMV, RoPE+KV+attention, wo GEMV+residual,
+RMSNorm->w1w3 GEMV+SiLU*up, w2 GEMV+residual), final norm + fp16 lm_head GEMV, top-k sampling -- the reference's
 `decode_one_token` (inference/generate.py:82-86), replayed as one hipGraph.  Like the reference's harness the
 tokens are decoded from a BOS-only prompt in sequences of 100 new tokens (generate.py:395-401), so the KV length
 seen by the attention kernel cycles through 1..100.  Weights are synthetic (`--random_init` of the reference):
@@ -13,30 +16,130 @@ there is no network for checkpoints; every quantized tensor has the real shape, 
 HBM before the timed region.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the decode path of one sequence does not shard
-without changing the reference's data path, so ranks run independent replicas (one sequence per GPU, no data-path
-collective) and the job value is the sum -- "replicas only", weak scaling.
+without changing the reference's data path, so `value` comes from independent replicas (one sequence per GPU, no
+data-path collective; "replicas only", weak scaling -- DESIGN.md section 6).  The north star's layer pipeline
+(BASELINE configs[4]: Llama-3.3-70B 2-bit over the N GPUs, point-to-point hops, N sequences in flight) is measured in the
+same run and reported as the `pipeline_70b` sub-record of the same JSON line (guarded by a watchdog: a hang of that leg
+cannot take the replicas line with it).
 
-Output: ONE JSON line on rank 0 (schema in the task contract) with `roofline` (dominant quantized kernel, the
-w1w3 AP-GEMV, algorithmic bytes B_ap / average launch duration measured with HIP events on the launch stream over
-all 32 layers' distinct weights) and `cpu_baseline` (oracle port timed on the host cores on a bounded sample).
+Output: ONE JSON line on rank 0 (schema in the task contract) with
+  `roofline`           dominant quantized kernel (the w1w3 AP-GEMV exactly as the decode graph launches it: RMSNorm prologue,
+                       gate/up pair epilogue), algorithmic bytes B_ap / average launch duration, HIP events on the launch stream
+                       over all layers' distinct weights; `traffic` = HBM bytes per launch from the committed PMC passes of
+                       the SAME kernel template and mode (profiles/r02_w1w3_traffic.json), else null
+  `roofline_by_shape`  the four Llama-3-8B GEMV shapes x 2/3/4 bits (BASELINE.json metric: "+3/4-bit sweep"), default dispatch
+  `exact_mode_tok_s`   the same decode with every quantized GEMV in the bit-exact (reference fp16 order) mode
+  `cpu_baseline`       oracle ports timed on the host cores on a bounded sample (N = 1 only)
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MODEL = "meta-llama/Meta-Llama-3.1-8B-Instruct"
+QTIP_MODEL = "meta-llama/Llama-2-7b"
+PP_MODEL = "meta-llama/Llama-3.3-70B-Instruct"
 SEQ_NEW_TOKENS = 100  # reference default max_new_tokens (generate.py:398)
 HBM_PEAK_GBPS = 8000.0
+SHAPES_8B = {"wqkv": (6144, 4096), "wo": (4096, 4096), "w1w3": (28672, 4096), "w2": (4096, 14336)}
 
 
 def b_ap(bits, N, K):
     """algorithmic bytes of one AP-GEMV launch: planes + LUT + x + y"""
     return bits * N * K // 8 + 2 * N * (1 << bits) + 2 * K + 2 * N
+
+
+def b_qtip(R, M, K):
+    """algorithmic bytes of one QTIP matvec: trellis + codebook + x + y"""
+    return R * M * K // 8 + 2048 + 2 * K + 4 * M
+
+
+def graph_time_us(launch, n_distinct, iters=200, reps=5):
+    """average launch duration of `launch(i)` (i rotating over n_distinct argument sets) inside one captured graph,
+    HIP events on the launch stream, best of `reps` replays"""
+    import torch
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for i in range(n_distinct):
+            launch(i)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for i in range(iters):
+                launch(i % n_distinct)
+        g.replay()
+        s.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(reps):
+            e0.record(s)
+            g.replay()
+            e1.record(s)
+            s.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+    return best
+
+
+def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
+    """One AP-GEMV shape, default dispatch, rotating over > 512 MB of distinct weights (the 256 MiB Infinity Cache cannot
+    serve them).  fused = None: the plain entry point (gq_anyprec_gemv); "norm": RMSNorm prologue; "norm_pairs": RMSNorm
+    prologue + gate/up pair epilogue (the decode graph's w1w3 launch); "resid": residual epilogue (wo / w2 launches)."""
+    import torch
+    from guidedquant_amd import _lib
+    d = torch.device("cuda", torch.cuda.current_device())
+    per = bits * N * K // 8
+    nbuf = max(2, min(64, (min_ws + per - 1) // per))
+    g = torch.Generator(device=d)
+    g.manual_seed(1)
+    qs = [torch.randint(-2**31, 2**31 - 1, (bits, N, K // 32), dtype=torch.int32, device=d, generator=g) for _ in range(nbuf)]
+    luts = [(torch.randn(N, 1 << bits, device=d, generator=g) * 0.02).half().sort(dim=1).values.contiguous() for _ in range(nbuf)]
+    x = torch.randn(1, 1, K, device=d, generator=g).half()
+    nw = (1 + 0.1 * torch.randn(K, device=d, generator=g)).half()
+    res = torch.randn(N, device=d, generator=g).half()
+    out = torch.empty(1, 1, N, dtype=torch.float16, device=d)
+    L = _lib.lib()
+
+    def run(i):
+        sp = _lib.current_stream_ptr()
+        if fused is None:
+            rc = L.gq_anyprec_gemv(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), 1, N, K, bits, 0, sp)
+        elif fused in ("norm", "norm_pairs"):
+            rc = L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, nw.data_ptr(),
+                                         1e-5, None, 4 if fused == "norm_pairs" else 0, sp)
+        else:
+            rc = L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, None, 0.0,
+                                         res.data_ptr(), 1, sp)
+        assert rc == 0, L.gq_last_error()
+
+    us = graph_time_us(run, nbuf, iters)
+    gbs = b_ap(bits, N, K) / us / 1e3
+    return {"shape": name, "N": N, "K": K, "bits": bits, "launch": fused or "plain", "us": round(us, 3), "GBps": round(gbs, 1),
+            "frac": round(gbs / HBM_PEAK_GBPS, 4)}
+
+
+def decode_tok_s(model, dev, steps, warmup, torch_sampling=False):
+    """tokens/s of the captured decode step (BOS prompt, sequences of 100 new tokens), wall clock around `steps` replays"""
+    import torch
+    from guidedquant_amd.generate import DecodeGraph
+    graph = DecodeGraph(model, dev, native_sampling=not torch_sampling, temperature=0.0, top_k=32)
+    bos = torch.tensor([[(128000 if model.config.vocab_size > 100000 else 1)]], dtype=torch.int32, device=dev)
+    zero = torch.zeros((1, ), dtype=torch.int32, device=dev)
+
+    def run_steps(n):
+        done = 0
+        while done < n:
+            graph.tok.copy_(bos)
+            graph.pos.copy_(zero)
+            for _ in range(min(SEQ_NEW_TOKENS, n - done)):
+                graph.step()
+            done += min(SEQ_NEW_TOKENS, n - done)
+
+    return graph, run_steps
 
 
 def main():
@@ -45,12 +148,14 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--bits", type=int, default=2)
+    ap.add_argument("--backend", choices=["ap", "qtip"], default="ap")
     ap.add_argument("--mode", choices=["default", "exact", "fast"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="headline number and roofline object only (no shape table / exact-mode / CPU legs)")
     ap.add_argument("--parallel", choices=["replicas", "pp"], default="replicas",
-                    help="N>1: independent replicas (default) or the layer pipeline with point-to-point hops (pp)")
-    ap.add_argument("--model", default=MODEL, help="model name from guidedquant_amd.model.transformer_configs (e.g. "
-                    "meta-llama/Llama-3.3-70B-Instruct with --parallel pp on 8 GPUs); the headline metric is quoted on the default")
+                    help="N>1: what `value` measures -- independent replicas (default) or the layer pipeline (pp) of --model")
+    ap.add_argument("--no-pp-record", action="store_true", help="N>1: skip the pipeline_70b sub-record")
+    ap.add_argument("--model", default=None, help="model name from guidedquant_amd.model.transformer_configs; the headline metric is quoted on the default")
     ap.add_argument("--torch-sampling", action="store_true", help="sample with the reference's torch ops instead of the fused HIP sampler")
     args = ap.parse_args()
 
@@ -63,7 +168,7 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -71,29 +176,19 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from guidedquant_amd import _lib
-    from guidedquant_amd.generate import DecodeGraph, load_model, _get_model_size
+    from guidedquant_amd.generate import _get_model_size, load_model
 
     L = _lib.lib()
     if args.mode != "default":
         _lib.check(L.gq_set_ap_mode(1 if args.mode == "exact" else 0), "gq_set_ap_mode")
 
+    qtip = args.backend == "qtip"
+    name = args.model or (QTIP_MODEL if qtip else MODEL)
     torch.manual_seed(1234)
-    model = load_model(args.model, dev, "ap", args.bits, random_init=True)
+    model = load_model(name, dev, "qtip" if qtip else "ap", args.bits, random_init=True)
     cfg = model.config
     model.setup_caches(1, SEQ_NEW_TOKENS + 1)
-    assert model.native_ready()
-    graph = DecodeGraph(model, dev, native_sampling=not args.torch_sampling, temperature=0.0, top_k=32)
-    bos = torch.tensor([[128000 % cfg.vocab_size]], dtype=torch.int32, device=dev)
-    zero = torch.zeros((1, ), dtype=torch.int32, device=dev)
-
-    def run_steps(n):
-        done = 0
-        while done < n:
-            graph.tok.copy_(bos)
-            graph.pos.copy_(zero)
-            for _ in range(min(SEQ_NEW_TOKENS, n - done)):
-                graph.step()
-            done += min(SEQ_NEW_TOKENS, n - done)
+    assert model.native_ready(), "the fused HIP decode step does not serve this model"
 
     def barrier():
         if world > 1:
@@ -102,18 +197,9 @@ def main():
 
     pp = world > 1 and args.parallel == "pp"
     if pp:
-        # layer pipeline: stage r owns a contiguous layer range, `world` sequences in flight, hidden state hops r -> r+1
-        # and token ids hop back to stage 0 over RCCL send/recv; a "step" is still one decoded token (summed over
-        # the sequences), so the job decodes args.steps tokens per rank-equivalent = world * args.steps in total
-        from guidedquant_amd.pipeline import PipelinedDecoder, stage_ranges
-        rng = stage_ranges(cfg.n_layer, world, head_cost_layers=6.0)[rank]
-        dec = PipelinedDecoder(model, rank, world, rng, n_seq=world, max_new_tokens=max(args.steps, args.warmup),
-                               temperature=0.0, top_k=32, bos_id=128000 % cfg.vocab_size)
-
-        def run_steps(n):  # noqa: F811
-            dec.pos = [0] * dec.n_seq
-            with torch.no_grad():
-                dec.run(n)
+        run_steps, dec = pipeline_runner(model, rank, world, max(args.steps, args.warmup))
+    else:
+        graph, run_steps = decode_tok_s(model, dev, args.steps, args.warmup, args.torch_sampling)
 
     run_steps(args.warmup)
     barrier()
@@ -127,18 +213,80 @@ def main():
         dt = float(tmax.item())
     tok_s = world * args.steps / dt
 
-    # ------------------------------------------------------------------ roofline of the dominant quantized kernel
+    roofline = qtip_roofline(cfg, args.bits) if qtip else ap_roofline(model, args.bits, args.mode)
+    extras = {}
+    full = rank == 0 and world == 1 and not args.quick
+    if full and not qtip:
+        table = []
+        for b in (2, 3, 4):
+            for nm, (N, K) in SHAPES_8B.items():
+                table.append(bench_ap_shape(nm, N, K, b, iters=100))
+        extras["roofline_by_shape"] = {"note": "Llama-3-8B GEMV shapes, default dispatch, plain entry point (gq_anyprec_gemv), > 512 MB of "
+                                               "weights rotating, us per launch / algorithmic GB/s / fraction of 8 TB/s", "rows": table}
+        if args.mode == "default":
+            _lib.check(L.gq_set_ap_mode(1), "gq_set_ap_mode")
+            _, run_exact = decode_tok_s(model, dev, 200, 50, args.torch_sampling)
+            run_exact(50)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_exact(200)
+            torch.cuda.synchronize()
+            extras["exact_mode_tok_s"] = round(200 / (time.perf_counter() - t1), 2)
+            _lib.check(L.gq_set_ap_mode(-1), "gq_set_ap_mode")
+    cpu_baseline = None
+    if full and not qtip and not args.no_cpu_baseline:
+        cpu_baseline = cpu_baseline_sample(cfg, args.bits)
+
+    model_size, _ = _get_model_size(model)
+    mode = {"default": "exact" if os.environ.get("GQ_AP_EXACT", "0") != "0" else "default"}.get(args.mode, args.mode)
+    workload = ("%s QTIP %d-bit (trellis-coded, HYB code), unfused linears, bs=1 decode, BOS prompt, 100 new tokens per sequence, "
+                "top_k=32, temperature=0" % (cfg.model_name, args.bits)) if qtip else \
+        ("%s %d-bit Any-Precision (LNQ format), fused QKV/UpGate, bs=1 decode, BOS prompt, 100 new tokens per sequence, top_k=32, "
+         "temperature=0" % (cfg.model_name, args.bits))
+    line = {
+        "metric": "decode tokens/sec (bs=1)", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": workload, "bits": args.bits, "backend": args.backend,
+                   "parallelism": ("pp%d (layer pipeline, p2p hops, %d sequences in flight)" % (world, world)) if pp else ("replicas" if world > 1 else "single"),
+                   "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
+                   "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1)},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+    line.update(extras)
+
+    # ------------------------------------------------------------------ north-star multi-GPU config as a sub-record
+    if world > 1 and not pp and not args.no_pp_record and not qtip:
+        del model, graph, run_steps
+        torch.cuda.empty_cache()
+        line["pipeline_70b"] = guarded_pipeline_record(line, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------- rooflines
+def ap_roofline(model, bits, mode_arg):
+    """the w1w3 AP-GEMV exactly as the decode graph launches it, over the model's own (distinct) tensors"""
+    import torch
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    cfg = model.config
+    dev = model.output.weight.device
     s = torch.cuda.current_stream()
     I, D = cfg.intermediate_size, cfg.dim
     x = torch.randn(D, device=dev).half()
     gu = torch.empty(2 * I, dtype=torch.float16, device=dev)
     nw = model.layers[0].post_attention_layernorm.weight
+    paired = bool(model._native_state()["pairs"])
+    flags = 4 if paired else 0
 
     def w1w3_pass():
         for blk in model.layers:
             m = blk.feed_forward.w1w3
             rc = L.gq_anyprec_gemv_fused(x.data_ptr(), gu.data_ptr(), m.qweight.data_ptr(), m.lut.data_ptr(), 2 * I, D,
-                                         m.bitwidth, nw.data_ptr(), cfg.norm_eps, None, 0, _lib.current_stream_ptr())
+                                         m.bitwidth, nw.data_ptr(), cfg.norm_eps, None, flags, _lib.current_stream_ptr())
             assert rc == 0, L.gq_last_error()
 
     w1w3_pass()
@@ -151,78 +299,178 @@ def main():
     e1.record(s)
     e1.synchronize()
     t_kernel_us = e0.elapsed_time(e1) * 1e3 / (reps * cfg.n_layer)
-    bytes_launch = b_ap(args.bits, 2 * I, D)
+    bytes_launch = b_ap(bits, 2 * I, D)
     achieved = bytes_launch / t_kernel_us / 1e3  # GB/s
-    # HBM bytes per launch from the PMC counters: measured offline (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # passes, tools/prof_bench.sh) for exactly this kernel and shape, committed under profiles/ with its correction
-    traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_w1w3_traffic.json")
-    if args.bits == 2 and cfg.dim == 4096 and I == 14336 and os.path.exists(tpath):
+    exact = mode_arg == "exact" or (mode_arg == "default" and os.environ.get("GQ_AP_EXACT", "0") != "0")
+    # HBM bytes per launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    # tools/prof_bench.sh) for one kernel template, launch form and shape -- reported only when this run launches the same
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r02_w1w3_traffic.json")
+    if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": "AP-GEMV w1w3 %dx%d" % (2 * I, D),
-                "avg_launch_us": round(t_kernel_us, 3), "algorithmic_bytes_per_launch": bytes_launch}
-
-    # ------------------------------------------------------------------ CPU baseline (rank 0 only, bounded sample)
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = cpu_baseline_sample(cfg, args.bits)
-
-    model_size, _ = _get_model_size(model)
-    mode = {"default": "exact" if os.environ.get("GQ_AP_EXACT", "0") != "0" else "default"}.get(args.mode, args.mode)
-    if rank == 0:
-        line = {
-            "metric": "decode tokens/sec (bs=1)", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "%s %d-bit Any-Precision (LNQ format), fused QKV/UpGate, bs=1 decode, "
-                                   "BOS prompt, 100 new tokens per sequence, top_k=32, temperature=0" % (cfg.model_name, args.bits),
-                       "bits": args.bits, "parallelism": ("pp%d (layer pipeline, p2p hops, %d sequences in flight)" % (world, world)) if pp else ("replicas" if world > 1 else "single"), "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
-                       "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1)},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            t = json.load(f)
+        if (not exact and t.get("bits") == bits and t.get("N") == 2 * I and t.get("K") == D and t.get("launch") == ("norm_pairs" if paired else "norm")):
+            traffic, traffic_src = t.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/r02_w1w3_traffic.json)" % t.get("kernel")
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "AP-GEMV w1w3 %dx%d %d-bit, RMSNorm prologue%s (%s kernels)" % (2 * I, D, bits, " + gate/up pair epilogue" if paired else "",
+                                                                                  "exact-order" if exact else "default dispatch"),
+            "avg_launch_us": round(t_kernel_us, 3), "algorithmic_bytes_per_launch": bytes_launch}
 
 
+def qtip_roofline(cfg, R):
+    """the bare trellis-decode matvec at the model's gate/up shape (B_qtip bytes), rotating > 512 MB of trellis words"""
+    import torch
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda", torch.cuda.current_device())
+    M, K = cfg.intermediate_size, cfg.dim
+    per = R * M * K // 8
+    n = max(2, min(64, (512 << 20) // per))
+    tr = [torch.randint(-2**31, 2**31 - 1, (R * M * K // 32, ), dtype=torch.int32, device=d) for _ in range(n)]
+    tl = (torch.randn(1024, device=d) * 0.5).half()
+    x = (torch.randn(K, device=d) / 16).half()
+    y = torch.zeros(M, dtype=torch.float32, device=d)
+
+    def run(i):
+        rc = L.gq_qtip_matvec(y.data_ptr(), tr[i].data_ptr(), x.data_ptr(), tl.data_ptr(), M, K, R, _lib.current_stream_ptr())
+        assert rc == 0, L.gq_last_error()
+
+    us = graph_time_us(run, n, 100)
+    gbs = b_qtip(R, M, K) / us / 1e3
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBPS, 4),
+            "traffic": None, "kernel": "QTIP trellis matvec %dx%d R=%d (gq_qtip_matvec)" % (M, K, R), "avg_launch_us": round(us, 3),
+            "algorithmic_bytes_per_launch": b_qtip(R, M, K)}
+
+
+# ---------------------------------------------------------------------------------------------------------- pipeline
+def pipeline_runner(model, rank, world, max_tokens):
+    import torch
+    from guidedquant_amd.pipeline import PipelinedDecoder, measure_head_cost, stage_ranges
+    cfg = model.config
+    model.setup_caches(world, 1 + max_tokens)
+    head = measure_head_cost(model)
+    rng = stage_ranges(cfg.n_layer, world, head_cost_layers=head)[rank]
+    dec = PipelinedDecoder(model, rank, world, rng, n_seq=world, max_new_tokens=max_tokens, temperature=0.0, top_k=32,
+                           bos_id=128000 % cfg.vocab_size)
+    dec.head_cost_layers = head
+
+    def run_steps(n):
+        dec.reset()
+        with torch.no_grad():
+            dec.run(n)
+
+    return run_steps, dec
+
+
+def guarded_pipeline_record(line, rank, world, dev, limit_s=240.0):
+    """BASELINE configs[4] in the same run: Llama-3.3-70B 2-bit, stage g = a contiguous layer range on GPU g, `world` sequences
+    in flight.  A watchdog prints the replicas line without the record and exits if this leg does not finish in time."""
+    import torch
+    import torch.distributed as dist
+
+    def bail():
+        if rank == 0:
+            line["pipeline_70b"] = {"error": "timed out after %.0f s" % limit_s}
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    timer = threading.Timer(limit_s, bail)
+    timer.daemon = True
+    timer.start()
+    try:
+        from guidedquant_amd.generate import load_model
+        torch.manual_seed(1234)
+        model = load_model(PP_MODEL, dev, "ap", 2, random_init=True)
+        n_tok, n_warm = 48, 8
+        run_steps, dec = pipeline_runner(model, rank, world, n_tok)
+        run_steps(n_warm)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(n_tok)
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        rec = {"model": "Llama-3.3-70B-Instruct 2-bit Any-Precision, fused QKV/UpGate", "stages": world, "sequences_in_flight": world,
+               "tokens_per_sequence": n_tok, "aggregate_tok_s": round(world * n_tok / dt, 2), "per_stream_tok_s": round(n_tok / dt, 2),
+               "ms_per_stage_tick": round(dt / (world * n_tok) * 1e3, 4), "head_cost_layers_measured": dec.head_cost_layers,
+               "layers_per_stage": [len(r) for r in __import__("guidedquant_amd.pipeline", fromlist=["stage_ranges"]).stage_ranges(
+                   model.config.n_layer, world, head_cost_layers=dec.head_cost_layers)],
+               "graphs": bool(dec.graphs), "note": "single-stream 1-GPU figure of the same model: python bench.py --model " + PP_MODEL}
+    except Exception as e:  # the replicas measurement stands on its own
+        rec = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    timer.cancel()
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------- CPU legs
 def cpu_baseline_sample(cfg, bits):
-    """Reference-order AP-GEMV port (oracle/, C + OpenMP) on the host cores: one transformer layer's four GEMVs at
-    full size, extrapolated to tokens/s = 1 / (n_layer * t_layer + t_lm_head).  The reference itself has no CPU
-    kernel for this path."""
+    """CPU baselines of BASELINE.md section 4 on the host cores, one full-size transformer layer (4 GEMVs) each, extrapolated
+    to tokens/s = 1 / (n_layer * t_layer + t_lm_head) with the FULL fp32 lm_head matvec:
+      value  packed native-float GEMV (oracle.ap_gemv_f32: planes + LUT read directly, float accumulation, C + OpenMP)
+      also   dense torch F.linear on the dequantised W (fp32 and bf16) -- what linear_class=nn.Linear would execute;
+             the order-faithful binary16 emulator (oracle.ap_gemv_f16, the parity oracle: exact software half arithmetic);
+             the product's own CPU twin (gq_anyprec_gemv_cpu, AVX2 + OpenMP), for reference
+    The reference itself has no CPU kernel for this path."""
     import numpy as np
     import torch
     from oracle import oracle
-    from guidedquant_amd import pack
+    from guidedquant_amd import ap_gemv, pack
     oracle.build()
     cores = os.cpu_count() or 1
     oracle.set_threads(cores)
+    torch.set_num_threads(cores)
     D, I = cfg.dim, cfg.intermediate_size
     kvd = (cfg.n_head + 2 * cfg.n_local_heads) * cfg.head_dim
     shapes = [(kvd, D), (D, D), (2 * I, D), (D, I)]
     rng = np.random.default_rng(0)
-    t_layer = 0.0
+
+    def best(fn, reps):
+        fn()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            t.append(time.perf_counter() - t0)
+        return min(t)
+
+    t_f32 = t_f16 = t_twin = t_d32 = t_dbf = 0.0
     for N, K in shapes:
         q = pack.random_planes(N, K, bits, seed=N + K)
         lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
         xv = rng.normal(0, 1, K).astype(np.float16)
+        t_f32 += best(lambda: oracle.ap_gemv_f32(xv, q, lut, bits), 3)
         t0 = time.perf_counter()
         oracle.ap_gemv_f16(xv, q, lut, bits)
-        t_layer += time.perf_counter() - t0
-    # dense lm_head on the CPU: fp32 matvec of a 1/8 row sample, scaled
-    rows = cfg.vocab_size // 8
-    W = torch.randn(rows, D, dtype=torch.float32)
-    xv = torch.randn(D, dtype=torch.float32)
-    torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        W @ xv
-    t_lm = (time.perf_counter() - t0) / 3 * 8
-    tok_s = 1.0 / (cfg.n_layer * t_layer + t_lm)
-    return {"value": round(tok_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"one full-size layer (4 AP-GEMVs, fp16-order oracle, {cores} OpenMP threads: {t_layer:.3f} s) x {cfg.n_layer} "
-                      f"+ fp32 lm_head matvec ({t_lm * 1e3:.1f} ms, measured on 1/8 of the rows)"}
+        t_f16 += time.perf_counter() - t0
+        qt, lt = torch.from_numpy(q), torch.from_numpy(lut)
+        xt = torch.from_numpy(xv).view(1, 1, K)
+        ot = torch.empty(1, 1, N, dtype=torch.float16)
+        t_twin += best(lambda: ap_gemv.anyprec_gemv(xt, ot, qt, lt, bits), 3)
+        W = ap_gemv.anyprec_dequant(qt, lt, bits).float()
+        x32 = xt.float().view(1, K)
+        t_d32 += best(lambda: torch.nn.functional.linear(x32, W), 3)
+        Wb, xb = W.bfloat16(), x32.bfloat16()
+        t_dbf += best(lambda: torch.nn.functional.linear(xb, Wb), 3)
+        del W, Wb
+    Wl = torch.randn(cfg.vocab_size, D, dtype=torch.float32)
+    xl = torch.randn(1, D, dtype=torch.float32)
+    t_lm = best(lambda: torch.nn.functional.linear(xl, Wl), 3)
+    del Wl
+
+    def tps(t_layer):
+        return round(1.0 / (cfg.n_layer * t_layer + t_lm), 4)
+
+    return {"value": tps(t_f32), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"one full-size layer (4 AP-GEMVs) per variant x {cfg.n_layer} + the full fp32 lm_head matvec ({t_lm * 1e3:.1f} ms); "
+                      f"value = packed native-float GEMV, oracle.ap_gemv_f32, {cores} OpenMP threads: {t_f32 * 1e3:.2f} ms per layer",
+            "also": {"dense_f32_linear_on_W_deq_tok_s": tps(t_d32), "dense_bf16_linear_on_W_deq_tok_s": tps(t_dbf),
+                     "emulated_fp16_order_oracle_tok_s": tps(t_f16), "product_cpu_twin_tok_s": tps(t_twin),
+                     "ms_per_layer": {"packed_f32": round(t_f32 * 1e3, 2), "dense_f32": round(t_d32 * 1e3, 2), "dense_bf16": round(t_dbf * 1e3, 2),
+                                      "emulated_fp16_order": round(t_f16 * 1e3, 1), "product_cpu_twin": round(t_twin * 1e3, 2)}}}
 
 
 if __name__ == "__main__":

@@ -12,10 +12,10 @@
     (qtip/lib/linear/quantized_linear.py:12-153): buffers `trellis int16[(N/16)(K/16), 16R]`, `tlut fp16[512,2]`,
     `SU fp16[K]`, `SV fp32[N]`, `rcp`, `tp_rank`, non-persistent `had_left/had_right`.
 
-The non-power-of-two Hadamard factors (172, 156, 140, 108, 60, 52, 36, 28, 40, 20, 12) are literal tables in the
-reference (~95k lines of matmul_had.py); they are data of the checkpoint format, not code, and are NOT vendored here:
-`get_hadK` serves powers of two out of the box and looks other factors up in an .npz given by GQ_HADAMARD_TABLES
-(keys "had{K}", int8 +-1 matrices, e.g. exported once from a reference install).
+The non-power-of-two Hadamard factors (172, 156, 140, 124, 116, 108, 60, 52, 36, 28, 20, 12) are literal tables in the
+reference (~95k lines of matmul_had.py); they are data of the checkpoint format, not code: `get_hadK` reads them from the
+bit-packed data file guidedquant_amd/data/hadamard_factors.npz (11 KB, written by tools/make_hadamard_tables.py from the
+reference in the authoring container); GQ_HADAMARD_TABLES may name an .npz (keys "had{K}") that overrides it.
 """
 import math
 import os
@@ -131,12 +131,30 @@ if "hadamard::hadamard" not in _registered:
     _registered.add("hadamard::hadamard")
 
 # --------------------------------------------------------------------------------------------- Hadamard factors
-_HAD_FACTORS = (172, 156, 140, 108, 60, 52, 36, 28, 40, 20, 12)  # order of matmul_had.py:13-67
+_HAD_FACTORS = (172, 156, 140, 124, 116, 108, 60, 52, 36, 28, 20, 12)  # order of matmul_had.py:13-67
 _tables = None
 
 
 def _is_pow2(n):
     return n > 0 and (n & (n - 1)) == 0
+
+
+def _load_hadamard_tables():
+    """the reference's factor matrices (matmul_had.py:133-..., get_had12 .. get_had172) from the packed data file shipped
+    with the package (tools/make_hadamard_tables.py: K x K signs, np.packbits row-major); an .npz named by
+    GQ_HADAMARD_TABLES (keys "had{K}", +-1 matrices) overrides / extends it"""
+    tabs = {}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "hadamard_factors.npz")
+    if os.path.exists(path):
+        with np.load(path) as z:
+            for key in z.files:
+                K = int(key[3:])
+                bits = np.unpackbits(z[key])[:K * K].reshape(K, K)
+                tabs[key] = (bits.astype(np.int8) * 2 - 1)
+    user = os.environ.get("GQ_HADAMARD_TABLES")
+    if user and os.path.exists(user):
+        tabs.update(dict(np.load(user)))
+    return tabs
 
 
 def get_hadK(n, transpose=False):
@@ -148,12 +166,10 @@ def get_hadK(n, transpose=False):
     for K in _HAD_FACTORS:
         if n % K == 0 and _is_pow2(n // K):
             if _tables is None:
-                path = os.environ.get("GQ_HADAMARD_TABLES")
-                _tables = dict(np.load(path)) if path and os.path.exists(path) else {}
+                _tables = _load_hadamard_tables()
             if f"had{K}" not in _tables:
-                raise NotImplementedError(
-                    f"Hadamard factor of order {K} (n = {n}) is a data table of the reference (matmul_had.py) that is not "
-                    "vendored; point GQ_HADAMARD_TABLES at an .npz with key 'had%d'" % K)
+                raise NotImplementedError(f"no Hadamard factor table of order {K} (n = {n}) in guidedquant_amd/data/"
+                                          "hadamard_factors.npz or GQ_HADAMARD_TABLES")
             h = torch.from_numpy(_tables[f"had{K}"].astype(np.float32))
             return (h.T if transpose else h), K
     raise AssertionError(f"no Hadamard factorisation for n = {n}")

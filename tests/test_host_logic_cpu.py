@@ -108,8 +108,23 @@ def test_rope_tables_and_generic_forward_on_cpu():
 def test_qtip_host_side():
     from guidedquant_amd import qtip
     assert qtip.get_hadK(4096) == (None, 1)
-    with pytest.raises(NotImplementedError, match="not vendored|GQ_HADAMARD_TABLES"):
-        qtip.get_hadK(11008)
+    # the reference's factor tables ship as a packed data file (tools/make_hadamard_tables.py); factor order of
+    # matmul_had.py:13-67; every shipped table is a Hadamard matrix and equals the reference-generated golden copies
+    import glob
+    import os
+    import numpy as np
+    for n, K in ((11008, 172), (14336, 28), (5120, 20), (13824, 108), (28672, 28), (6656, 52), (7680, 60), (20480, 20), (15872, 124)):
+        h, k = qtip.get_hadK(n)
+        assert k == K and tuple(h.shape) == (K, K)
+        assert torch.equal(h @ h.T, K * torch.eye(K))
+        ht, _ = qtip.get_hadK(n, transpose=True)
+        assert torch.equal(ht, h.T)
+    for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "had_n*.npz")):
+        g = np.load(f)
+        if int(g["K"]) > 1:
+            assert np.array_equal(g["hadK"], qtip.get_hadK(int(g["n"]))[0].numpy()), f
+    with pytest.raises(AssertionError):
+        qtip.get_hadK(11 * 1024)
     assert qtip.has_kernel('quantlut_sym', 16, 2, 2, 9, 16, 16) and not qtip.has_kernel('lut', 16, 2, 2, 9, 16, 16)
     lin = qtip.QuantizedLinear(256, 512, 16, 16, 16, 3, 2, 9, 'quantlut_sym')
     assert lin.trellis.shape == (32 * 16, 48) and lin.tlut.shape == (512, 2) and lin.SU.shape == (256, ) and lin.SV.dtype == torch.float32

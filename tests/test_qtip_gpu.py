@@ -413,15 +413,14 @@ def test_qtip_native_decode_with_factor_width(tmp_path, monkeypatch, inter, key)
 
 
 def test_qtip_native_decode_with_factor_hidden_size(tmp_path, monkeypatch):
-    """hidden size AND MLP width with Hadamard factors (the Llama-2-13b pattern: 5120 = 40 * 128, 13824 = 108 * 128; here
-    2560 = 40 * 64 and 6912 = 108 * 64): every linear runs transform -> bare matvec -> transform.  The tables are the
-    caller's data; any +-1 matrix exercises the arithmetic, so the test makes its own."""
+    """hidden size AND MLP width with Hadamard factors (the Llama-2-13b pattern: 5120 = 20 * 256, 13824 = 108 * 128; here
+    2560 = 20 * 128 and 6912 = 108 * 64): every linear runs transform -> bare matvec -> transform, with the factor tables
+    shipped in guidedquant_amd/data/hadamard_factors.npz (matmul_had.py:13-67 order: 20 is the first factor of 2560)."""
     from guidedquant_amd import model as gm, qtip
     from guidedquant_amd.generate import load_model
-    rng = np.random.default_rng(3)
-    np.savez(tmp_path / "tables.npz", had40=rng.choice([-1, 1], (40, 40)).astype(np.int8), had108=rng.choice([-1, 1], (108, 108)).astype(np.int8))
-    monkeypatch.setenv("GQ_HADAMARD_TABLES", str(tmp_path / "tables.npz"))
+    monkeypatch.delenv("GQ_HADAMARD_TABLES", raising=False)
     qtip._tables = None
+    assert qtip.get_hadK(2560)[1] == 20 and qtip.get_hadK(6912)[1] == 108
     gm.transformer_configs["qtip-factor13-test"] = dict(model_name="llama-qtip-factor13-test", block_size=128, vocab_size=512, n_layer=2,
                                                         n_head=20, dim=2560, intermediate_size=6912, n_local_heads=20)
     try:

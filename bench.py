@@ -40,6 +40,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# three OpenMP runtimes meet in the CPU legs (torch's libgomp, the oracle's libgomp, the product twins' libomp): idle worker
+# threads must sleep, not spin, or each library's parallel region fights the previous one's spinning pool for the cores
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 MODEL = "meta-llama/Meta-Llama-3.1-8B-Instruct"
 QTIP_MODEL = "meta-llama/Llama-2-7b"
@@ -437,21 +442,27 @@ def cpu_baseline_sample(cfg, bits):
             t.append(time.perf_counter() - t0)
         return min(t)
 
-    t_f32 = t_f16 = t_twin = t_d32 = t_dbf = 0.0
+    layers = []
     for N, K in shapes:
         q = pack.random_planes(N, K, bits, seed=N + K)
         lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
-        xv = rng.normal(0, 1, K).astype(np.float16)
-        t_f32 += best(lambda: oracle.ap_gemv_f32(xv, q, lut, bits), 3)
+        layers.append((N, K, q, lut, rng.normal(0, 1, K).astype(np.float16)))
+    # one variant at a time over the four shapes (the runtimes' thread pools do not alternate inside a measurement)
+    t_f32 = sum(best(lambda: oracle.ap_gemv_f32(xv, q, lut, bits), 3) for N, K, q, lut, xv in layers)
+    t_f16 = 0.0
+    for N, K, q, lut, xv in layers:
         t0 = time.perf_counter()
         oracle.ap_gemv_f16(xv, q, lut, bits)
         t_f16 += time.perf_counter() - t0
+    t_twin = t_d32 = t_dbf = 0.0
+    for N, K, q, lut, xv in layers:
         qt, lt = torch.from_numpy(q), torch.from_numpy(lut)
         xt = torch.from_numpy(xv).view(1, 1, K)
         ot = torch.empty(1, 1, N, dtype=torch.float16)
-        t_twin += best(lambda: ap_gemv.anyprec_gemv(xt, ot, qt, lt, bits), 3)
-        W = ap_gemv.anyprec_dequant(qt, lt, bits).float()
-        x32 = xt.float().view(1, K)
+        t_twin += best(lambda: ap_gemv.anyprec_gemv(xt, ot, qt, lt, bits), 5)
+    for N, K, q, lut, xv in layers:
+        W = ap_gemv.anyprec_dequant(torch.from_numpy(q), torch.from_numpy(lut), bits).float()
+        x32 = torch.from_numpy(xv).float().view(1, K)
         t_d32 += best(lambda: torch.nn.functional.linear(x32, W), 3)
         Wb, xb = W.bfloat16(), x32.bfloat16()
         t_dbf += best(lambda: torch.nn.functional.linear(xb, Wb), 3)

@@ -56,6 +56,9 @@ def lib():
         # torch first: it ships its own libamdhip64; the extension must bind to the HIP runtime torch has already loaded, or
         # the process ends up with two runtimes and the extension's sees no device ("no ROCm-capable device is detected")
         import torch  # noqa: F401
+        # the CPU twins run on LLVM's OpenMP runtime next to torch's libgomp pool: its idle workers must sleep at once
+        # (default: spin for 200 ms), or they take the cores from the torch ops that follow
+        os.environ.setdefault("KMP_BLOCKTIME", "0")
         L = ctypes.CDLL(LIB_PATH)
         vp, u32, i32, f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
         L.gq_version.restype = i32

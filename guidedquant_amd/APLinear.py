@@ -12,6 +12,7 @@ does not accumulate), so zeroing only cost a kernel launch per linear per token.
 import torch
 import torch.nn as nn
 
+from . import ap_gemv
 from .plugin import anyprec_dequant, anyprec_gemv
 
 
@@ -39,6 +40,10 @@ class APLinear(nn.Module):
         return self
 
     def gemm(self, x):
+        # prefill rows: the MFMA GEMM with the dequantisation fused in (no dense copy of W); shapes / devices it does not
+        # serve take the reference's two steps, dequantise + matmul (APLinear.py:35-38)
+        if ap_gemv.anyprec_gemm_supported(x, self.qweight, self.bitwidth):
+            return ap_gemv.anyprec_gemm(x, self.qweight, self.lut, self.bitwidth)
         weight = anyprec_dequant(self.qweight, self.lut, self.bitwidth)
         return torch.matmul(x, weight.T)
 

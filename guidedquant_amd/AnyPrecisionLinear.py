@@ -55,7 +55,9 @@ class AnyPrecisionLinear(nn.Module):
             w_bits = kwargs['precision']
         else:
             w_bits = self.precision
-        if x.numel() // x.shape[-1] > 1:
+        if x.numel() // x.shape[-1] > 1 and ap_gemv.anyprec_gemm_supported(x, self.qweight, w_bits):
+            x = ap_gemv.anyprec_gemm(x, self.qweight, self._buffers[f'lut{w_bits}'].to(torch.float16), w_bits)
+        elif x.numel() // x.shape[-1] > 1:
             weight = ap_gemv.anyprec_dequant(self.qweight, self._buffers[f'lut{w_bits}'].to(torch.float16),
                                              w_bits).to(x.dtype)
             x = torch.matmul(x, weight.T)

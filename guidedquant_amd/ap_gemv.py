@@ -97,6 +97,34 @@ def anyprec_dequant(qweight, lut, bitwidth):
     return weight
 
 
+def anyprec_gemm_supported(x, qweight, bitwidth):
+    """True when the fused prefill GEMM (gq_anyprec_gemm) serves this call: GPU tensors, fp16, 2..4 bits, K % 64 == 0"""
+    import os
+    return (x.is_cuda and qweight.is_cuda and x.dtype == torch.float16 and 2 <= int(bitwidth) <= 4 and x.shape[-1] % 64 == 0
+            and os.environ.get("GQ_PREFILL_FUSED", "1") != "0")
+
+
+def anyprec_gemm(x, qweight, lut, bitwidth):
+    """x fp16 [..., K] (more than one row) -> fp16 [..., N] = x @ dequant(qweight, lut).T with the dequantisation fused into
+    the MFMA loop: the seq_len > 1 branch of APLinear.forward (inference/APLinear.py:35-50) without the dense copy of W."""
+    bitwidth = int(bitwidth)
+    _chk(2 <= bitwidth <= 4, "fused prefill GEMM serves bit widths 2..4.")
+    _chk(qweight.dtype == torch.int32 and qweight.dim() == 3 and qweight.size(0) >= bitwidth, "qweight tensor must be int32 of shape (>= bitwidth, N, K/32).")
+    _chk(lut.dtype == torch.float16 and lut.dim() == 2 and lut.size(0) == qweight.size(1) and lut.size(1) == (1 << bitwidth),
+         "lut tensor must be float16 of shape (output_feat, 2 ** bitwidth).")
+    _chk(x.dtype == torch.float16 and x.is_cuda and qweight.is_cuda and lut.is_cuda, "x, qweight and lut must be float16 / int32 tensors on the GPU.")
+    _chk(qweight.is_contiguous() and lut.is_contiguous(), "qweight and lut tensors must be contiguous.")
+    N, K = qweight.size(1), qweight.size(2) * 32
+    _chk(x.shape[-1] == K, "input_feat mismatch.")
+    x2 = x.reshape(-1, K).contiguous()
+    out = torch.empty((x2.size(0), N), dtype=torch.float16, device=x.device)
+    with _dev_guard(qweight):
+        rc = _lib.lib().gq_anyprec_gemm(x2.data_ptr(), out.data_ptr(), qweight.data_ptr(), lut.data_ptr(), x2.size(0), N, K, bitwidth,
+                                        _lib.current_stream_ptr())
+    _lib.check(rc, "anyprec_gemm")
+    return out.reshape(*x.shape[:-1], N)
+
+
 def lutgemm_gemv(input, output, q_weight, alpha, q_bias, bitwidth, group_size):
     bitwidth, group_size = int(bitwidth), int(group_size)
     _chk(1 <= bitwidth <= 8, "Bitwidth must be between 1 and 8.")

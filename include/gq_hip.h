@@ -80,6 +80,17 @@ int gq_anyprec_dequant(const uint32_t *qweight, const void *lut, void *W, uint32
                        void *stream);
 
 /*
+ * Any-Precision prefill GEMM with the dequantisation fused into the matrix-core loop.
+ *   out[s][n] = sum_k x[s][k] * lut[n][code(n,k)]        x fp16 [S][K], out fp16 [S][N] (written)
+ * Replaces the seq_len > 1 branch of APLinear.forward / AnyPrecisionLinear.forward (inference/APLinear.py:35-50,
+ * any_precision/modules/AnyPrecisionLinear.py:69-71): ap_gemv.anyprec_dequant (dequant_kbit_store, anyprec.cu:294-359) followed
+ * by torch.matmul -- without writing and re-reading the dense fp16 copy of W.  fp32 accumulation, one rounding to fp16.
+ * bits 2..4, K % 64 == 0 (GQ_ENOTSUP otherwise: the caller keeps the dequant path); qweight may hold more planes than bits.
+ */
+int gq_anyprec_gemm(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t S, uint32_t N, uint32_t K,
+                    int bits, void *stream);
+
+/*
  * Host (CPU) twins of the two Any-Precision entry points: same arguments with HOST pointers, no stream; `nthreads` <= 0
  * uses the OpenMP default.  They serve BASELINE.json configs[0] ("CPU reference APLinear path via generate.py"): the module
  * semantics of inference/APLinear.py:35-60 with the tensors in host memory (the reference hard-codes 'cuda',

@@ -136,3 +136,34 @@ def run_fused(x, q, lut, bits, norm_weight=None, eps=1e-5, residual=None, flags=
     _lib.check(rc, "gq_anyprec_gemv_fused")
     torch.cuda.synchronize()
     return out.cpu().numpy()
+
+
+def tiny_hf_anyprec_checkpoint(path, D=128, I=256, H=4, KV=2, Lr=2, V=96, seed=2):
+    """write an HF-layout Any-Precision checkpoint directory (config.json with the `anyprec` section incl. arch_config,
+    pack.py:190-195; model.safetensors with `...{qweight,lut2,lut3}` keys, pack.py:112-123) of a tiny Llama; returns
+    (LlamaConfig, state dict, module names, dims)"""
+    import json
+    import torch
+    import transformers
+    from safetensors.torch import save_file
+    hf_cfg = transformers.LlamaConfig(hidden_size=D, intermediate_size=I, num_hidden_layers=Lr, num_attention_heads=H, num_key_value_heads=KV,
+                                      vocab_size=V, max_position_embeddings=64, rms_norm_eps=1e-5, tie_word_embeddings=False)
+    names = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
+    cfg = hf_cfg.to_dict()
+    cfg["anyprec"] = dict(seed_precision=2, parent_precision=3, group_count=1,
+                          arch_config=dict(module_names=names, model_name="model", layers_name="layers"))
+    (path / "config.json").write_text(json.dumps(cfg))
+    g = torch.Generator().manual_seed(seed)
+    hd = D // H
+    shapes = dict(zip(names, [(D, D), (KV * hd, D), (KV * hd, D), (D, D), (I, D), (I, D), (D, I)]))
+    sd = {"model.embed_tokens.weight": (torch.randn(V, D, generator=g) * 0.5).half(), "model.norm.weight": torch.ones(D).half(),
+          "lm_head.weight": (torch.randn(V, D, generator=g) * 0.2).half()}
+    for i in range(Lr):
+        sd[f"model.layers.{i}.input_layernorm.weight"] = torch.ones(D).half()
+        sd[f"model.layers.{i}.post_attention_layernorm.weight"] = torch.ones(D).half()
+        for name, (n, k) in shapes.items():
+            sd[f"model.layers.{i}.{name}.qweight"] = torch.randint(-2**31, 2**31 - 1, (3, n, k // 32), dtype=torch.int32, generator=g)
+            for b in (2, 3):
+                sd[f"model.layers.{i}.{name}.lut{b}"] = (torch.randn(n, 2**b, generator=g) * 0.08).sort(dim=1).values.half().contiguous()
+    save_file(sd, str(path / "model.safetensors"))
+    return hf_cfg, sd, names, (D, I, H, KV, Lr, V)

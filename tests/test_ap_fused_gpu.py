@@ -277,3 +277,35 @@ def test_anyprecision_linear_forward_multi_precision(oracle, mode):
                               "lut2": torch.full((N, 4), 60000.0, dtype=torch.float16)})
         big = lin2(torch.full((1, 1, K), 100.0, dtype=torch.float16, device=d))
         assert float(big.float().abs().max()) == float(torch.tensor(torch.finfo(torch.float16).max * (1.0 - 5e-3)).half())
+
+
+def test_anyprecision_for_causal_lm_on_gpu(tmp_path):
+    """the HF path on the GPU (inference_example.py:34-77 harness shape): from_quantized -> HF generate with the rows == 1
+    calls on the HIP LUT-GEMV; logits against the dense HF model holding the dequantised weights, at 2 and 3 bits"""
+    transformers = pytest.importorskip("transformers")
+    from ap_helpers import tiny_hf_anyprec_checkpoint
+    from guidedquant_amd import ap_gemv
+    from guidedquant_amd.AnyPrecisionForCausalLM import AnyPrecisionForCausalLM
+    hf_cfg, sd, names, (D, I, H, KV, Lr, V) = tiny_hf_anyprec_checkpoint(tmp_path, D=512, I=1024, H=8, KV=2, V=256)
+    d = torch.device("cuda:0")
+    m = AnyPrecisionForCausalLM.from_quantized(str(tmp_path))
+    assert m.device.type == "cuda" and m.ap_linears[0].qweight.is_cuda and m.ap_linears[0].output.is_cuda
+    ids = torch.tensor([[3, 17, 5, 60, 2]], device=d)
+    for b in (2, 3):
+        dense = transformers.LlamaForCausalLM(hf_cfg).half()
+        dsd = {k: v for k, v in sd.items() if not (k.endswith(".qweight") or ".lut" in k)}
+        for i in range(Lr):
+            for name in names:
+                p = f"model.layers.{i}.{name}"
+                dsd[p + ".weight"] = ap_gemv.anyprec_dequant(sd[p + ".qweight"], sd[p + f".lut{b}"], b)
+        dense.load_state_dict(dsd, strict=True)
+        dense = dense.to(d)
+        with torch.no_grad():
+            want = dense(ids).logits.float()
+            got = m(ids, precision=b).logits.float()
+            got1 = m(ids[:, :1], precision=b).logits.float()
+        assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max())
+        assert float((got1[0, 0] - want[0, 0]).abs().max()) <= 2e-2 * float(want.abs().max())
+    out = m.generate(ids[:, :2], max_new_tokens=8, do_sample=False, precision=2)
+    ref = transformers.LlamaForCausalLM(hf_cfg)  # noqa: F841  (shape only)
+    assert out.shape == (1, 10) and m.precision == 3

@@ -1,0 +1,109 @@
+"""GPU parity: the fused-dequant prefill GEMM (gq_anyprec_gemm, csrc/ap_gemm.hip) -- the seq_len > 1 branch of
+APLinear.forward (inference/APLinear.py:35-50: anyprec_dequant + matmul) -- against the oracle's dequantised matrix times x
+in float64.  fp32 accumulation, one fp16 rounding: |got - exact| <= 2^-11 |exact| + 1e-5 * sum|x||w| (tolerance stated here)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(x, q, lut, bits):
+    from guidedquant_amd import ap_gemv
+    d = torch.device("cuda:0")
+    out = ap_gemv.anyprec_gemm(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float16)).to(d), torch.from_numpy(np.ascontiguousarray(q)).to(d),
+                               torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float16)).to(d), bits)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _check(got, x, q, lut, bits, oracle, rows=None):
+    if rows is not None:
+        q, lut, got = np.ascontiguousarray(q[:, rows, :]), lut[rows], got[:, rows]
+    W = oracle.ap_dequant(q, lut, bits).astype(np.float64)
+    X = np.asarray(x, dtype=np.float16).astype(np.float64)
+    ref = X @ W.T
+    scale = np.abs(X) @ np.abs(W).T
+    err = np.abs(got.astype(np.float64) - ref)
+    assert np.isfinite(got.astype(np.float32)).all()
+    assert (err <= 2.0**-11 * 1.001 * np.abs(ref) + 1e-5 * scale + 1e-7).all(), (err / (scale + 1e-30)).max()
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("ap_b") if int(np.load(p)["bits"]) in (2, 3, 4) and int(np.load(p)["qweight"].shape[2]) % 2 == 0])
+def test_gemm_goldens(oracle, path):
+    """the reference-generated fixtures (pack.py planes, _dequantize_weight W): x = the fixture vector stacked with noise rows"""
+    g = np.load(path)
+    bits = int(g["bits"])
+    K = g["qweight"].shape[2] * 32
+    rng = np.random.default_rng(1)
+    X = np.concatenate([g["x"].reshape(1, K), rng.normal(0, 1, (6, K)).astype(np.float16)])
+    got = _gemm(X, g["qweight"], g["lut"], bits)
+    ref = X.astype(np.float64) @ g["W"].astype(np.float64).T
+    scale = np.abs(X.astype(np.float64)) @ np.abs(g["W"].astype(np.float64)).T
+    assert (np.abs(got.astype(np.float64) - ref) <= 2.0**-11 * 1.001 * np.abs(ref) + 1e-5 * scale + 1e-7).all()
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("N,K,S", [(256, 4096, 5), (128, 1024, 128), (200, 1088, 33), (130, 2048, 129), (64, 11008, 77), (36, 64, 3),
+                                   (100, 1984, 260)])
+def test_gemm_random(oracle, bits, N, K, S):
+    """row / token / K tails: N not a multiple of 128 (or 4), S not a multiple of 128, tail chunks of 64 .. 960 weights"""
+    rng = np.random.default_rng(bits * 977 + N + K + S)
+    codes = rng.integers(0, 1 << bits, (N, K), dtype=np.uint8)
+    q = oracle.ap_pack(codes, bits)
+    lut = (rng.normal(0, 1, (N, 1 << bits)) * 10.0**rng.integers(-3, 1, (N, 1))).astype(np.float16)
+    X = (rng.normal(0, 1, (S, K)) * np.where(rng.random((S, K)) < 0.02, 20.0, 1.0)).astype(np.float16)
+    _check(_gemm(X, q, lut, bits), X, q, lut, bits, oracle)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("N,K,S", [(6144, 4096, 512), (28672, 4096, 256), (4096, 14336, 384), (4096, 11008, 130)])
+def test_gemm_full_size_sampled_rows(oracle, bits, N, K, S):
+    from guidedquant_amd import pack
+    rng = np.random.default_rng(bits + N + K)
+    q = pack.random_planes(N, K, bits, seed=bits * 31 + N)
+    lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
+    X = rng.normal(0, 1, (S, K)).astype(np.float16)
+    got = _gemm(X, q, lut, bits)
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(N - 40, N), rng.integers(0, N, 64)]))
+    _check(got, X, q, lut, bits, oracle, rows=rows)
+
+
+def test_gemm_is_deterministic_and_row_independent(oracle):
+    """size-independent properties: replays are bit-identical; a token's output row does not depend on what else is in the batch"""
+    from guidedquant_amd import pack
+    bits, N, K = 2, 1024, 4096
+    rng = np.random.default_rng(5)
+    q = pack.random_planes(N, K, bits, seed=9)
+    lut = np.sort(rng.normal(0, 0.02, (N, 4)).astype(np.float16), axis=1)
+    X = rng.normal(0, 1, (200, K)).astype(np.float16)
+    a, b = _gemm(X, q, lut, bits), _gemm(X, q, lut, bits)
+    assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+    c = _gemm(X[37:150], q, lut, bits)
+    assert np.array_equal(a[37:150].view(np.uint16), c.view(np.uint16))
+
+
+def test_modules_take_the_fused_gemm_for_prefill_rows(oracle):
+    """APLinear / AnyPrecisionLinear with seq_len > 1: the fused GEMM and the reference's dequant + matmul branch agree"""
+    from guidedquant_amd.APLinear import APLinear
+    d = torch.device("cuda:0")
+    bits, N, K = 3, 512, 2048
+    rng = np.random.default_rng(2)
+    codes = rng.integers(0, 1 << bits, (N, K), dtype=np.uint8)
+    q, lut = oracle.ap_pack(codes, bits), rng.normal(0, 0.03, (N, 1 << bits)).astype(np.float16)
+    lin = APLinear(K, N, bits, device=d)
+    lin.load_state_dict({"qweight": torch.from_numpy(q), "lut": torch.from_numpy(lut)})
+    xs = torch.from_numpy(rng.normal(0, 1, (1, 70, K)).astype(np.float16)).to(d)
+    y = lin(xs)
+    assert tuple(y.shape) == (1, 70, N) and y.dtype == torch.float16
+    _check(y.cpu().numpy()[0], xs.cpu().numpy()[0], q, lut, bits, oracle)
+    os.environ["GQ_PREFILL_FUSED"] = "0"
+    try:
+        y0 = lin(xs)
+    finally:
+        del os.environ["GQ_PREFILL_FUSED"]
+    assert float((y.float() - y0.float()).abs().max()) <= 2e-2 * float(y0.float().abs().max())

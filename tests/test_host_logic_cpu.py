@@ -308,3 +308,45 @@ def test_gate_up_rows_are_paired_in_place_and_exported_in_reference_layout():
     ff.w1w3.gq_row_pairs = True  # rows now (gate_0, up_0, ..): output index 2i is gate_i, 2i+1 is up_i
     paired = ff(x)
     assert torch.equal(paired.view(-1), (2 * torch.arange(256.0)) * (2 * torch.arange(256.0) + 1))
+
+
+def test_anyprecision_for_causal_lm_from_quantized_on_cpu(tmp_path):
+    """the HF-path entry (any_precision/modules/AnyPrecisionForCausalLM.py:123-168): a checkpoint directory with the `anyprec`
+    config section -> HF Llama with AnyPrecisionLinear modules; forward(precision=b) equals the same HF model with the
+    dequantised weights in nn.Linear; set_precision / prune_precisions / generate; host tensors run the CPU twins"""
+    transformers = pytest.importorskip("transformers")
+    from ap_helpers import tiny_hf_anyprec_checkpoint
+    from guidedquant_amd import ap_gemv
+    from guidedquant_amd.AnyPrecisionForCausalLM import AnyPrecisionForCausalLM
+    from guidedquant_amd.AnyPrecisionLinear import AnyPrecisionLinear
+    hf_cfg, sd, names, (D, I, H, KV, Lr, V) = tiny_hf_anyprec_checkpoint(tmp_path)
+    hd = D // H
+    m = AnyPrecisionForCausalLM.from_quantized(str(tmp_path), device="cpu")
+    assert m.supported_bits == [2, 3] and m.precision == 3 and len(m.ap_linears) == 7 * Lr
+    assert all(isinstance(l, AnyPrecisionLinear) for l in m.ap_linears) and m.layer_type == "LlamaDecoderLayer"
+    ids = torch.tensor([[3, 17, 5, 60, 2]])
+    for b in (2, 3):
+        dense = transformers.LlamaForCausalLM(hf_cfg).half()
+        dsd = {k: v for k, v in sd.items() if not (k.endswith(".qweight") or ".lut" in k)}
+        for i in range(Lr):
+            for name in names:
+                p = f"model.layers.{i}.{name}"
+                dsd[p + ".weight"] = ap_gemv.anyprec_dequant(sd[p + ".qweight"], sd[p + f".lut{b}"], b)
+        dense.load_state_dict(dsd, strict=True)
+        with torch.no_grad():
+            want = dense.float()(ids).logits
+            got = m(ids, precision=b).logits.float()           # prefill rows: dequant + matmul
+            got1 = m(ids[:, :1], precision=b).logits.float()   # one row: the GEMV twin
+        assert m.precision == 3  # restored
+        assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max())
+        assert float((got1[0, 0] - want[0, 0]).abs().max()) <= 2e-2 * float(want.abs().max())
+    out = m.generate(ids[:, :2], max_new_tokens=4, do_sample=False, precision=2)
+    assert out.shape == (1, 6) and m.precision == 3
+    with pytest.raises(RuntimeError):
+        m.set_precision(4)
+    with pytest.raises(NotImplementedError):
+        m.fuse_layers()
+    m2 = AnyPrecisionForCausalLM.from_quantized(str(tmp_path), precisions=[2], device="cpu")
+    assert m2.ap_linears[0].qweight.shape[0] == 2 and not hasattr(m2.ap_linears[0], "lut3")
+    nat = m2.native_decoder()
+    assert nat.layers[0].attention.wqkv.bitwidth == 2 and nat.layers[0].attention.wqkv.qweight.shape == (2, D + 2 * KV * hd, D // 32)

@@ -98,10 +98,19 @@ def anyprec_dequant(qweight, lut, bitwidth):
 
 
 def anyprec_gemm_supported(x, qweight, bitwidth):
-    """True when the fused prefill GEMM (gq_anyprec_gemm) serves this call: GPU tensors, fp16, 2..4 bits, K % 64 == 0"""
+    """True when a seq_len > 1 call should take the fused prefill GEMM (gq_anyprec_gemm).  It serves GPU fp16 tensors, 2..4
+    bits, K % 64 == 0.  GQ_PREFILL_FUSED=1 sends every such call to it, =0 none; by default ("auto") only the calls it was
+    measured faster on than the reference's two steps (dequantise + hipBLASLt GEMM; profiles/r02_prefill_gemm.txt): large
+    matrices with short prompts, where writing and re-reading the dense copy of W dominates (8B gate/up at S <= 128: 1.1-1.3x;
+    at S = 2048 the fused kernel reaches 0.25-0.31 of the fp16 MFMA peak against ~0.48 for hipBLASLt)."""
     import os
-    return (x.is_cuda and qweight.is_cuda and x.dtype == torch.float16 and 2 <= int(bitwidth) <= 4 and x.shape[-1] % 64 == 0
-            and os.environ.get("GQ_PREFILL_FUSED", "1") != "0")
+    if not (x.is_cuda and qweight.is_cuda and x.dtype == torch.float16 and 2 <= int(bitwidth) <= 4 and x.shape[-1] % 64 == 0):
+        return False
+    mode = os.environ.get("GQ_PREFILL_FUSED", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    rows = x.numel() // x.shape[-1]
+    return rows <= 160 and qweight.size(1) * x.shape[-1] >= 100_000_000
 
 
 def anyprec_gemm(x, qweight, lut, bitwidth):
@@ -123,6 +132,21 @@ def anyprec_gemm(x, qweight, lut, bitwidth):
                                         _lib.current_stream_ptr())
     _lib.check(rc, "anyprec_gemm")
     return out.reshape(*x.shape[:-1], N)
+
+
+def anyprec_pack(codes, bitwidth):
+    """codes uint8 [N, K] on the GPU -> qweight int32 [bitwidth, N, K // 32], the packed format of
+    any_precision/quantization/pack.py:304-321 (bit-identical to the host packer guidedquant_amd.pack.pack_codes)"""
+    bitwidth = int(bitwidth)
+    _chk(1 <= bitwidth <= 8, "Bitwidth must be between 1 and 8.")
+    _chk(codes.dtype == torch.uint8 and codes.dim() == 2 and codes.is_cuda and codes.is_contiguous(), "codes must be a contiguous uint8 [N, K] tensor on the GPU.")
+    N, K = codes.shape
+    _chk(K % 32 == 0, "K must be a multiple of 32.")
+    q = torch.empty((bitwidth, N, K // 32), dtype=torch.int32, device=codes.device)
+    with _dev_guard(codes):
+        rc = _lib.lib().gq_anyprec_pack(codes.data_ptr(), q.data_ptr(), N, K, bitwidth, _lib.current_stream_ptr())
+    _lib.check(rc, "anyprec_pack")
+    return q
 
 
 def lutgemm_gemv(input, output, q_weight, alpha, q_bias, bitwidth, group_size):

@@ -78,7 +78,7 @@ __device__ __forceinline__ f16x8 decode_byte(const u32 *w, u32 shift, const gq::
 template <int BITS>
 __global__ void __launch_bounds__(256, 2) ap_gemm_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ out,
                                                           const u32 *__restrict__ qw, const uint16_t *__restrict__ lut, u32 S, u32 N,
-                                                          u32 K) {
+                                                          u32 K, u32 dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages of [BS][ROWB]
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, r = lane & 31u, g = lane >> 5;
     const u32 n0 = blockIdx.x * BN + wave * 32u, s0 = blockIdx.y * BS;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) ap_gemm_kernel(const uint16_t *__restr
         Cursor nx = cur;
         advance(nx);
         const bool more = nx.chunk < nchunks;
-        if (more) {
+        if (more && !(dbg & 2u)) {  // (GQ_GEMM_DBG=2: no x traffic after the first stage)
             u32 a0, a1, an;
             stage_geom(nx, a0, a1, an);
             load_stage(a0, a1, an);  // in flight during the MFMAs below
@@ -184,7 +184,14 @@ __global__ void __launch_bounds__(256, 2) ap_gemm_kernel(const uint16_t *__restr
                 u32 wq[BITS];
 #pragma unroll
                 for (int p = 0; p < BITS; p++) wq[p] = w[p][q];
-                const f16x8 a = decode_byte<BITS>(wq, shift, L);
+                f16x8 a;
+                if (dbg & 1u) {  // ablation (GQ_GEMM_DBG=1): no decode
+                    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 t = {wq[0], wq[1], wq[0] ^ shift, wq[1] + (u32)q};
+                    a = __builtin_bit_cast(f16x8, t);
+                } else {
+                    a = decode_byte<BITS>(wq, shift, L);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const f16x8 b = *reinterpret_cast<const f16x8 *>(xs + (u32)j * 32u * ROWB + (u32)q * 16u);
@@ -230,7 +237,7 @@ int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u
     if (once.first_use())
         GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 grid((N + BN - 1u) / BN, (S + BS - 1u) / BS), block(256);
-    hipLaunchKernelGGL(kern, grid, block, smem, s, (const uint16_t *)x, (uint16_t *)out, qw, (const uint16_t *)lut, S, N, K);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, (const uint16_t *)x, (uint16_t *)out, qw, (const uint16_t *)lut, S, N, K, (u32)gq_env_int("GQ_GEMM_DBG", 0));
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

@@ -80,6 +80,13 @@ int gq_anyprec_dequant(const uint32_t *qweight, const void *lut, void *W, uint32
                        void *stream);
 
 /*
+ * Any-Precision packer on the device: codes u8 [N][K] (values < 2^bits) -> qweight u32 [bits][N][K/32], bit-identical to the
+ * host packer of a quantization run (any_precision/quantization/pack.py:12-83,101-110,304-321: np.packbits per plane + the
+ * warp byte permutation).  codes 8-byte aligned, K % 32 == 0, bits 1..8 (the parent precision).
+ */
+int gq_anyprec_pack(const uint8_t *codes, uint32_t *qweight, uint32_t N, uint32_t K, int bits, void *stream);
+
+/*
  * Any-Precision prefill GEMM with the dequantisation fused into the matrix-core loop.
  *   out[s][n] = sum_k x[s][k] * lut[n][code(n,k)]        x fp16 [S][K], out fp16 [S][N] (written)
  * Replaces the seq_len > 1 branch of APLinear.forward / AnyPrecisionLinear.forward (inference/APLinear.py:35-50,

@@ -98,7 +98,11 @@ def test_modules_take_the_fused_gemm_for_prefill_rows(oracle):
     lin = APLinear(K, N, bits, device=d)
     lin.load_state_dict({"qweight": torch.from_numpy(q), "lut": torch.from_numpy(lut)})
     xs = torch.from_numpy(rng.normal(0, 1, (1, 70, K)).astype(np.float16)).to(d)
-    y = lin(xs)
+    os.environ["GQ_PREFILL_FUSED"] = "1"  # (auto sends only large matrices with short prompts to the fused kernel)
+    try:
+        y = lin(xs)
+    finally:
+        del os.environ["GQ_PREFILL_FUSED"]
     assert tuple(y.shape) == (1, 70, N) and y.dtype == torch.float16
     _check(y.cpu().numpy()[0], xs.cpu().numpy()[0], q, lut, bits, oracle)
     os.environ["GQ_PREFILL_FUSED"] = "0"
@@ -107,3 +111,35 @@ def test_modules_take_the_fused_gemm_for_prefill_rows(oracle):
     finally:
         del os.environ["GQ_PREFILL_FUSED"]
     assert float((y.float() - y0.float()).abs().max()) <= 2e-2 * float(y0.float().abs().max())
+
+
+@pytest.mark.parametrize("path", golden_files("ap_b"))
+def test_device_packer_goldens_bit_exact(oracle, path):
+    """gq_anyprec_pack against the reference-generated planes (pack.py pack_single_weight goldens, bits 2..8, tail chunks)"""
+    from guidedquant_amd import ap_gemv
+    g = np.load(path)
+    bits = int(g["bits"])
+    codes = oracle.ap_unpack(g["qweight"], bits)
+    q = ap_gemv.anyprec_pack(torch.from_numpy(codes).cuda(), bits)
+    assert np.array_equal(q.cpu().numpy(), g["qweight"])
+    # any-precision prefix property: packing the parent codes and keeping the first b planes == packing codes >> (bits - b)
+    for b in range(1, bits):
+        qb = ap_gemv.anyprec_pack(torch.from_numpy(codes >> (bits - b)).cuda(), b)
+        assert torch.equal(qb, q[:b])
+
+
+def test_device_packer_full_size_round_trip():
+    """size-independent property at a BASELINE shape: pack on the device -> dequantise on the device == lut[codes]; and equals
+    the host packer"""
+    from guidedquant_amd import ap_gemv, pack
+    d = torch.device("cuda:0")
+    N, K, bits = 4096, 14336, 3
+    g = torch.Generator(device=d)
+    g.manual_seed(4)
+    codes = torch.randint(0, 1 << bits, (N, K), dtype=torch.uint8, device=d, generator=g)
+    lut = torch.randn(N, 1 << bits, device=d, generator=g).half()
+    q = ap_gemv.anyprec_pack(codes, bits)
+    W = ap_gemv.anyprec_dequant(q, lut, bits)
+    assert torch.equal(W, torch.gather(lut, 1, codes.long()))
+    rows = [0, 1, 777, N - 1]
+    assert np.array_equal(q[:, rows].cpu().numpy(), pack.pack_codes(codes[rows].cpu().numpy(), bits))

@@ -20,6 +20,9 @@ What one stage tick is on the GPU (native path):
     ticks later, after its send has completed;
   * forward hops and the token feedback use two process groups: with one communicator per rank pair, posted-ahead receives
     and sends of the two directions between the same pair (world = 2) would wait for each other in stream order.
+  * transport: device tensors go straight into isend / irecv (RCCL).  With a backend that only moves host memory (gloo; used
+    to run the multi-rank native path on ONE GPU in the tests) each hop is staged through a pinned host buffer -- same
+    schedule, same graphs.
 `stage_ranges(.., head_cost_layers=measure_head_cost(model))` balances the stages with the measured cost of the head.
 `PipelinedDecoder.run(n_tokens)` decodes n_tokens for each of the S sequences and returns them (on every rank).
 """
@@ -104,6 +107,11 @@ class PipelinedDecoder:
         self.pos = [0] * S                                            # host mirror (eager path only)
         self.use_graphs = (self.native and dev.type == "cuda") if use_graphs is None else use_graphs
         self.graphs = None
+        # host staging: the process group cannot move device memory (gloo) but the model lives on a GPU
+        self.staged = world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo"
+        if self.staged:
+            self.h_host = torch.zeros(S, c.dim, dtype=dt).pin_memory()
+            self.tok_host = torch.zeros(S, dtype=torch.int32).pin_memory()
         if self.native and self.last:
             self.rng_counter = torch.zeros(1, dtype=torch.int32, device=dev)
             self.work_val = torch.zeros(128 * 32, dtype=torch.float32, device=dev)
@@ -212,18 +220,40 @@ class PipelinedDecoder:
         recv_req = [None] * S  # the posted receive of each slot's next input
         send_req = [None] * S  # the last send out of each slot's buffer
 
+        class _StagedRecv:  # irecv into the pinned host row, copy to the device buffer on wait
+            def __init__(s_, req, host, devt):
+                s_.req, s_.host, s_.devt = req, host, devt
+
+            def wait(s_):
+                s_.req.wait()
+                s_.devt.copy_(s_.host, non_blocking=True)
+
+        def irecv(devt, host, src, group):
+            if not self.staged:
+                return dist.irecv(devt, src=src, group=group)
+            return _StagedRecv(dist.irecv(host, src=src, group=group), host, devt)
+
+        def isend(devt, host, dst, group):
+            if not self.staged:
+                return dist.isend(devt, dst=dst, group=group)
+            host.copy_(devt, non_blocking=True)
+            torch.cuda.current_stream().synchronize()  # the device-to-host copy has landed before the host send reads it
+            return dist.isend(host, dst=dst, group=group)
+
+        tok_stage = self.tok_host.clone().pin_memory() if self.staged else None  # send side of the token feedback
+
         def post_recv(step, slot):
             """post the receive of tick (step, slot)'s input, if it comes from another rank"""
             if step >= n_tokens or recv_req[slot] is not None:
                 return
             if self.first:
                 if step > 0 and w > 1:
-                    recv_req[slot] = dist.irecv(self.tok[slot:slot + 1], src=w - 1, group=self.fb_group)
+                    recv_req[slot] = irecv(self.tok[slot:slot + 1], self.tok_host[slot:slot + 1] if self.staged else None, w - 1, self.fb_group)
             else:
                 if send_req[slot] is not None:  # the buffer's previous content must have left before it is overwritten
                     send_req[slot].wait()
                     send_req[slot] = None
-                recv_req[slot] = dist.irecv(self.h[slot], src=r - 1, group=self.group)
+                recv_req[slot] = irecv(self.h[slot], self.h_host[slot] if self.staged else None, r - 1, self.group)
 
         def nxt(step, slot):
             return (step, slot + 1) if slot + 1 < S else (step + 1, 0)
@@ -244,14 +274,14 @@ class PipelinedDecoder:
                     send_req[slot] = None
                 self._tick(slot)
                 if not self.last:
-                    send_req[slot] = dist.isend(self.h[slot], dst=r + 1, group=self.group)
+                    send_req[slot] = isend(self.h[slot], self.h_host[slot] if self.staged else None, r + 1, self.group)
                 else:
                     out[slot, step:step + 1].copy_(self.tok_out[slot:slot + 1])
                     if w > 1 and step + 1 < n_tokens:
                         if send_req[slot] is not None:
                             send_req[slot].wait()
                         # the token leaves from the output row (stable storage: tok_out[slot] is rewritten next step)
-                        send_req[slot] = dist.isend(out[slot, step:step + 1], dst=0, group=self.fb_group)
+                        send_req[slot] = isend(out[slot, step:step + 1], tok_stage[slot:slot + 1] if self.staged else None, 0, self.fb_group)
         for req in send_req:
             if req is not None:
                 req.wait()

@@ -32,19 +32,22 @@ def _model(dev):
     return m.eval()
 
 
-def _worker(rank, world, port, ntok, q):
+def _worker(rank, world, port, ntok, q, backend="nccl", one_gpu=False):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.cuda.set_device(0 if one_gpu else rank)
+    dev = torch.device("cuda", 0 if one_gpu else rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from guidedquant_amd.pipeline import PipelinedDecoder, stage_ranges
         model = _model(dev)
         rng = stage_ranges(model.config.n_layer, world, head_cost_layers=1.0)[rank]
         dec = PipelinedDecoder(model, rank, world, rng, n_seq=world, max_new_tokens=ntok, temperature=0.0, top_k=32, bos_id=1)
-        assert dec.native and dec.graphs is not None
+        assert dec.native and dec.graphs is not None and dec.staged == (backend == "gloo")
         with torch.no_grad():
             out = dec.run(ntok)
             dec.reset()
@@ -81,3 +84,32 @@ def test_pipelined_native_decode_two_gpus_equals_single_gpu():
             if p.is_alive():
                 p.kill()
     assert got[0] == ref and got[1] == ref and got2 == got
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_native_decode_ranks_sharing_one_gpu(world):
+    """the multi-rank NATIVE path on the one GPU a gpurun box has: `world` processes on cuda:0, gloo process group (hops staged
+    through pinned host buffers), one hipGraph per (stage, slot), device-side positions, posted receives, separate feedback
+    communicator -- tokens of every sequence equal the single-process decode, also on a second run over the same graphs"""
+    import torch.multiprocessing as mp
+    from guidedquant_amd.generate import generate
+    ntok = 12
+    d0 = torch.device("cuda", 0)
+    ref = generate(_model(d0), torch.tensor([1], dtype=torch.int32, device=d0), ntok, use_graph=False, temperature=0.0, top_k=32)[0, 1:].tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ntok, q, "gloo", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got, got2 = q.get(timeout=400)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert all(row == ref for row in got) and got2 == got

@@ -174,11 +174,20 @@ def main():
         print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    # GQ_BENCH_ONE_GPU=1 (with GQ_BENCH_BACKEND=gloo): every rank on cuda:0 -- exercises the N > 1 code path (replicas line,
+    # pipeline_70b record, watchdog) on a one-GPU box; the numbers of such a run mean nothing
+    one_gpu = os.environ.get("GQ_BENCH_ONE_GPU", "0") != "0"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GQ_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from guidedquant_amd import _lib
     from guidedquant_amd.generate import _get_model_size, load_model
@@ -262,9 +271,12 @@ def main():
 
     # ------------------------------------------------------------------ north-star multi-GPU config as a sub-record
     if world > 1 and not pp and not args.no_pp_record and not qtip:
-        del model, graph, run_steps
-        torch.cuda.empty_cache()
-        line["pipeline_70b"] = guarded_pipeline_record(line, rank, world, dev)
+        try:
+            del model, graph, run_steps
+            torch.cuda.empty_cache()
+            line["pipeline_70b"] = guarded_pipeline_record(line, rank, world, dev)
+        except Exception as e:  # never lose the replicas line to this leg
+            line["pipeline_70b"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -87,6 +87,17 @@ int gq_anyprec_dequant(const uint32_t *qweight, const void *lut, void *W, uint32
 int gq_anyprec_pack(const uint8_t *codes, uint32_t *qweight, uint32_t N, uint32_t K, int bits, void *stream);
 
 /*
+ * LNQ coordinate descent, one 128-column block (any_precision/quantization/layerwise_quantize.py:93-118, the inner loop of
+ * update_P): for j = col_start .. col_end - 1 in order, per output row:  sol = W[j] - B[j];  a = argmin_c |sol - C[c]| (lowest
+ * index on ties);  assign[j] = a, What[j] = C[a];  B[k] += (C[a] - W[j]) * Hn[j][k] for j < k < col_end.
+ *   W, B, What f32 [N][d] (B is read, its running copy lives in LDS);  Hn f32 [groups][d][d] = H with column k divided by
+ *   H[k][k];  C f32 [N][n_cluster], 2 <= n_cluster <= 16;  assign u8 [N][d];  group_rows = N / groups, a multiple of 32.
+ * fp32, the reference's operation order, no contraction.
+ */
+int gq_lnq_cd_block(const float *W, const float *B, const float *Hn, const float *C, uint8_t *assign, float *What, uint32_t N,
+                    uint32_t d, uint32_t n_cluster, uint32_t group_rows, uint32_t col_start, uint32_t col_end, void *stream);
+
+/*
  * Any-Precision prefill GEMM with the dequantisation fused into the matrix-core loop.
  *   out[s][n] = sum_k x[s][k] * lut[n][code(n,k)]        x fp16 [S][K], out fp16 [S][N] (written)
  * Replaces the seq_len > 1 branch of APLinear.forward / AnyPrecisionLinear.forward (inference/APLinear.py:35-50,

@@ -259,6 +259,33 @@ def lutgemm_f64(x, qweight, alpha, q_bias, bits, group_size):
     return o
 
 
+# --------------------------------------------------------------------------- LNQ inner loop
+def lnq_cd_block_np(W, B, Hn, C, group_rows, st, end):
+    """The sequential 128-column inner loop of update_P (any_precision/quantization/layerwise_quantize.py:93-118), float32
+    with the reference's operation order (product rounded, then added), vectorised over the independent rows.
+    W, B f32 [N, d]; Hn f32 [G, d, d] (column k of H divided by H[k][k]); C f32 [N, n_cluster].
+    Returns (assign u8 [N, end - st], What f32 [N, end - st]); ties of the argmin go to the lowest index."""
+    W, B, Hn, C = (np.asarray(a, dtype=np.float32) for a in (W, B, Hn, C))
+    N = W.shape[0]
+    nb = end - st
+    Bb = B[:, st:end].copy()
+    grp = np.arange(N) // group_rows
+    assign = np.zeros((N, nb), dtype=np.uint8)
+    What = np.zeros((N, nb), dtype=np.float32)
+    for j in range(nb):
+        w = W[:, st + j]
+        sol = (w - Bb[:, j]).astype(np.float32)
+        dist = np.abs((sol[:, None] - C).astype(np.float32))
+        arg = dist.argmin(axis=1)
+        val = C[np.arange(N), arg]
+        assign[:, j], What[:, j] = arg, val
+        if j + 1 < nb:
+            delta = (val - w).astype(np.float32)
+            h = Hn[grp, st + j, st + j + 1:end]
+            Bb[:, j + 1:] = (Bb[:, j + 1:] + (delta[:, None] * h).astype(np.float32)).astype(np.float32)
+    return assign, What
+
+
 # --------------------------------------------------------------------------- QTIP
 def qtip_decode(compressed, tlut, M, K, R):
     """compressed int32[R*M*K/32], tlut fp16[512,2] -> W fp16[M,K]  (kernel_decompress.py:5-55)"""

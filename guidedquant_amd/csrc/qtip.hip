@@ -40,104 +40,403 @@ __device__ __forceinline__ u32 unit_of<3>(const u32 (&d)[3], u32 j) {
 template <>
 __device__ __forceinline__ u32 unit_of<4>(const u32 (&d)[4], u32 j) { return d[j]; }
 
-// one 32-row band M2 of the matvec: xs (fp16 [K]) and the codebook tl are in LDS (barrier done by the caller), part is
-// [waves][32] scratch; out[M2 * 32 .. + 31] is written by the first 32 threads
-struct QtipNoop {
-    __device__ __forceinline__ void operator()() const {}
+#ifndef QT_ABL
+#define QT_ABL 0  // experiments (tools/qtip_ablation.sh): 1 no codebook lookups, 2 no MFMA, 4 no ds_bpermute, 8 no activation read, 16 no state arithmetic, 32 no FWHT, 64 no codebook fill
+#endif
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+unsigned long long *g_qdbg = nullptr;  // optional per-wave phase stamps of the middle block (tools/qtip_phase_timing.py)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ the band engine
+// Round 2 redesign (round 1: one v_dot2 per state, one 2 KiB codebook with ~3.5-way bank conflicts, 8 VALU per state).
+//
+// Lane <-> trellis mapping.  The format hands lane s = 4 a + b of a 16x16 tile the states of rows a, a + 8 and columns
+// 2b, 2b+1, 2b+8, 2b+9 -- the A fragment of the reference's mma.sync.  v_mfma_f32_16x16x32_f16 wants lane (g = l / 16,
+// r = l % 16) to hold 8 k-slots of ONE row r, all 16 rows of a lane group g agreeing on the columns.  Which global bytes a
+// lane loads is free, so lane l = 16 b + 8 a4 + a takes stream unit s = 4 a + b of tile row a4 (the two 16-row halves of
+// the band are the two halves of the 16 logical rows), for BOTH column tiles a3 = 0, 1 of the 32-column tile block:
+//   A operand "rows a"     = states i = 0, 2 of a3 = 0, 1  -> columns 2g + {0,1}, 16 + 2g + {0,1}, 8 + 2g + {0,1}, 24 + 2g + {0,1}
+//   A operand "rows a + 8" = states i = 1, 3                (same columns),
+//   B operand (all 16 columns equal) = those 8 activations: ONE ds_read_b128 of a copy of x stored in that order.
+// Two MFMAs per 32 x 32 tile block replace 8 v_dot2 per lane and the cross-lane sums; fp32 accumulation as before.
+//
+// State arithmetic, R = 2 (two states per register; halves = column tiles a3 = 0 / 1):
+//   pack  = {unit(a3 = 1), unit(a3 = 0)} (one v_perm), npack = the neighbour lane's pack (one ds_bpermute);
+//   P_i   = 16-bit windows at bit offset 4 i of {pack : npack} per half (i = 0: pack itself; 7 ops for i = 1..3);
+//   M_i   = v_pk_mad_u16(P_i, P_i, P_i) = st (st + 1) mod 2^16 per half: bits 6..14 = codebook entry, bit 15 = sign;
+//   entry address = ((M & 0xFFC0) << 1) | 4 (lane % 32): the codebook is held 32 times, entry-major (128 bytes per entry,
+//   lane l reads copy l % 32: ds_read_b32 is banked (a / 4) % 32 per 32-lane group, so every lookup is conflict-free), and
+//   sign-expanded (1024 entries; entry 512 + e = entry e with the low half negated) when the 128 KiB fit beside the
+//   activations (SX = 1), else 512 entries + 3 ops per register for the sign (SX = 0).
+// R = 3, 4 build the same P_i registers through 64-bit shifts (generic path).
+//
+// Work distribution: `nitems` items = (32-row band, K range); block b walks items b, b + gridDim, ... with ONE codebook
+// fill and ONE activation prologue; the 16 waves of a block split an item's tile blocks (K2 = k2lo + w, + W, ...), their
+// register prefetch queue (PF tile blocks per wave) runs across item boundaries.  The sum of a band is formed in a fixed
+// order: tile blocks in ascending order within a wave (MFMA accumulator), waves in ascending order through LDS.
+template <int SX>
+struct QtipTab {
+    static constexpr u32 ENT = SX ? 1024u : 512u;
+    static constexpr u32 WORDS = ENT * 32u;
 };
-// `between` runs behind the request of the first PF tile blocks (the caller's prologue: it does not depend on them)
-template <int R, class F = QtipNoop>
-__device__ __forceinline__ void qtip_band(float *out, const u32 *comp, const uint16_t *xs, const u32 *tl, float *part, u32 M2, u32 K,
-                                          F between = F(), u32 k2lo = 0u, u32 k2hi = 0xFFFFFFFFu) {
-    const u32 T = blockDim.x, tid = threadIdx.x, W = T >> 6, w = tid >> 6, l = tid & 63u;
-    const u32 a4 = l >> 5, s = l & 31u;  // tile-row parity, stream unit
-    const u32 a = s >> 2, b = s & 3u;
-    const u32 nK2 = K / 32u;
-    const unsigned char *band = reinterpret_cast<const unsigned char *>(comp) + (size_t)M2 * nK2 * 128u * R;
-    float acc0 = 0.f, acc1 = 0.f;        // rows a and a + 8 of tile row 2*M2 + a4
-    // The stream of a wave is a chain of 4R-byte-per-lane loads: with one load in flight per wave a CU has 4 KiB
-    // outstanding and the kernel is latency-bound (measured 0.35 TB/s).  PF tile blocks are requested ahead.
-    constexpr u32 PF = 8;
-    u32 dq[PF][R];
-    if (k2hi > nK2) k2hi = nK2;  // the K range of this block (split-K launches: a part of the band)
-    auto fetch = [&](u32 slot, u32 K2) {
-        if (K2 < k2hi) {
-            const u32 *row = reinterpret_cast<const u32 *>(band + (size_t)K2 * 128u * R + (size_t)s * 4u * R);
+
+// Codebook fill.  Lane c % 8 of a group of 8 writes 16-byte chunk c % 8 of entry c / 8: a wave-instruction covers 1 KiB of
+// contiguous LDS (entry-per-lane stores -- stride 128 bytes -- put all lanes on the same 4 banks: measured 8,500 cycles for
+// the fill, 5x).  With 1024 threads chunk tid + 1024 k belongs to entry tid / 8 + 128 k: four words per thread, REQUESTED
+// BEFORE the first tile blocks (vector memory returns in order: behind them the words would arrive after ~4,000 cycles), the
+// sign-expanded upper half of the table from the same four registers.
+struct QtipTabRegs {
+    u32 w[4];
+};
+__device__ __forceinline__ void qtip_table_request(QtipTabRegs &r, const uint16_t *tlut) {
+    if (blockDim.x == 1024u) {
 #pragma unroll
-            for (int i = 0; i < R; i++) dq[slot][i] = __builtin_nontemporal_load(row + i);
-        }
-    };
+        for (u32 k = 0; k < 4; k++) r.w[k] = reinterpret_cast<const u32 *>(tlut)[(threadIdx.x >> 3) + 128u * k];
+    }
+}
+template <int SX>
+__device__ __forceinline__ void qtip_fill_table(u32 *tab, const uint16_t *tlut, const QtipTabRegs &r) {
+    const u32 T = blockDim.x, tid = threadIdx.x;
+#if QT_ABL & 64
+    if (tid < 64u) tab[tid] = r.w[0];
+    return;
+#endif
+    if (T == 1024u) {
 #pragma unroll
-    for (u32 p = 0; p < PF; p++) fetch(p, k2lo + w + p * W);
-    between();
-    for (u32 K2b = k2lo + w; K2b < k2hi; K2b += W * PF) {
-#pragma unroll
-        for (u32 p = 0; p < PF; p++) {
-            const u32 K2 = K2b + p * W;
-            if (K2 >= k2hi) break;
-            u32 d[R];
-#pragma unroll
-            for (int i = 0; i < R; i++) d[i] = dq[p][i];
-            fetch(p, K2 + W * PF);
-#pragma unroll
-            for (u32 a3 = 0; a3 < 2; a3++) {
-                const u32 u = unit_of<R>(d, 2u * a3 + a4);
-                const u32 un = (u32)__shfl((int)u, (int)((l & 32u) | ((s + 1u) & 31u)), 64);
-                const u64 comb = ((u64)u << (8 * R)) | (u64)un;
-                const u32 comb32 = (u << 16) | un;  // R == 2: the whole window in one register
-                const uint16_t *xk = xs + 32u * K2 + 16u * a3 + 2u * b;
-                const u32 x0 = *reinterpret_cast<const u32 *>(xk), x1 = *reinterpret_cast<const u32 *>(xk + 8);
-#pragma unroll
-                for (u32 i = 0; i < 4; i++) {
-                    // state -> st * (st + 1) (24-bit multiply-add: st < 2^16) -> codebook word at byte (idx >> 4) & 0x7FC,
-                    // sign of the low half folded in with one 3-input op
-                    const u32 st = R == 2 ? __builtin_amdgcn_ubfe(comb32, 16u - 4u * i, 16u)
-                                          : (u32)(comb >> (16 * R - 2 * R * i - 16)) & 0xFFFFu;
-                    // st * (st + 1) as ONE 24-bit multiply-add.  Written in asm: the compiler knows that only bits 6..15 of the
-                    // result are used, drops the 16-bit mask of st and then needs a full-width v_mad_u64_u32 (quarter rate) for
-                    // the windows that are wider than 24 bits; v_mad_u32_u24 ignores the upper bits by itself.
-                    u32 idx;
-                    asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(idx) : "v"(st));
-                    const u32 w2 = *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(tl) + ((idx >> 4) & 0x7FCu)) ^ (idx & 0x8000u);
-                    const u32 xv = (i & 2u) ? x1 : x0;  // cc = i / 2
-                    if (i & 1u)                        // d = i % 2
-                        acc1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, w2), __builtin_bit_cast(h16x2, xv), acc1, false);
-                    else
-                        acc0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, w2), __builtin_bit_cast(h16x2, xv), acc0, false);
-                }
+        for (u32 k = 0; k < 4; k++) {
+            const u32 wv = r.w[k];
+            reinterpret_cast<u32x4 *>(tab)[tid + 1024u * k] = u32x4{wv, wv, wv, wv};
+            if (SX) {
+                const u32 ws = wv ^ 0x8000u;
+                reinterpret_cast<u32x4 *>(tab)[tid + 1024u * (k + 4u)] = u32x4{ws, ws, ws, ws};
             }
         }
+        return;
     }
-    // sum over the 4 lanes b = 0..3 of a row (one quad)
-    acc0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc0), 0xB1, 0xF, 0xF, false));
-    acc0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc0), 0x4E, 0xF, 0xF, false));
-    acc1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc1), 0xB1, 0xF, 0xF, false));
-    acc1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc1), 0x4E, 0xF, 0xF, false));
-    if (b == 0) {
-        part[w * 32u + a4 * 16u + a] = acc0;
-        part[w * 32u + a4 * 16u + a + 8u] = acc1;
-    }
-    __syncthreads();
-    if (tid < 32u) {
-        float t = 0.f;
-        for (u32 i = 0; i < W; i++) t += part[i * 32u + tid];
-        out[M2 * 32u + tid] = t;
+    for (u32 c = tid; c < QtipTab<SX>::ENT * 8u; c += T) {
+        const u32 e = c >> 3;
+        u32 wv = reinterpret_cast<const u32 *>(tlut)[e & 511u];
+        if (SX && (e & 512u)) wv ^= 0x8000u;
+        reinterpret_cast<u32x4 *>(tab)[c] = u32x4{wv, wv, wv, wv};
     }
 }
 
+// position (in halves) of activation k inside the permuted copy: tile block K2 = k / 32, pair q = (k % 32) / 2 -> lane group
+// g = q % 4, slot {0, 2, 1, 3}[q / 4] (the order of the A registers above), element k % 2
+__device__ __forceinline__ u32 qtip_xpos(u32 k) {
+    const u32 q = (k >> 1) & 15u, qc = q >> 2;
+    const u32 slot = ((qc & 1u) << 1) | (qc >> 1);
+    return (k & ~31u) + ((q & 3u) << 3) + (slot << 1) + (k & 1u);
+}
+// 8 consecutive activations (k = 8 u .. 8 u + 7, packed as 4 words) -> the permuted copy (4 ds_write_b32)
+__device__ __forceinline__ void qtip_store_x8(uint16_t *xsp, u32 u, const u32 (&o)[4]) {
+    u32 *dst = reinterpret_cast<u32 *>(xsp) + (u >> 2) * 16u;
+    const u32 qc = u & 3u, slot = ((qc & 1u) << 1) | (qc >> 1);
+#pragma unroll
+    for (u32 e = 0; e < 4; e++) dst[e * 4u + slot] = o[e];
+}
+
+struct QtItem {
+    u32 boff;    // byte offset of the band inside the linear's trellis tensor
+    float *out;  // 32 sums
+    u32 k2lo, k2hi;
+};
+struct QtipNoop {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// The trellis stream is requested in CHUNKS of CH consecutive tile blocks, one wave-instruction of LW bytes per lane each
+// (R = 2: 4 tile blocks = 64 x 16 bytes; R = 3: 2 = 64 x 12; R = 4: 2 = 64 x 16).  Measured (tools/ubench/qtip_stream.hip):
+// 8 bytes per lane -- one tile block per instruction, what this kernel did before -- streams the 12.6 MB of q/k/v in 6.1 us,
+// 16 bytes per lane in 3.9 us, whatever the queue depth.  The loaded rows are then in "loader order" (lane = tile block x
+// row of units); a 1 KiB LDS slot per wave turns them into the MFMA lane order: the loader lane stores its 16 bytes (R = 2:
+// already as the four {column tile 1 : column tile 0} packs of its two unit rows and both 16-row halves), each consumer lane
+// reads its own and its neighbour's (one dword each at R = 2).  LDS operations of ONE wave are served in order, so the slot
+// needs no barrier and no second buffer: the reads of a chunk are issued before the store of the next one.
 template <int R>
+struct QtChunk {
+    static constexpr u32 CH = R == 2 ? 4u : 2u;
+    static constexpr u32 LD = R == 3 ? 3u : 4u;          // dwords per lane and load
+    static constexpr u32 BYTES = CH * 128u * (u32)R;     // = 64 * 4 * LD
+};
+
+template <int R>
+__device__ __forceinline__ void qtip_load_chunk(u32 (&d)[QtChunk<R>::LD], __amdgpu_buffer_rsrc_t rs, u32 voff, u32 soff) {
+    if constexpr (R == 3) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 2 /* nt */);
+        d[0] = v[0], d[1] = v[1], d[2] = v[2];
+    } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 2);
+        d[0] = v[0], d[1] = v[1], d[2] = v[2], d[3] = v[3];
+    }
+}
+
+// comp / comp_bytes: the trellis tensor the items of this block index into (one linear per block).
+// stg: [waves] 1 KiB slots.  Items' K ranges start at multiples of CH tile blocks.
+// WC: waves per block if known at compile time (16: the activation reads of a loop use immediate offsets), 0: blockDim / 64.
+template <int R, int SX, int WC, class ItemFn, class F>
+__device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp, float *part, unsigned char *stg, const u32 *comp, u32 comp_bytes,
+                                            u32 nitems, ItemFn item_of, F between, unsigned long long *dbg = nullptr) {
+    constexpr u32 CH = QtChunk<R>::CH, LD = QtChunk<R>::LD, CB = QtChunk<R>::BYTES;
+    const u32 T = blockDim.x, tid = threadIdx.x, W = WC ? (u32)WC : T >> 6, l = tid & 63u;
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // (wave-uniform: the loop tests stay on the scalar unit)
+    const u32 g = l >> 4, a4 = (l >> 3) & 1u, a = l & 7u, s = 4u * a + g;
+    const u32 sn = (s + 1u) & 31u;  // the window of unit s ends in unit s + 1 of the same tile (cyclic)
+    const u32 lane4 = (l & 31u) * 4u, voff = l * (4u * LD);
+    const unsigned char *tabb = reinterpret_cast<const unsigned char *>(tab);
+    unsigned char *slot = stg + w * 1024u;
+    // R = 2: the slot holds, per loader lane (tile block tb = lane / 16, unit rows 2 j, 2 j + 1), 16 bytes
+    // {pack(2j, half 0), pack(2j + 1, half 0), pack(2j, half 1), pack(2j + 1, half 1)} at 256 tb + 16 j
+    const unsigned char *own_p = slot + (R == 2 ? 16u * (s >> 1) + 8u * a4 + 4u * (s & 1u) : s * (4u * R));
+    const unsigned char *nbr_p = slot + (R == 2 ? 16u * (sn >> 1) + 8u * a4 + 4u * (sn & 1u) : sn * (4u * R));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)comp, 0, (int)comp_bytes, 0x00020000);
+    constexpr u32 PF = 2;  // chunks per wave in flight
+    u32 dq[PF][LD];
+    u32 nstamp = 0;
+    auto stamp = [&]() {
+        if (dbg && blockIdx.x == gridDim.x / 2 && l == 0 && nstamp < 8u) dbg[w * 8u + nstamp++] = __builtin_readcyclecounter();
+    };
+    stamp();
+    u32 j = blockIdx.x;
+    if (j >= nitems) return;  // (whole block)
+    QtItem cur = item_of(j);
+    // Queue refill without vector ALU work: the lane part of the address is a constant VGPR, the chunk a scalar offset.
+    // A slot with nothing left to fetch re-reads the last chunk of the item (a cache hit, never used).
+    auto fetch = [&](u32 p, const QtItem &it, u32 c) {
+        const u32 chi = (it.k2hi + CH - 1u) / CH, cc = c < chi ? c : chi - 1u;
+        qtip_load_chunk<R>(dq[p], rs, voff, it.boff + cc * CB);
+    };
+#pragma unroll
+    for (u32 p = 0; p < PF; p++) fetch(p, cur, cur.k2lo / CH + w + p * W);
+    stamp();
+    between();
+    stamp();
+    f32x4 accA[2], accB[2];  // even / odd tile blocks: no MFMA waits for the one before it
+    const u32 emask = SX ? 0xFFC0FFC0u : 0x7FC07FC0u;
+    auto lookup2 = [&](u32 P, u32 &wlo, u32 &whi) {
+        u32 m;
+        u32 alo, ahi;
+#if QT_ABL & 16
+        m = P;
+        alo = (P & 0x7F80u) | lane4;
+        ahi = alo + 128u;
+#else
+        asm("v_pk_mad_u16 %0, %1, %1, %1" : "=v"(m) : "v"(P));
+        const u32 y = m & emask;
+        // byte address = 2 * (entry << 6) + 4 * (lane % 32), per 16-bit half (v_mad_u32_u16: half select, times 2, plus lane)
+        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[0,0,0,0]" : "=v"(alo) : "v"(y), "v"(lane4));
+        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(ahi) : "v"(y), "v"(lane4));
+#endif
+#if QT_ABL & 1
+        wlo = alo, whi = ahi;
+#else
+        wlo = *reinterpret_cast<const u32 *>(tabb + alo);
+        whi = *reinterpret_cast<const u32 *>(tabb + ahi);
+#endif
+        if (!SX) {
+            const u32 sg = m & 0x80008000u;
+            wlo ^= sg & 0xFFFFu;
+            whi ^= sg >> 16;
+        }
+    };
+    // A chunk and its tile blocks in stages, so that the LDS round trips of several tile blocks are in flight:
+    //   chunk_in: the loaded registers -> the wave's LDS slot (the queue slot is refilled right away);
+    //   stage_a : this lane's units and its neighbour's (both column tiles) out of the slot;
+    //   stage_b : the four state-pair registers -> 8 codebook lookups + the activations (ds_read);
+    //   stage_c : two MFMAs.
+    struct TbA {
+        u32 own[R == 2 ? 1 : 2], nbr[R == 2 ? 1 : 2];
+    };
+    struct TbB {
+        u32x4 wa, wb, xb;
+    };
+    auto chunk_store = [&](const u32 (&d)[LD]) {
+        if constexpr (R == 2) {
+            const u32x4 q = {__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
+                             __builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u)};
+            *reinterpret_cast<u32x4 *>(slot + l * 16u) = q;
+        } else {
+#pragma unroll
+            for (u32 i = 0; i < LD; i++) reinterpret_cast<u32 *>(slot + l * (4u * LD))[i] = d[i];
+        }
+    };
+    auto stage_a = [&](u32 tbk, TbA &t) {
+        if constexpr (R == 2) {
+            t.own[0] = *reinterpret_cast<const u32 *>(own_p + tbk * 256u);
+            t.nbr[0] = *reinterpret_cast<const u32 *>(nbr_p + tbk * 256u);
+        } else {
+            u32 d0[R], d1[R];
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                d0[i] = reinterpret_cast<const u32 *>(own_p + tbk * (128u * R))[i];
+                d1[i] = reinterpret_cast<const u32 *>(nbr_p + tbk * (128u * R))[i];
+            }
+#pragma unroll
+            for (u32 a3 = 0; a3 < 2; a3++) t.own[a3] = unit_of<R>(d0, 2u * a3 + a4), t.nbr[a3] = unit_of<R>(d1, 2u * a3 + a4);
+        }
+    };
+    auto stage_b = [&](const TbA &t, const uint16_t *xrow, TbB &o) {
+        u32 P[4];
+        if constexpr (R == 2) {
+            // windows at bit offsets 4 i of {pack : npack}, both halves at once: (pack << 4 i) | (npack >> (16 - 4 i)) under a
+            // per-half mask (one 3-input bit operation; shifts are 4-byte encodings: half the issue cost of VOP3 forms)
+            const u32 pack = t.own[0], npack = t.nbr[0];
+            P[0] = pack;
+            P[1] = ((pack << 4) & 0xFFF0FFF0u) | ((npack >> 12) & 0x000F000Fu);
+            P[2] = __builtin_amdgcn_perm(pack, npack, 0x06030401u);
+            P[3] = ((pack << 12) & 0xF000F000u) | ((npack >> 4) & 0x0FFF0FFFu);
+        } else {
+            const u64 comb0 = ((u64)t.own[0] << (8 * R)) | (u64)t.nbr[0], comb1 = ((u64)t.own[1] << (8 * R)) | (u64)t.nbr[1];
+#pragma unroll
+            for (u32 i = 0; i < 4; i++) {
+                const u32 sh = 16 * R - 2 * R * i - 16;
+                P[i] = ((u32)(comb0 >> sh) & 0xFFFFu) | ((u32)(comb1 >> sh) << 16);
+            }
+        }
+        u32 t0, t1;
+        lookup2(P[0], t0, t1);
+        o.wa[0] = t0, o.wa[1] = t1;
+        lookup2(P[2], t0, t1);
+        o.wa[2] = t0, o.wa[3] = t1;
+        lookup2(P[1], t0, t1);
+        o.wb[0] = t0, o.wb[1] = t1;
+        lookup2(P[3], t0, t1);
+        o.wb[2] = t0, o.wb[3] = t1;
+#if QT_ABL & 8
+        o.xb = o.wa;
+#else
+        o.xb = *reinterpret_cast<const u32x4 *>(xrow);
+#endif
+    };
+    auto stage_c = [&](const TbB &o, u32 par) {
+#if QT_ABL & 2
+        accA[par][0] += __builtin_bit_cast(float, o.wa[0] ^ o.wa[1] ^ o.wa[2] ^ o.wa[3] ^ o.xb[0]);
+        accB[par][0] += __builtin_bit_cast(float, o.wb[0] ^ o.wb[1] ^ o.wb[2] ^ o.wb[3] ^ o.xb[1]);
+        return;
+#endif
+        accA[par] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, o.wa), __builtin_bit_cast(h16x8, o.xb), accA[par], 0, 0, 0);
+        accB[par] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, o.wb), __builtin_bit_cast(h16x8, o.xb), accB[par], 0, 0, 0);
+    };
+    const uint16_t *xg = xsp + 8u * g;  // this lane group's 8 activations of tile block K2: xg + 32 K2
+    u32 flip = 0;
+    for (;;) {
+        const u32 jn = j + gridDim.x;
+        const bool has_next = jn < nitems;
+        const QtItem nxt = has_next ? item_of(jn) : cur;
+        const u32 chi = (cur.k2hi + CH - 1u) / CH, first = cur.k2lo / CH + w;
+        const u32 cnt = first < chi ? (chi - first + W - 1u) / W : 0u;  // chunks of this wave in this item
+        const u32 nl = (cnt + PF - 1u) / PF;
+#pragma unroll
+        for (u32 q = 0; q < 2; q++) accA[q] = f32x4{0.f, 0.f, 0.f, 0.f}, accB[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (u32 i = 0; i < nl; i++) {
+            const u32 cb = first + i * PF * W;  // chunk of slot 0 in this loop; slot p: cb + p W
+            const bool lastloop = i + 1u == nl;
+            // what the slots are refilled with: the next loop of this item, or the first loop of the block's next item
+            const QtItem &ft = lastloop ? nxt : cur;
+            const u32 fc = lastloop ? nxt.k2lo / CH + w : cb + PF * W;
+            const uint16_t *xrow = xg + 32u * CH * cb;
+            // slots p < nv hold chunks of this item (nv = PF except in its last loop); tile block k of slot p exists if
+            // CH (cb + p W) + k < k2hi (a K range may end inside its last chunk).  The stages of consecutive tile blocks overlap:
+            // the lookups of tile block t + 1 are issued before the MFMAs of t, a chunk enters its LDS slot ahead of that.
+            const u32 rem = cnt - i * PF, nv = rem < PF ? rem : PF;
+            auto exists = [&](u32 p, u32 k) { return p < nv && CH * (cb + p * W) + k < cur.k2hi; };
+            TbA ta[2][CH];
+            TbB tb[2];
+            auto chunk_in = [&](u32 p) {
+                if (p < nv) chunk_store(dq[p]);
+                fetch(p, ft, fc + p * W);
+                if (p < nv) {
+#pragma unroll
+                    for (u32 k = 0; k < CH; k++) stage_a(k, ta[p & 1u][k]);
+                }
+            };
+            chunk_in(0);
+            stage_b(ta[0][0], xrow, tb[0]);
+#pragma unroll
+            for (u32 t = 0; t < PF * CH; t++) {
+                const u32 p = t / CH, k = t % CH, tn = t + 1u, pn = tn / CH, kn = tn % CH;
+                if (tn < PF * CH) {
+                    if (kn == 0u) chunk_in(pn);
+                    if (exists(pn, kn)) stage_b(ta[pn & 1u][kn], xrow + 32u * (CH * pn * W + kn), tb[tn & 1u]);
+                }
+                if (exists(p, k)) stage_c(tb[t & 1u], t & 1u);
+            }
+        }
+        if (nl == 0u && has_next) {  // (a wave without chunks in this item still feeds its queue)
+#pragma unroll
+            for (u32 p = 0; p < PF; p++) fetch(p, nxt, nxt.k2lo / CH + w + p * W);
+        }
+        stamp();
+        // D layout: lane (gq = l / 16, n = l % 16) holds logical rows 4 gq + 0..3 of column n (all columns are equal):
+        // lanes n < 4 store element n of "rows a", lanes 4 <= n < 8 element n - 4 of "rows a + 8"
+        {
+            const u32 n = l & 15u, e = n & 3u, r = 4u * g + e;
+            const f32x4 sa = accA[0] + accA[1], sb = accB[0] + accB[1];
+            const f32x4 src = (n & 4u) ? sb : sa;
+            const float v = e == 0u ? src[0] : (e == 1u ? src[1] : (e == 2u ? src[2] : src[3]));
+            float *pw = part + flip * (W * 32u) + w * 32u;
+            if (n < 8u) pw[16u * (r >> 3) + (r & 7u) + 8u * (n >> 2)] = v;
+        }
+        __syncthreads();
+        if (tid < 32u) {
+            const float *pr = part + flip * (W * 32u);
+            float t = 0.f;
+            for (u32 i = 0; i < W; i++) t += pr[i * 32u + tid];
+            cur.out[tid] = t;
+        }
+        stamp();
+        flip ^= 1u;
+        if (!has_next) break;
+        cur = nxt;
+        j = jn;
+    }
+}
+
+template <int R, int SX, int WC>
 __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32 *comp, const uint16_t *x, const uint16_t *tlut,
-                                                          u32 M, u32 K) {
-    // the codebook sits in a STATIC LDS array (address 0, known to the compiler: the lookup address needs no base add)
-    __shared__ __attribute__((aligned(16))) u32 tl[512];         // [512] half2 codebook
+                                                          u32 M, u32 K, unsigned long long *dbg) {
+    __shared__ __attribute__((aligned(128))) u32 tab[QtipTab<SX>::WORDS];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);          // [K]
-    float *part = reinterpret_cast<float *>(xs + K);            // [waves][32 rows]
-    const u32 T = blockDim.x, tid = threadIdx.x;
-    for (u32 i = tid; i < 512u; i += T) tl[i] = reinterpret_cast<const u32 *>(tlut)[i];
-    for (u32 i = tid; i < K / 8u; i += T) reinterpret_cast<uint4 *>(xs)[i] = reinterpret_cast<const uint4 *>(x)[i];
-    __syncthreads();
-    qtip_band<R>(out, comp, xs, tl, part, blockIdx.x, K);
+    uint16_t *xsp = reinterpret_cast<uint16_t *>(smem);          // [K] permuted copy
+    float *part = reinterpret_cast<float *>(xsp + K);            // [2][waves][32 rows]
+    unsigned char *stg = reinterpret_cast<unsigned char *>(part + 2u * (blockDim.x >> 6) * 32u);  // [waves] 1 KiB chunk slots
+    const u32 T = blockDim.x, tid = threadIdx.x, nK2 = K / 32u;
+    auto item_of = [&](u32 j) {
+        return QtItem{j * nK2 * 128u * R, out + (size_t)j * 32u, 0u, nK2};
+    };
+    // codebook words and activations first, the tile blocks behind them (in-order return)
+    QtipTabRegs tr;
+    qtip_table_request(tr, tlut);
+    constexpr u32 NX = 2;  // 8-element units per thread held in registers (K <= 16 T)
+    const bool xin = K <= 8u * NX * T;
+    uint4 xq[NX];
+    if (xin) {
+#pragma unroll
+        for (u32 k = 0; k < NX; k++) {
+            const u32 u = tid + k * T;
+            xq[k] = u < K / 8u ? reinterpret_cast<const uint4 *>(x)[u] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    auto prologue = [&]() {
+        qtip_fill_table<SX>(tab, tlut, tr);
+        if (xin) {
+#pragma unroll
+            for (u32 k = 0; k < NX; k++) {
+                const u32 u = tid + k * T;
+                const u32 o[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
+                if (u < K / 8u) qtip_store_x8(xsp, u, o);
+            }
+        } else {
+            for (u32 u = tid; u < K / 8u; u += T) {
+                const uint4 q = reinterpret_cast<const uint4 *>(x)[u];
+                const u32 o[4] = {q.x, q.y, q.z, q.w};
+                qtip_store_x8(xsp, u, o);
+            }
+        }
+        __syncthreads();
+    };
+    qtip_engine<R, SX, WC>(tab, xsp, part, stg, comp, (M / 32u) * nK2 * 128u * R, M / 32u, item_of, prologue, dbg);
 }
 
 // in-place Sylvester butterflies on n floats in LDS (n a power of two, barriers inside, one behind the last pass).
@@ -171,20 +470,22 @@ __device__ __forceinline__ void fwht_lds(float *v, u32 n, u32 P) {
                     }
 #pragma unroll
             for (u32 m = 1; m < 8; m <<= 1) {  // element stride 8 m: the partner thread is t ^ m (same wave: 8 | 64)
-                const bool upper = (t & m) != 0;
+                // lower thread: r + other, upper thread: other - r  ==  other + (+-r): one sign flip (v_xor) and one add that takes
+                // the partner's value through its DPP operand (v_add_f32_dpp; this file is built without the SLP vectoriser, which
+                // packs the adds into v_pk_add_f32 and blocks that fold), instead of move / add / subtract / select
+                const u32 smask = (t & m) ? 0x80000000u : 0u;
 #pragma unroll
                 for (u32 k = 0; k < 8; k++) {
                     // lane ^ 1, ^ 2: quad permutes; lane ^ 4 = half-row mirror (^ 7) of the quad reversal (^ 3): DPP moves on
                     // the VALU instead of 24 ds_bpermute per thread through the LDS crossbar
                     int o = __builtin_bit_cast(int, r[k]);
-                    if (m == 1u) o = __builtin_amdgcn_update_dpp(o, o, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
-                    else if (m == 2u) o = __builtin_amdgcn_update_dpp(o, o, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+                    if (m == 1u) o = __builtin_amdgcn_update_dpp(0, o, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                    else if (m == 2u) o = __builtin_amdgcn_update_dpp(0, o, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
                     else {
-                        o = __builtin_amdgcn_update_dpp(o, o, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
-                        o = __builtin_amdgcn_update_dpp(o, o, 0x141, 0xF, 0xF, false);  // row_half_mirror
+                        o = __builtin_amdgcn_update_dpp(0, o, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+                        o = __builtin_amdgcn_update_dpp(0, o, 0x141, 0xF, 0xF, true);  // row_half_mirror
                     }
-                    const float other = __builtin_bit_cast(float, o);
-                    r[k] = upper ? other - r[k] : r[k] + other;
+                    r[k] = __builtin_bit_cast(float, o) + __builtin_bit_cast(float, __builtin_bit_cast(u32, r[k]) ^ smask);
                 }
             }
             *reinterpret_cast<float4 *>(v + 8u * t) = make_float4(r[0], r[1], r[2], r[3]);
@@ -248,7 +549,7 @@ struct QtipIn {
     const float *SU;
     const uint16_t *tlut;
     float *y32;
-    u32 band0;  // first band (block / ksplit) of this linear
+    u32 blk0, nblk;  // the blocks [blk0, blk0 + nblk) walk the items (band, K range) of this linear
     u32 M;
 };
 struct QtipOut {
@@ -263,38 +564,48 @@ struct QtipInArgs {
     const uint16_t *x, *x2, *normw;
     float eps, kscale;  // kscale = (float)K^-1/2, rounded from double like the scale argument of hadamard()
     u32 K, n;
-    u32 ksplit;  // 1 / 2: blocks per band; block (band, ks) covers half of K and writes its sums to y32 + ks * M
+    u32 ksplit;  // 1..4 K ranges per band; range ks of a band writes its sums to y32 + ks * M
     QtipIn lin[3];
     u32 nprev;          // 1 / 2: x (and x2) are the outputs of the linears prev[] whose transform-out is done here (M == K)
     QtipOut prev[2];
+    u32 xs_off, stg_off, part_off, xp_off;  // byte offsets inside the dynamic LDS (host: qtip_in_layout)
+    unsigned long long *dbg;
 };
 enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2, QPRO_PRE = 3 };
 
-template <int R, int PRO>
+// y32 of a producing linear: its split-K parts added in ascending order (what gq_qtip_linear_out reads)
+__device__ __forceinline__ float qtip_sum_parts(const float *y32, u32 M, u32 parts, u32 i) {
+    float t = y32[i];
+    for (u32 p = 1; p < parts; p++) t += y32[(size_t)p * M + i];
+    return t;
+}
+
+// dynamic LDS (offsets from the host, qtip_in_layout): v fp32 [K] at 0, dead once the transform is done -- the chunk slots
+// (and, from K = 8192 on, the permuted fp16 copy xs too) re-use it --, xs, part [2][W][32], xp fp16 [nprev][K];
+// pre-transformed input: xs | part | slots
+template <int R, int PRO, int SX, int WC>
 __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 tl[512];
+    __shared__ __attribute__((aligned(128))) u32 tab[QtipTab<SX>::WORDS];
     __shared__ float redf[17];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 K = a.K, T = blockDim.x, tid = threadIdx.x;
     float *v = reinterpret_cast<float *>(smem);                 // [K] fp32 transform buffer (none for a pre-transformed input)
-    uint16_t *xs = reinterpret_cast<uint16_t *>(v + (PRO == QPRO_PRE ? 0u : K));  // [K] fp16 matvec input
-    float *part = reinterpret_cast<float *>(xs + K);            // [waves][32]
-    const u32 bid = blockIdx.x / a.ksplit, ks = blockIdx.x % a.ksplit;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem + a.xs_off);  // [K] fp16 matvec input, permuted (qtip_store_x8)
+    float *part = reinterpret_cast<float *>(smem + a.part_off);    // [2][waves][32]
+    unsigned char *stg = smem + a.stg_off;                          // [waves] 1 KiB chunk slots
     u32 li = 0;
-    if (a.n > 1 && bid >= a.lin[1].band0) li = 1;
-    if (a.n > 2 && bid >= a.lin[2].band0) li = 2;
+    if (a.n > 1 && blockIdx.x >= a.lin[1].blk0) li = 1;
+    if (a.n > 2 && blockIdx.x >= a.lin[2].blk0) li = 2;
     const QtipIn L = a.lin[li];
-    // codebook words of this thread (T >= 256): requested now, stored to LDS in the prologue
-    const u32 tl0 = reinterpret_cast<const u32 *>(L.tlut)[tid & 511u], tl1 = reinterpret_cast<const u32 *>(L.tlut)[(tid + 256u) & 511u];
     // Folded transform-out of the producing linear(s): what gq_qtip_linear_out would have written is rebuilt in LDS by
     // every block (same arithmetic, same order) and stored once, by block 0, for the kernels that need it later
     // (the residual stream).  One launch and one global round trip less per linear.
     const uint16_t *xg = a.x, *x2g = a.x2;
     if (a.nprev) {
-        uint16_t *xp = reinterpret_cast<uint16_t *>(part + (T >> 6) * 32u);  // [nprev][K] fp16
+        uint16_t *xp = reinterpret_cast<uint16_t *>(smem + a.xp_off);  // [nprev][K] fp16
         for (u32 r = 0; r < a.nprev; r++) {
             const QtipOut P = a.prev[r];
-            for (u32 i = tid; i < K; i += T) v[i] = P.parts == 2u ? P.y32[i] + P.y32[K + i] : P.y32[i];
+            for (u32 i = tid; i < K; i += T) v[i] = qtip_sum_parts(P.y32, K, P.parts, i);
             __syncthreads();
             fwht_lds(v, K);
             for (u32 i = tid; i < K; i += T) {
@@ -311,6 +622,8 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     // The input vectors are requested first (registers), the first tile blocks of the band behind them, and the prologue
     // runs while those are on their way from HBM (vector memory returns in order: requested the other way round, the
     // first use of x would wait for the tiles).
+    QtipTabRegs tr;
+    qtip_table_request(tr, L.tlut);
     constexpr u32 NU = 2;  // 8-element units per thread held in registers (K <= 16 T)
     const bool inreg = !a.nprev && K <= 8u * NU * T && PRO != QPRO_PRE && !(((uintptr_t)xg | (uintptr_t)x2g | (uintptr_t)a.normw | (uintptr_t)L.SU) & 15u);
     uint4 xq[NU], x2q[NU], nwq[NU];
@@ -327,11 +640,20 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
             if constexpr (PRO == QPRO_SILUMUL) x2q[k] = ok ? reinterpret_cast<const uint4 *>(x2g)[u] : make_uint4(0u, 0u, 0u, 0u);
         }
     }
+    u32 pst = 0;
+    auto pstamp = [&]() {
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63u) == 0 && pst < 8u) a.dbg[128u + (tid >> 6) * 8u + pst++] = __builtin_readcyclecounter();
+    };
     auto prologue = [&]() {
-        if (tid < 512u) tl[tid] = tl0;
-        if (T == 256u) tl[tid + 256u] = tl1;
+        pstamp();
+        qtip_fill_table<SX>(tab, L.tlut, tr);
+        pstamp();
         if constexpr (PRO == QPRO_PRE) {  // x is the transformed fp16 input already (gq_qtip_transform): K need not be a power of two
-            for (u32 i = tid; i < K / 8u; i += T) reinterpret_cast<uint4 *>(xs)[i] = reinterpret_cast<const uint4 *>(xg)[i];
+            for (u32 u = tid; u < K / 8u; u += T) {
+                const uint4 q = reinterpret_cast<const uint4 *>(xg)[u];
+                const u32 o[4] = {q.x, q.y, q.z, q.w};
+                qtip_store_x8(xs, u, o);
+            }
             __syncthreads();
             return;
         }
@@ -359,14 +681,13 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
             for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
             if ((tid & 63u) == 0) redf[tid >> 6] = ss;
             __syncthreads();
-            if (tid == 0) {
+            {  // every thread adds the wave sums in the same order (broadcast reads): no second barrier, no serial thread
                 float t = 0.f;
                 for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
-                redf[16] = 1.0f / sqrtf(t / (float)K + a.eps);
+                nscale = 1.0f / sqrtf(t / (float)K + a.eps);
             }
-            __syncthreads();
-            nscale = redf[16];
         }
+        pstamp();
         auto elem = [&](uint16_t xb, uint16_t x2b, uint16_t nwb, float su) {
             h16 xh = __builtin_bit_cast(h16, xb);
             if constexpr (PRO == QPRO_RMSNORM) xh = (h16)gq_pin_f32((float)xh * nscale) * __builtin_bit_cast(h16, nwb);
@@ -401,22 +722,46 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
                 v[i] = elem(xg[i], PRO == QPRO_SILUMUL ? x2g[i] : (uint16_t)0, PRO == QPRO_RMSNORM ? a.normw[i] : (uint16_t)0, L.SU[i]);
         }
         __syncthreads();
+        pstamp();
+#if !(QT_ABL & 32)
         fwht_lds(v, K);
+#endif
+        pstamp();
+        // fp32 -> fp16, IN PLACE (xs is the front half of v): every thread takes its (<= NU) units of 8 values into
+        // registers, one barrier, then the permuted stores (the host checks K <= 16 T)
         const float sc = a.kscale;
-        for (u32 u = tid; u < K / 8u; u += T) {  // 8 values per step: two 16-byte LDS reads, one 16-byte write
-            const float4 f0 = reinterpret_cast<const float4 *>(v)[2u * u], f1 = reinterpret_cast<const float4 *>(v)[2u * u + 1u];
-            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-            u32 o[4];
+        u32 o[NU][4];
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                o[e] = (u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e] * sc) / 32.0f)) |
-                       ((u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e + 1] * sc) / 32.0f)) << 16);
-            reinterpret_cast<uint4 *>(xs)[u] = make_uint4(o[0], o[1], o[2], o[3]);
+        for (u32 k = 0; k < NU; k++) {
+            const u32 u = tid + k * T;
+            if (u < K / 8u) {
+                const float4 f0 = reinterpret_cast<const float4 *>(v)[2u * u], f1 = reinterpret_cast<const float4 *>(v)[2u * u + 1u];
+                const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    o[k][e] = (u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e] * sc) / 32.0f)) |
+                              ((u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e + 1] * sc) / 32.0f)) << 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < NU; k++) {
+            const u32 u = tid + k * T;
+            if (u < K / 8u) qtip_store_x8(xs, u, o[k]);
         }
         __syncthreads();
     };
-    const u32 nK2 = K / 32u, khalf = (nK2 + a.ksplit - 1u) / a.ksplit;
-    qtip_band<R>(L.y32 + (size_t)ks * L.M, L.comp, xs, tl, part, bid - L.band0, K, prologue, ks * khalf, (ks + 1u) * khalf);
+    constexpr u32 CH = QtChunk<R>::CH;
+    const u32 nK2 = K / 32u, nch = (nK2 + CH - 1u) / CH, kpart = ((nch + a.ksplit - 1u) / a.ksplit) * CH, bl = blockIdx.x - L.blk0;
+    // item t of this linear = (band t / ksplit, K range t % ksplit); this block takes t = bl, bl + nblk, ...
+    auto item_of = [&](u32 jj) {  // jj = blockIdx.x + r * gridDim.x  ->  t = bl + r * nblk
+        const u32 r = (jj - blockIdx.x) / gridDim.x, t = bl + r * L.nblk, band = t / a.ksplit, ks = t % a.ksplit;
+        const u32 lo = ks * kpart, hi = lo + kpart < nK2 ? lo + kpart : nK2;
+        return QtItem{band * nK2 * 128u * R, L.y32 + (size_t)ks * L.M + (size_t)band * 32u, lo, hi};
+    };
+    // number of items of this block, expressed in the engine's index space (j = blockIdx.x + r * gridDim.x < nitems)
+    const u32 total = (L.M / 32u) * a.ksplit, mine = bl < total ? (total - bl + L.nblk - 1u) / L.nblk : 0u;
+    qtip_engine<R, SX, WC>(tab, xs, part, stg, L.comp, (L.M / 32u) * nK2 * 128u * R, mine ? blockIdx.x + (mine - 1u) * gridDim.x + 1u : 0u, item_of, prologue, a.dbg);
 }
 
 struct QtipOutArgs {
@@ -440,16 +785,17 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
             const u32 u = tid + k * T;
             const bool ok = u < M / 4u;
             float4 y = ok ? reinterpret_cast<const float4 *>(L.y32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && L.parts == 2u) {
-                const float4 y2 = reinterpret_cast<const float4 *>(L.y32 + M)[u];
-                y = make_float4(y.x + y2.x, y.y + y2.y, y.z + y2.z, y.w + y2.w);
-            }
+            if (ok)
+                for (u32 p = 1; p < L.parts; p++) {
+                    const float4 y2 = reinterpret_cast<const float4 *>(L.y32 + (size_t)p * M)[u];
+                    y = make_float4(y.x + y2.x, y.y + y2.y, y.z + y2.z, y.w + y2.w);
+                }
             if (ok) reinterpret_cast<float4 *>(v)[u] = y;
             svr[k] = ok ? reinterpret_cast<const float4 *>(L.SV32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             rsr[k] = (ok && L.resid) ? reinterpret_cast<const uint2 *>(L.resid)[u] : make_uint2(0u, 0u);
         }
     } else {
-        for (u32 i = tid; i < M; i += T) v[i] = L.parts == 2u ? L.y32[i] + L.y32[M + i] : L.y32[i];
+        for (u32 i = tid; i < M; i += T) v[i] = qtip_sum_parts(L.y32, M, L.parts, i);
     }
     __syncthreads();
     fwht_lds(v, M);
@@ -616,45 +962,122 @@ __global__ void __launch_bounds__(1024) fwht_kernel(const float *x, float *y, u3
 }
 }  // namespace
 
+namespace {
+// waves per block: the chunks of every K range are dealt out to them (a range shorter than the block still works: the
+// surplus waves only take part in the barriers), 16 = four per SIMD for the usual widths
+u32 qtip_waves(u32 min_range) {  // min_range: chunks in the shortest K range
+    u32 wv = 1;
+    while (wv < 16u && wv < min_range) wv *= 2u;
+    return wv;
+}
+constexpr size_t QT_LDS = 160u * 1024u, QT_STATIC_SLACK = 256u;  // (redf + alignment)
+bool qtip_sx_fits(size_t dyn) { return dyn + (size_t)QtipTab<1>::WORDS * 4u + QT_STATIC_SLACK <= QT_LDS; }
+bool qtip_fits(size_t dyn) { return dyn + (size_t)QtipTab<0>::WORDS * 4u + QT_STATIC_SLACK <= QT_LDS; }
+}  // namespace
+
 extern "C" int gq_qtip_matvec(float *out, const uint32_t *compressed, const void *x, const void *codebook, uint32_t M,
                               uint32_t K, int R, void *stream) {
     if (!out || !compressed || !x || !codebook) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (R < 2 || R > 4) return gq_fail(GQ_ENOTSUP, "R (bits per weight) must be 2, 3 or 4 (kernel_check.py:1-14).");
     if (M == 0 || K == 0 || M % 32u || K % 32u) return gq_fail(GQ_EINVAL, "M and K must be positive multiples of 32.");
     if (((uintptr_t)x | (uintptr_t)compressed | (uintptr_t)codebook) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
-    const u32 nK2 = K / 32u;
-    u32 waves = nK2 >= 8u ? 8u : (nK2 >= 4u ? 4u : (nK2 >= 2u ? 2u : 1u));
-    // fewer 32-row bands than CUs (e.g. M = 4096: 128 blocks): 16 waves per band shorten the per-wave decode loop
-    if (nK2 >= 32u && M / 32u <= 256u) waves = 16u;
-    const size_t smem = (size_t)K * 2u + (size_t)waves * 32u * 4u;  // + 2 KiB static codebook
-    if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "K too large.");
+    const u32 nK2 = K / 32u, ch = R == 2 ? 4u : 2u, waves = qtip_waves((nK2 + ch - 1u) / ch), bands = M / 32u;
+    const size_t smem = (size_t)K * 2u + (size_t)waves * 2u * 32u * 4u + (size_t)waves * 1024u;
+    if (!qtip_fits(smem)) return gq_fail(GQ_ENOTSUP, "K too large.");
+    const int sx = qtip_sx_fits(smem) && gq_env_int("GQ_QTIP_SX", 1) ? 1 : 0;
+    const u32 cus = (u32)gq_cu_count();
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(M / 32u), block(waves * 64u);
-#define GQ_LAUNCH_QTIP(RR)                                                                                            \
+    dim3 grid(bands < cus ? bands : cus), block(waves * 64u);
+#define GQ_LAUNCH_QTIP_W(RR, SS, WW)                                                                                  \
     do {                                                                                                              \
-        static GqPerDeviceOnce once;                                                                                      \
-        if (once.first_use()) {                                                                             \
-            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_matvec_kernel<RR>),                  \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); /* + 2 KiB static */ \
+        static GqPerDeviceOnce once;                                                                                  \
+        if (once.first_use()) {                                                                                       \
+            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_matvec_kernel<RR, SS, WW>),          \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,                              \
+                                             (int)(QT_LDS - (size_t)QtipTab<SS>::WORDS * 4u - QT_STATIC_SLACK)));     \
         }                                                                                                             \
-        hipLaunchKernelGGL(qtip_matvec_kernel<RR>, grid, block, smem, s, out, compressed, (const uint16_t *)x,         \
-                           (const uint16_t *)codebook, M, K);                                                         \
+        hipLaunchKernelGGL((qtip_matvec_kernel<RR, SS, WW>), grid, block, smem, s, out, compressed, (const uint16_t *)x, \
+                           (const uint16_t *)codebook, M, K, g_qdbg);                                                 \
     } while (0)
-    if (R == 2) GQ_LAUNCH_QTIP(2);
-    else if (R == 3) GQ_LAUNCH_QTIP(3);
-    else GQ_LAUNCH_QTIP(4);
+#define GQ_LAUNCH_QTIP(RR, SS)                      \
+    do {                                            \
+        if (waves == 16u) GQ_LAUNCH_QTIP_W(RR, SS, 16); \
+        else GQ_LAUNCH_QTIP_W(RR, SS, 0);           \
+    } while (0)
+#define GQ_LAUNCH_QTIP_R(RR)               \
+    do {                                   \
+        if (sx) GQ_LAUNCH_QTIP(RR, 1);     \
+        else GQ_LAUNCH_QTIP(RR, 0);        \
+    } while (0)
+    if (R == 2) GQ_LAUNCH_QTIP_R(2);
+    else if (R == 3) GQ_LAUNCH_QTIP_R(3);
+    else GQ_LAUNCH_QTIP_R(4);
+#undef GQ_LAUNCH_QTIP_R
 #undef GQ_LAUNCH_QTIP
+#undef GQ_LAUNCH_QTIP_W
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }
 
 namespace {
 bool pow2(u32 n) { return n && !(n & (n - 1u)); }
+
+// blocks per linear: the `cus` blocks of a launch are shared out in proportion to the bands (every block serves ONE linear:
+// its prologue multiplies by that linear's SU); returns the largest number of rounds (items per block) of any linear
+u32 qtip_share_blocks(int n, const u32 *bands, u32 ksplit, u32 cus, u32 *nblk) {
+    u32 total = 0, items = 0;
+    for (int i = 0; i < n; i++) total += bands[i], items += bands[i] * ksplit;
+    if (items <= cus) {
+        for (int i = 0; i < n; i++) nblk[i] = bands[i] * ksplit;
+        return 1u;
+    }
+    u32 used = 0;
+    for (int i = 0; i < n; i++) {
+        nblk[i] = (u32)((unsigned long long)cus * bands[i] / total);
+        if (nblk[i] == 0u) nblk[i] = 1u;
+        used += nblk[i];
+    }
+    while (used < cus) {  // leftover blocks to the linear with the most items per block
+        int best = 0;
+        double worst = -1.0;
+        for (int i = 0; i < n; i++) {
+            const double load = (double)bands[i] * ksplit / nblk[i];
+            if (load > worst) worst = load, best = i;
+        }
+        nblk[best]++, used++;
+    }
+    u32 rounds = 0;
+    for (int i = 0; i < n; i++) {
+        const u32 r = (bands[i] * ksplit + nblk[i] - 1u) / nblk[i];
+        if (r > rounds) rounds = r;
+    }
+    return rounds;
+}
+}  // namespace
+
+extern "C" void gq_debug_set_qtip_timing_buffer(void *p) { g_qdbg = (unsigned long long *)p; }
+
+extern "C" int gq_qtip_plan_ksplit(int n, const uint32_t *M, uint32_t K, int max_ksplit) {
+    if (n < 1 || n > 3 || !M || K < 32u) return 1;
+    if (max_ksplit > 4) max_ksplit = 4;
+    const u32 cus = (u32)gq_cu_count(), nK2 = K / 32u;
+    u32 bands[3], nblk[3];
+    for (int i = 0; i < n; i++) bands[i] = M[i] / 32u;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ks = 1; ks <= max_ksplit; ks++) {
+        if (ks > 1 && nK2 / 4u / (u32)ks < 16u) break;  // every K range keeps the 16 waves of a block busy (one 4-tile-block chunk each)
+        const u32 rounds = qtip_share_blocks(n, bands, (u32)ks, cus, nblk);
+        // time ~ rounds of 1 / ks band each, plus a small price per extra part (its flush and the consumer's extra read)
+        const double cost = (double)rounds / ks * (1.0 + 0.02 * (ks - 1));
+        if (cost < best_cost - 1e-9) best_cost = cost, best = ks;
+    }
+    return best;
 }
 
 extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
                                  int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, void *stream) {
-    if (ksplit < 1 || ksplit > 2) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: ksplit must be 1 or 2.");
+    if (ksplit < 1 || ksplit > 4) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: ksplit must be 1..4.");
     if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 1..3 linears.");
     if (n_prev < 0 || n_prev > 2 || (n_prev && !prev)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 0..2 producing linears.");
     if (n_prev == 0 && !x) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: x is null.");
@@ -667,6 +1090,8 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
         return gq_fail(GQ_ENOTSUP, "fused QTIP linear: K must be a power of two in 32..16384.");
     if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2 && !n_prev) || prologue < 0 || prologue > 3)
         return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: prologue operand missing.");
+    const u32 nK2 = K / 32u;
+    if ((u32)ksplit > nK2) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: more K ranges than tile blocks.");
     QtipInArgs a{};
     a.x = (const uint16_t *)x;
     a.x2 = (const uint16_t *)x2;
@@ -675,51 +1100,87 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
     a.kscale = (float)pow((double)K, -0.5);
     a.K = K;
     a.n = (u32)n;
-    u32 bands = 0, minM = 0xFFFFFFFFu;
+    u32 bands[3] = {0, 0, 0}, nblk[3] = {0, 0, 0};
     for (int i = 0; i < n; i++) {
         if (!lin[i].trellis || (!lin[i].SU && prologue != GQ_QPRO_PRETRANSFORMED) || !lin[i].tlut || !lin[i].y32 || lin[i].M == 0 || lin[i].M % 32u)
             return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: null pointer or M not a multiple of 32.");
         if (((uintptr_t)lin[i].trellis | (uintptr_t)lin[i].tlut) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
-        a.lin[i] = QtipIn{lin[i].trellis, lin[i].SU, (const uint16_t *)lin[i].tlut, lin[i].y32, bands, lin[i].M};
-        bands += lin[i].M / 32u;
-        if (lin[i].M < minM) minM = lin[i].M;
+        bands[i] = lin[i].M / 32u;
     }
-    const u32 nK2 = K / 32u;
-    u32 waves = nK2 >= 8u ? 8u : (nK2 >= 4u ? 4u : (nK2 >= 2u ? 2u : 1u));
-    if (nK2 >= 32u && bands * (u32)ksplit <= 256u) waves = 16u;
+    qtip_share_blocks(n, bands, (u32)ksplit, (u32)gq_cu_count(), nblk);
+    u32 blocks = 0;
+    for (int i = 0; i < n; i++) {
+        a.lin[i] = QtipIn{lin[i].trellis, lin[i].SU, (const uint16_t *)lin[i].tlut, lin[i].y32, blocks, nblk[i], lin[i].M};
+        blocks += nblk[i];
+    }
+    // K ranges in chunks (the engine's load unit: 4 tile blocks at R = 2, else 2)
+    const u32 ch = R == 2 ? 4u : 2u, nch = (nK2 + ch - 1u) / ch, cpart = (nch + (u32)ksplit - 1u) / (u32)ksplit;
+    if (cpart * ((u32)ksplit - 1u) >= nch) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: an empty K range (ksplit too large for K).");
+    const u32 clast = nch - ((u32)ksplit - 1u) * cpart;
+    u32 waves = qtip_waves(clast < cpart ? clast : cpart);
     if (waves < 4u) waves = 4u;  // the transform wants threads
+    if (prologue != GQ_QPRO_PRETRANSFORMED && K > 16u * waves * 64u) waves = 16u;  // (the in-place fp16 conversion: <= 2 units per thread)
     a.ksplit = (u32)ksplit;
+    a.dbg = g_qdbg;
     a.nprev = (u32)n_prev;
     for (int i = 0; i < n_prev; i++) {
         if (!prev[i].y32 || !prev[i].SV32 || prev[i].M != K) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: producing linear must have M == K.");
+        if (prev[i].parts > 4u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: parts must be 0..4.");
         a.prev[i] = QtipOut{prev[i].y32, prev[i].SV32, (const uint16_t *)prev[i].resid, (uint16_t *)prev[i].out, K, (float)pow((double)K, -0.5),
-                            prev[i].parts == 2u ? 2u : 1u};
+                            prev[i].parts ? prev[i].parts : 1u};
     }
-    const size_t smem = (size_t)K * (prologue == GQ_QPRO_PRETRANSFORMED ? 2u : 6u) + (size_t)waves * 32u * 4u + (size_t)n_prev * K * 2u;  // <= 130 KiB for K <= 16384
-    if (smem > 150u * 1024u) return gq_fail(GQ_ENOTSUP, "gq_qtip_linear_in: K too large.");
+    // LDS layout: the transform buffer v (K floats at 0) is dead when the matvec starts: the chunk slots re-use it, and so does
+    // the fp16 copy xs when both fit (K >= 8192; the conversion is staged through registers)
+    const size_t slots = (size_t)waves * 1024u, pbytes = (size_t)waves * 2u * 32u * 4u;
+    size_t end;
+    if (prologue == GQ_QPRO_PRETRANSFORMED) {
+        a.xs_off = 0, a.part_off = K * 2u, a.stg_off = (u32)(K * 2u + pbytes), end = (size_t)K * 2u + pbytes + slots;
+    } else if ((size_t)K * 2u + slots <= (size_t)K * 4u) {
+        a.xs_off = 0, a.stg_off = K * 2u, a.part_off = K * 4u, end = (size_t)K * 4u + pbytes;
+    } else {
+        const size_t va = (size_t)K * 4u > slots ? (size_t)K * 4u : slots;
+        a.stg_off = 0, a.xs_off = (u32)va, a.part_off = (u32)(va + (size_t)K * 2u), end = va + (size_t)K * 2u + pbytes;
+    }
+    a.xp_off = (u32)end;
+    const size_t smem = end + (size_t)n_prev * K * 2u;
+    if (!qtip_fits(smem)) return gq_fail(GQ_ENOTSUP, "gq_qtip_linear_in: K too large.");
+    const int sx = qtip_sx_fits(smem) && gq_env_int("GQ_QTIP_SX", 1) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(bands * (u32)ksplit), block(waves * 64u);
-#define GQ_LAUNCH_QIN(RR, PP)                                                                                         \
+    dim3 grid(blocks), block(waves * 64u);
+#define GQ_LAUNCH_QIN_W(RR, PP, SS, WW)                                                                               \
     do {                                                                                                              \
-        static GqPerDeviceOnce once;                                                                                      \
-        if (once.first_use()) {                                                                                                   \
-            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_in_kernel<RR, PP>),           \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); /* + static */ \
+        static GqPerDeviceOnce once;                                                                                  \
+        if (once.first_use()) {                                                                                       \
+            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_in_kernel<RR, PP, SS, WW>),   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,                              \
+                                             (int)(QT_LDS - (size_t)QtipTab<SS>::WORDS * 4u - QT_STATIC_SLACK)));     \
         }                                                                                                             \
-        hipLaunchKernelGGL((qtip_linear_in_kernel<RR, PP>), grid, block, smem, s, a);                                 \
+        hipLaunchKernelGGL((qtip_linear_in_kernel<RR, PP, SS, WW>), grid, block, smem, s, a);                         \
+    } while (0)
+#define GQ_LAUNCH_QIN(RR, PP, SS)                       \
+    do {                                                \
+        if (waves == 16u) GQ_LAUNCH_QIN_W(RR, PP, SS, 16); \
+        else GQ_LAUNCH_QIN_W(RR, PP, SS, 0);            \
+    } while (0)
+#define GQ_LAUNCH_QIN_S(RR, PP)            \
+    do {                                   \
+        if (sx) GQ_LAUNCH_QIN(RR, PP, 1);  \
+        else GQ_LAUNCH_QIN(RR, PP, 0);     \
     } while (0)
 #define GQ_LAUNCH_QIN_R(RR)                                                   \
     do {                                                                      \
-        if (prologue == GQ_QPRO_RMSNORM) GQ_LAUNCH_QIN(RR, QPRO_RMSNORM);     \
-        else if (prologue == GQ_QPRO_SILU_MUL) GQ_LAUNCH_QIN(RR, QPRO_SILUMUL); \
-        else if (prologue == GQ_QPRO_PRETRANSFORMED) GQ_LAUNCH_QIN(RR, QPRO_PRE); \
-        else GQ_LAUNCH_QIN(RR, QPRO_NONE);                                    \
+        if (prologue == GQ_QPRO_RMSNORM) GQ_LAUNCH_QIN_S(RR, QPRO_RMSNORM);     \
+        else if (prologue == GQ_QPRO_SILU_MUL) GQ_LAUNCH_QIN_S(RR, QPRO_SILUMUL); \
+        else if (prologue == GQ_QPRO_PRETRANSFORMED) GQ_LAUNCH_QIN_S(RR, QPRO_PRE); \
+        else GQ_LAUNCH_QIN_S(RR, QPRO_NONE);                                    \
     } while (0)
     if (R == 2) GQ_LAUNCH_QIN_R(2);
     else if (R == 3) GQ_LAUNCH_QIN_R(3);
     else GQ_LAUNCH_QIN_R(4);
 #undef GQ_LAUNCH_QIN_R
+#undef GQ_LAUNCH_QIN_S
 #undef GQ_LAUNCH_QIN
+#undef GQ_LAUNCH_QIN_W
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }
@@ -732,9 +1193,9 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
         if (!lin[i].y32 || !lin[i].SV32 || !lin[i].out) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out: null pointer argument.");
         if (!pow2(lin[i].M) || lin[i].M < 32u || lin[i].M > 32768u)
             return gq_fail(GQ_ENOTSUP, "fused QTIP linear: M must be a power of two in 32..32768.");
-        if (lin[i].parts > 2u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out: parts must be 0 / 1 / 2.");
+        if (lin[i].parts > 4u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out: parts must be 0..4.");
         a.lin[i] = QtipOut{lin[i].y32, lin[i].SV32, (const uint16_t *)lin[i].resid, (uint16_t *)lin[i].out, lin[i].M,
-                           (float)pow((double)lin[i].M, -0.5), lin[i].parts == 2u ? 2u : 1u};
+                           (float)pow((double)lin[i].M, -0.5), lin[i].parts ? lin[i].parts : 1u};
         if (lin[i].M > maxM) maxM = lin[i].M;
     }
     const size_t smem = (size_t)maxM * 4u;

@@ -449,8 +449,11 @@ class Transformer(nn.Module):
                 tables[key] = f32(t)
             return tables[key]
 
-        def ksplit(m):  # fewer 32-row bands than half the CUs (wo, down): two blocks per band, each over half of K
-            return 2 if m.out_features // 32 <= 128 and os.environ.get("GQ_QTIP_KSPLIT", "1") != "0" else 1
+        def ksplit(m):  # K ranges per band: the split with the fewest band-equivalents per block (wo, down: 128 bands on 256 units -> 2)
+            if os.environ.get("GQ_QTIP_KSPLIT", "1") == "0":
+                return 1
+            import ctypes
+            return int(_lib.lib().gq_qtip_plan_ksplit(1, (ctypes.c_uint32 * 1)(m.out_features), m.in_features, 2))
 
         y32, xs16 = st["y32"], st["xs16"]
 

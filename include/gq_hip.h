@@ -167,8 +167,11 @@ int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, float scale
  *   x fp16 [K] (prologue SILU_MUL: x = gate, x2 = up), norm_weight fp16 [K];
  *   GqQtipIn : trellis u32 [R*M*K/32], SU f32 [K], tlut fp16 [1024], y32 f32 [M] (written);
  *   GqQtipOut: y32 f32 [M], SV32 f32 [M] (= SV * 32), resid fp16 [M] or NULL, out fp16 [M] (may alias resid).
- * ksplit = 2: two blocks per 32-row band, each over half of K, partial sums to y32[0..M) and y32[M..2M) (y32 must hold
- * 2 M floats; gq_qtip_linear_out with parts = 2 adds them): for launches with fewer bands than half the CUs (wo, down).
+ * ksplit = 1..4: K ranges per 32-row band; range s of a band writes its partial sums to y32[s M .. (s + 1) M) (y32 must
+ * hold ksplit * M floats; gq_qtip_linear_out with parts = ksplit adds them in ascending order).  A launch runs at most one
+ * block per compute unit; every block serves ONE linear and walks that linear's (band, K range) items, so a split evens
+ * out launches whose band count is not a multiple of the block count (q/k/v: 3 x 128 bands on 256 units -> ksplit 3).
+ * gq_qtip_plan_ksplit(n, M[], K, max) returns the split with the fewest band-equivalents per block for this device.
  * Folding: with n_prev = 1 (2 for SILU_MUL) the input vector(s) of gq_qtip_linear_in are NOT read from x / x2 but rebuilt
  * from prev[] -- the transform-out of the linear(s) that produce them (M == K), residual included -- by every block, and
  * stored to prev[i].out (if not NULL; must not alias prev[i].resid) once: gq_qtip_linear_out and its launch are saved for
@@ -191,11 +194,12 @@ typedef struct GqQtipOut {
     const void *resid;
     void *out;
     uint32_t M;
-    uint32_t parts; /* 0 / 1: y32 is [M]; 2: y32 is [2][M] split-K partial sums (ksplit = 2 of gq_qtip_linear_in) */
+    uint32_t parts; /* 0 / 1: y32 is [M]; 2..4: y32 is [parts][M] split-K partial sums (ksplit of gq_qtip_linear_in) */
 } GqQtipOut;
 int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
                       int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, void *stream);
 int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
+int gq_qtip_plan_ksplit(int n, const uint32_t *M, uint32_t K, int max_ksplit); /* host-side helper, launches nothing */
 
 /*
  * Either side of a QTIP linear whose width n = Kf * P carries a non-power-of-two Hadamard factor (inference/lib/utils/
@@ -273,6 +277,7 @@ int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperat
  * s_memtime phase stamps into (tools/phase_timing.py); NULL (default) disables it. */
 void gq_reset_env_cache(void);
 void gq_debug_set_timing_buffer(void *device_buffer);
+void gq_debug_set_qtip_timing_buffer(void *device_buffer); /* u64 [16 waves][8] phase stamps of gq_qtip_matvec's middle block */
 
 #ifdef __cplusplus
 }

@@ -1141,8 +1141,11 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
         const size_t va = (size_t)K * 4u > slots ? (size_t)K * 4u : slots;
         a.stg_off = 0, a.xs_off = (u32)va, a.part_off = (u32)(va + (size_t)K * 2u), end = va + (size_t)K * 2u + pbytes;
     }
-    a.xp_off = (u32)end;
-    const size_t smem = end + (size_t)n_prev * K * 2u;
+    // the rebuilt input vector(s) of a folded transform-out: one vector fits the (not yet written) xs region when that is
+    // not inside v; otherwise behind everything
+    const bool xp_in_xs = n_prev == 1 && a.xs_off != 0u;
+    a.xp_off = xp_in_xs ? a.xs_off : (u32)end;
+    const size_t smem = xp_in_xs ? end : end + (size_t)n_prev * K * 2u;
     if (!qtip_fits(smem)) return gq_fail(GQ_ENOTSUP, "gq_qtip_linear_in: K too large.");
     const int sx = qtip_sx_fits(smem) && gq_env_int("GQ_QTIP_SX", 1) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;

@@ -433,7 +433,8 @@ class Transformer(nn.Module):
         st["g"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
         st["u"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
         mmax = max(c.dim, c.intermediate_size)
-        st["y32"] = torch.zeros(3, 2 * mmax, dtype=torch.float32, device=dev)  # [linear][split-K part][M]
+        # [linear][split-K part][M]; rows 3 / 4: the sums of wo / down while their transform-out is folded into the next launch
+        st["y32"] = torch.zeros(5, 2 * mmax, dtype=torch.float32, device=dev)
         st["xs16"] = torch.zeros(3, mmax, dtype=torch.float16, device=dev)     # transformed inputs (factor widths)
         keep = []    # fp32 copies and descriptor arrays the plans point into
         tables = {}  # one fp32 device copy per distinct Hadamard factor table (every layer's module holds its own buffer)
@@ -457,36 +458,50 @@ class Transformer(nn.Module):
 
         y32, xs16 = st["y32"], st["xs16"]
 
-        def group(mods, xp, x2p, normw, pro, outs, resid):
-            """launches of one group: mods share the input vector xp (x2p for silu*mul); outs[i] fp16 destinations"""
+        def group(mods, xp, x2p, normw, pro, outs, resid, prev=None, defer=None):
+            """launches of one group: mods share the input vector xp (x2p for silu*mul); outs[i] fp16 destinations.
+            prev: GqQtipOut of the linear that PRODUCES xp, its transform-out folded into this group's first launch (which then
+            stores xp itself); defer = row of y32: this group's own transform-out is left to the consumer (-> returned descriptor)"""
             R, K = mods[0].K, mods[0].in_features
             plan = []
             # split-K partial sums are added by the fused transform-out only: single linears with a power-of-two output width
             ks = ksplit(mods[0]) if len(mods) == 1 and mods[0].K_right == 1 else 1
+            ysl = [y32[defer]] if defer is not None else [y32[i] for i in range(len(mods))]
             if mods[0].K_left == 1:  # fused transform-in + matvec, all linears in one launch
-                arr = (_lib.GqQtipIn * len(mods))(*[_lib.GqQtipIn(m.trellis.data_ptr(), f32(m.SU), m.tlut.data_ptr(), y32[i].data_ptr(), m.out_features)
+                arr = (_lib.GqQtipIn * len(mods))(*[_lib.GqQtipIn(m.trellis.data_ptr(), f32(m.SU), m.tlut.data_ptr(), ysl[i].data_ptr(), m.out_features)
                                                     for i, m in enumerate(mods)])
                 keep.append(arr)
-                plan.append(("gq_qtip_linear_in", (xp, x2p, normw, c.norm_eps, pro, K, R, len(mods), arr, 0, None, ks)))
+                if prev is not None:
+                    parr = (_lib.GqQtipOut * 1)(prev)
+                    keep.append(parr)
+                    plan.append(("gq_qtip_linear_in", (None, None, normw, c.norm_eps, pro, K, R, len(mods), arr, 1, parr, ks)))
+                else:
+                    plan.append(("gq_qtip_linear_in", (xp, x2p, normw, c.norm_eps, pro, K, R, len(mods), arr, 0, None, ks)))
             else:  # factor transform of the shared input (one launch), then the bare matvec per linear
                 xf = (_lib.GqQtipXf * len(mods))(*[_lib.GqQtipXf(None, f32(m.SU), table(m.had_left), None, xs16[i].data_ptr())
                                                    for i, m in enumerate(mods)])
                 keep.append(xf)
                 plan.append(("gq_qtip_transform", (1, xp, x2p, normw, c.norm_eps, pro, len(mods), xf, K, mods[0].K_left, 1)))
+                assert prev is None
                 for i, m in enumerate(mods):
-                    arr = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(m.trellis.data_ptr(), None, m.tlut.data_ptr(), y32[i].data_ptr(), m.out_features))
+                    arr = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(m.trellis.data_ptr(), None, m.tlut.data_ptr(), ysl[i].data_ptr(), m.out_features))
                     keep.append(arr)
                     plan.append(("gq_qtip_linear_in", (xs16[i].data_ptr(), None, None, 0.0, 3, K, R, 1, arr, 0, None, ks)))
             p2 = [i for i, m in enumerate(mods) if m.K_right == 1]
             fac = [i for i, m in enumerate(mods) if m.K_right != 1]
+            if defer is not None:  # (a single linear with a power-of-two output width)
+                desc = _lib.GqQtipOut(ysl[0].data_ptr(), f32(mods[0].SV, 32.0), resid, outs[0], mods[0].out_features, ks)
+                arr = (_lib.GqQtipOut * 1)(desc)
+                keep.append(arr)
+                return plan, desc, [("gq_qtip_linear_out", (1, arr))]
             if p2:
-                arr = (_lib.GqQtipOut * len(p2))(*[_lib.GqQtipOut(y32[i].data_ptr(), f32(mods[i].SV, 32.0), resid, outs[i], mods[i].out_features, ks)
+                arr = (_lib.GqQtipOut * len(p2))(*[_lib.GqQtipOut(ysl[i].data_ptr(), f32(mods[i].SV, 32.0), resid, outs[i], mods[i].out_features, ks)
                                                    for i in p2])
                 keep.append(arr)
                 plan.append(("gq_qtip_linear_out", (len(p2), arr)))
             for Kf, M in sorted({(mods[i].K_right, mods[i].out_features) for i in fac}):
                 idx = [i for i in fac if (mods[i].K_right, mods[i].out_features) == (Kf, M)]
-                xf = (_lib.GqQtipXf * len(idx))(*[_lib.GqQtipXf(y32[i].data_ptr(), f32(mods[i].SV, 32.0), table(mods[i].had_right), resid, outs[i])
+                xf = (_lib.GqQtipXf * len(idx))(*[_lib.GqQtipXf(ysl[i].data_ptr(), f32(mods[i].SV, 32.0), table(mods[i].had_right), resid, outs[i])
                                                   for i in idx])
                 keep.append(xf)
                 plan.append(("gq_qtip_transform", (0, None, None, None, 0.0, 0, len(idx), xf, M, Kf, 0)))
@@ -494,16 +509,36 @@ class Transformer(nn.Module):
 
         x, h, y, qkv = st["x"], st["h"], st["y"], st["qkv"]
         e = qkv.element_size()
+        # Folding (GQ_QTIP_FOLD=1, default OFF): the transform-out of wo (+ residual) is rebuilt by the gate / up launch, that of
+        # down (+ residual) by the NEXT layer's q / k / v launch (gq_qtip_linear_in with n_prev = 1; bit-identical, the vector is
+        # stored once for the residual stream): two launches per layer less, but every one of the 256 blocks repeats the
+        # 4096-point transform and takes the slower prologue path -- measured 365 vs 385 tokens/s on the Llama-2-7b shape
+        # (400 vs 422 with a power-of-two MLP), so it stays off.  Needs power-of-two widths on both sides of the fold.
+        fold = os.environ.get("GQ_QTIP_FOLD", "0") != "0"
         layers = []
+        prev_down = None
         for b in self.layers:
             at, ff = b.attention, b.feed_forward
-            layers.append(dict(
-                qkv=group([at.wq, at.wk, at.wv], x.data_ptr(), None, b.input_layernorm.weight.data_ptr(), 1,
-                          [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e], None),
-                o=group([at.wo], y.data_ptr(), None, None, 0, [h.data_ptr()], x.data_ptr()),
-                gu=group([ff.w1, ff.w3], h.data_ptr(), None, b.post_attention_layernorm.weight.data_ptr(), 1,
-                         [st["g"].data_ptr(), st["u"].data_ptr()], None),
-                d=group([ff.w2], st["g"].data_ptr(), st["u"].data_ptr(), None, 2, [x.data_ptr()], h.data_ptr())))
+            qkv_outs = [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e]
+            can_o = fold and at.wo.K_right == 1 and ff.w1.K_left == 1
+            can_d = fold and ff.w2.K_right == 1 and at.wq.K_left == 1
+            d = dict(qkv=group([at.wq, at.wk, at.wv], x.data_ptr(), None, b.input_layernorm.weight.data_ptr(), 1, qkv_outs, None))
+            # (q / k / v of this layer with the previous layer's down folded in; the first layer of a range takes the plain form)
+            d["qkv_f"] = group([at.wq, at.wk, at.wv], None, None, b.input_layernorm.weight.data_ptr(), 1, qkv_outs, None, prev=prev_down) \
+                if prev_down is not None else None
+            if can_o:
+                d["o"], desc_o, _ = group([at.wo], y.data_ptr(), None, None, 0, [h.data_ptr()], x.data_ptr(), defer=3)
+                d["gu"] = group([ff.w1, ff.w3], None, None, b.post_attention_layernorm.weight.data_ptr(), 1,
+                                [st["g"].data_ptr(), st["u"].data_ptr()], None, prev=desc_o)
+            else:
+                d["o"] = group([at.wo], y.data_ptr(), None, None, 0, [h.data_ptr()], x.data_ptr())
+                d["gu"] = group([ff.w1, ff.w3], h.data_ptr(), None, b.post_attention_layernorm.weight.data_ptr(), 1,
+                                [st["g"].data_ptr(), st["u"].data_ptr()], None)
+            if can_d:
+                d["d"], prev_down, d["d_out"] = group([ff.w2], st["g"].data_ptr(), st["u"].data_ptr(), None, 2, [x.data_ptr()], h.data_ptr(), defer=4)
+            else:
+                d["d"], prev_down, d["d_out"] = group([ff.w2], st["g"].data_ptr(), st["u"].data_ptr(), None, 2, [x.data_ptr()], h.data_ptr()), None, None
+            layers.append(d)
         st["qtip_layers"] = layers
         st["qtip_keep"] = keep
 
@@ -526,9 +561,15 @@ class Transformer(nn.Module):
             for name, args in plan:
                 ck(getattr(L, name)(*args, sp), name)
 
+        pending = None  # transform-out of the previous layer's down projection, not yet run
         for li in range(l0, l1):
             d, at = b["qtip_layers"][li], self.layers[li].attention
-            run(d["qkv"])
+            if pending is not None and d["qkv_f"] is not None:
+                run(d["qkv_f"])  # (rebuilds and stores the hidden state itself)
+            else:
+                if pending is not None:
+                    run(pending)
+                run(d["qkv"])
             ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
                                       at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
                                       y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
@@ -536,6 +577,9 @@ class Transformer(nn.Module):
             run(d["o"])
             run(d["gu"])
             run(d["d"])
+            pending = d["d_out"]
+        if pending is not None:
+            run(pending)
 
     def native_embed(self, tok: Tensor, x: Tensor):
         _lib.check(_lib.lib().gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), self.config.dim,

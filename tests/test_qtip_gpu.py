@@ -447,3 +447,65 @@ def test_qtip_native_decode_with_factor_hidden_size(tmp_path, monkeypatch):
             assert bool(torch.isfinite(got).all())
             err = float(torch.abs(got - ref[p]).max()) / (float(torch.abs(ref[p]).max()) + 1e-9)
             assert err < 2e-2, err
+
+
+# ----------------------------------------------------------------------------- band engine corner cases (round 2 rebuild)
+@pytest.mark.parametrize("R", [2, 3, 4])
+@pytest.mark.parametrize("M,K", [(64, 160), (96, 2080), (32, 96), (22016, 512), (9024, 1056)])
+def test_matvec_ragged_chunks_and_many_items(oracle, R, M, K):
+    """K / 32 not a multiple of the engine's load chunk (4 tile blocks at R = 2, 2 else): the last chunk of a band is partly
+    valid and runs into the next band's bytes (or past the tensor: buffer bounds); more bands than blocks: every block walks
+    several items with one codebook fill and one activation copy"""
+    g = torch.Generator(device="cpu").manual_seed(R * 7919 + M + K)
+    compressed = torch.randint(torch.iinfo(torch.int32).min, torch.iinfo(torch.int32).max, (R * M * K // 32, ), dtype=torch.int32, generator=g).numpy()
+    tlut = torch.clamp(torch.randn(512, 2, generator=g) / 16, -1, 1).to(torch.float16).numpy()
+    x = torch.clamp(torch.randn(K, 1, generator=g) / 16, -1, 1).to(torch.float16).numpy()
+    got = _run(compressed, tlut, x, M, K, R)
+    _check(got, compressed, tlut, x, M, K, R, oracle)
+
+
+@pytest.mark.parametrize("R", [2, 3, 4])
+@pytest.mark.parametrize("Ms,K", [([4096, 1024, 1024], 4096), ([1024], 11008), ([2048, 2048], 1056), ([352], 160)])
+def test_pretransformed_linear_in_all_splits(oracle, R, Ms, K):
+    """gq_qtip_linear_in (GQ_QPRO_PRETRANSFORMED = the bare matvec, any K % 32 == 0) with 1..4 K ranges per band and up to three
+    linears in one launch (each block serves one linear): the parts, added in ascending order, equal the oracle's product"""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(R * 31 + K + sum(Ms))
+    comp = [torch.randint(torch.iinfo(torch.int32).min, torch.iinfo(torch.int32).max, (R * M * K // 32, ), dtype=torch.int32, generator=g) for M in Ms]
+    tlut = torch.clamp(torch.randn(512, 2, generator=g) / 16, -1, 1).to(torch.float16)
+    x = torch.clamp(torch.randn(K, generator=g) / 16, -1, 1).to(torch.float16)
+    cd = [c.to(d) for c in comp]
+    td, xd = tlut.reshape(-1).to(d), x.to(d)
+    for ks in (1, 2, 3, 4):
+        if ks > K // 32:
+            continue
+        y32 = [torch.full((ks * M,), float("nan"), dtype=torch.float32, device=d) for M in Ms]
+        ain = (_lib.GqQtipIn * len(Ms))(*[_lib.GqQtipIn(cd[i].data_ptr(), None, td.data_ptr(), y32[i].data_ptr(), M) for i, M in enumerate(Ms)])
+        rc = L.gq_qtip_linear_in(xd.data_ptr(), None, None, 0.0, 3, K, R, len(Ms), ain, 0, None, ks, None)
+        nch = -(-(K // 32) // (4 if R == 2 else 2))
+        if -(-nch // ks) * (ks - 1) >= nch:  # an empty K range: rejected, not silently mis-split
+            assert rc != 0
+            continue
+        _lib.check(rc, "linear_in")
+        torch.cuda.synchronize()
+        for i, M in enumerate(Ms):
+            parts = y32[i].reshape(ks, M).cpu().numpy()
+            assert np.isfinite(parts).all()
+            got = parts[0].copy()
+            for p in range(1, ks):
+                got += parts[p]
+            _check(got, comp[i].numpy(), tlut.numpy(), x.numpy().reshape(K, 1), M, K, R, oracle)
+
+
+def test_plan_ksplit_is_a_valid_split():
+    from guidedquant_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    for Ms, K in (([4096], 4096), ([4096, 4096, 4096], 4096), ([11008, 11008], 4096), ([4096], 11008), ([64], 128), ([32], 32)):
+        ks = L.gq_qtip_plan_ksplit(len(Ms), (ctypes.c_uint32 * len(Ms))(*Ms), K, 4)
+        assert 1 <= ks <= 4
+        assert ks == 1 or (K // 32) // 4 // ks >= 16  # every range keeps 16 waves busy
+    # one linear with 128 bands on a 256-unit chip: two ranges
+    assert L.gq_qtip_plan_ksplit(1, (ctypes.c_uint32 * 1)(4096), 4096, 4) == 2

@@ -191,7 +191,10 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     const unsigned char *own_p = slot + (R == 2 ? 16u * (s >> 1) + 8u * a4 + 4u * (s & 1u) : s * (4u * R));
     const unsigned char *nbr_p = slot + (R == 2 ? 16u * (sn >> 1) + 8u * a4 + 4u * (sn & 1u) : sn * (4u * R));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)comp, 0, (int)comp_bytes, 0x00020000);
-    constexpr u32 PF = 2;  // chunks per wave in flight
+#ifndef QT_PF
+#define QT_PF 2
+#endif
+    constexpr u32 PF = QT_PF;  // chunks per wave in flight
     u32 dq[PF][LD];
     u32 nstamp = 0;
     auto stamp = [&]() {

@@ -572,6 +572,9 @@ struct QtipInArgs {
     u32 nprev;          // 1 / 2: x (and x2) are the outputs of the linears prev[] whose transform-out is done here (M == K)
     QtipOut prev[2];
     u32 xs_off, stg_off, part_off, xp_off;  // byte offsets inside the dynamic LDS (host: qtip_in_layout)
+    // gq_qtip_linear: the block that finishes a linear LAST (device-scope counter) also runs its transform-out
+    QtipOut fin[3];
+    u32 *fin_ctr;  // [n] zero before the first launch; the finishing block resets its counter
     unsigned long long *dbg;
 };
 enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2, QPRO_PRE = 3 };
@@ -581,6 +584,66 @@ __device__ __forceinline__ float qtip_sum_parts(const float *y32, u32 M, u32 par
     float t = y32[i];
     for (u32 p = 1; p < parts; p++) t += y32[(size_t)p * M + i];
     return t;
+}
+
+// Transform-out of one linear by one block: y32 (split-K parts added in ascending order) -> hadamard * m^-1/2 -> * (SV * 32) ->
+// fp16 (+ residual).  v: M floats of LDS.  Shared by gq_qtip_linear_out and the finishing block of gq_qtip_linear (same code:
+// the two forms agree bit for bit).
+__device__ __forceinline__ void qtip_transform_out(const QtipOut &L, float *v) {
+    const u32 T = blockDim.x, tid = threadIdx.x, M = L.M;
+    // 4 consecutive outputs per thread and step: 16-byte loads of the sums, the scales and (8 bytes) the residual, all
+    // requested before the transform (one block: nothing else hides their latency)
+    constexpr u32 PRE = 2;  // M <= 8192 at 1024 threads
+    const bool vec = !(((uintptr_t)L.y32 | (uintptr_t)L.SV32) & 15u) && !(((uintptr_t)L.resid | (uintptr_t)L.out) & 7u);
+    const bool pre = vec && M <= 4u * PRE * T;
+    float4 svr[PRE];
+    uint2 rsr[PRE];
+    if (pre) {
+#pragma unroll
+        for (u32 k = 0; k < PRE; k++) {
+            const u32 u = tid + k * T;
+            const bool ok = u < M / 4u;
+            float4 y = ok ? reinterpret_cast<const float4 *>(L.y32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok)
+                for (u32 p = 1; p < L.parts; p++) {
+                    const float4 y2 = reinterpret_cast<const float4 *>(L.y32 + (size_t)p * M)[u];
+                    y = make_float4(y.x + y2.x, y.y + y2.y, y.z + y2.z, y.w + y2.w);
+                }
+            if (ok) reinterpret_cast<float4 *>(v)[u] = y;
+            svr[k] = ok ? reinterpret_cast<const float4 *>(L.SV32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rsr[k] = (ok && L.resid) ? reinterpret_cast<const uint2 *>(L.resid)[u] : make_uint2(0u, 0u);
+        }
+    } else {
+        for (u32 i = tid; i < M; i += T) v[i] = qtip_sum_parts(L.y32, M, L.parts, i);
+    }
+    __syncthreads();
+    fwht_lds(v, M);
+    const float sc = L.mscale;
+    if (pre) {
+#pragma unroll
+        for (u32 k = 0; k < PRE; k++) {
+            const u32 u = tid + k * T;
+            if (u < M / 4u) {
+                const float4 f = reinterpret_cast<const float4 *>(v)[u];
+                const float fv[4] = {f.x, f.y, f.z, f.w}, sv[4] = {svr[k].x, svr[k].y, svr[k].z, svr[k].w};
+                const u32 rw[2] = {rsr[k].x, rsr[k].y};
+                uint16_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    h16 y = (h16)gq_pin_f32((fv[e] * sc) * sv[e]);
+                    if (L.resid) y = __builtin_bit_cast(h16, (uint16_t)(rw[e >> 1] >> (16 * (e & 1)))) + y;
+                    o[e] = __builtin_bit_cast(uint16_t, y);
+                }
+                reinterpret_cast<uint2 *>(L.out)[u] = make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16));
+            }
+        }
+        return;
+    }
+    for (u32 i = tid; i < M; i += T) {
+        h16 y = (h16)gq_pin_f32((v[i] * sc) * L.SV32[i]);
+        if (L.resid) y = __builtin_bit_cast(h16, L.resid[i]) + y;
+        L.out[i] = __builtin_bit_cast(uint16_t, y);
+    }
 }
 
 // dynamic LDS (offsets from the host, qtip_in_layout): v fp32 [K] at 0, dead once the transform is done -- the chunk slots
@@ -765,6 +828,23 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     // number of items of this block, expressed in the engine's index space (j = blockIdx.x + r * gridDim.x < nitems)
     const u32 total = (L.M / 32u) * a.ksplit, mine = bl < total ? (total - bl + L.nblk - 1u) / L.nblk : 0u;
     qtip_engine<R, SX, WC>(tab, xs, part, stg, L.comp, (L.M / 32u) * nK2 * 128u * R, mine ? blockIdx.x + (mine - 1u) * gridDim.x + 1u : 0u, item_of, prologue, a.dbg);
+    if (a.fin_ctr) {
+        // Every sum of this block is written (by wave 0, in program order before this point).  Release them to the device,
+        // count the block in; the block that completes the count acquires the others' sums and transforms them.  No block
+        // waits for another one: this is not a grid barrier, the last arrival simply carries on.
+        __shared__ u32 is_last;
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            const u32 old = atomicAdd(a.fin_ctr + li, 1u);
+            is_last = old == L.nblk - 1u ? 1u : 0u;
+            if (is_last) a.fin_ctr[li] = 0u;  // (nobody touches it again before the next launch)
+        }
+        __syncthreads();
+        if (!is_last) return;
+        __threadfence();
+        qtip_transform_out(a.fin[li], reinterpret_cast<float *>(tab));  // the codebook is dead: its LDS holds the M floats
+    }
 }
 
 struct QtipOutArgs {
@@ -772,62 +852,7 @@ struct QtipOutArgs {
 };
 __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *v = reinterpret_cast<float *>(smem);
-    const QtipOut L = a.lin[blockIdx.x];
-    const u32 T = blockDim.x, tid = threadIdx.x, M = L.M;
-    // 4 consecutive outputs per thread and step: 16-byte loads of the sums, the scales and (8 bytes) the residual, all
-    // requested before the transform (one block: nothing else hides their latency)
-    constexpr u32 PRE = 2;  // M <= 8192 at 1024 threads
-    const bool vec = !(((uintptr_t)L.y32 | (uintptr_t)L.SV32) & 15u) && !(((uintptr_t)L.resid | (uintptr_t)L.out) & 7u);
-    const bool pre = vec && M <= 4u * PRE * T;
-    float4 svr[PRE];
-    uint2 rsr[PRE];
-    if (pre) {
-#pragma unroll
-        for (u32 k = 0; k < PRE; k++) {
-            const u32 u = tid + k * T;
-            const bool ok = u < M / 4u;
-            float4 y = ok ? reinterpret_cast<const float4 *>(L.y32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok)
-                for (u32 p = 1; p < L.parts; p++) {
-                    const float4 y2 = reinterpret_cast<const float4 *>(L.y32 + (size_t)p * M)[u];
-                    y = make_float4(y.x + y2.x, y.y + y2.y, y.z + y2.z, y.w + y2.w);
-                }
-            if (ok) reinterpret_cast<float4 *>(v)[u] = y;
-            svr[k] = ok ? reinterpret_cast<const float4 *>(L.SV32)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-            rsr[k] = (ok && L.resid) ? reinterpret_cast<const uint2 *>(L.resid)[u] : make_uint2(0u, 0u);
-        }
-    } else {
-        for (u32 i = tid; i < M; i += T) v[i] = qtip_sum_parts(L.y32, M, L.parts, i);
-    }
-    __syncthreads();
-    fwht_lds(v, M);
-    const float sc = L.mscale;
-    if (pre) {
-#pragma unroll
-        for (u32 k = 0; k < PRE; k++) {
-            const u32 u = tid + k * T;
-            if (u < M / 4u) {
-                const float4 f = reinterpret_cast<const float4 *>(v)[u];
-                const float fv[4] = {f.x, f.y, f.z, f.w}, sv[4] = {svr[k].x, svr[k].y, svr[k].z, svr[k].w};
-                const u32 rw[2] = {rsr[k].x, rsr[k].y};
-                uint16_t o[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    h16 y = (h16)gq_pin_f32((fv[e] * sc) * sv[e]);
-                    if (L.resid) y = __builtin_bit_cast(h16, (uint16_t)(rw[e >> 1] >> (16 * (e & 1)))) + y;
-                    o[e] = __builtin_bit_cast(uint16_t, y);
-                }
-                reinterpret_cast<uint2 *>(L.out)[u] = make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16));
-            }
-        }
-        return;
-    }
-    for (u32 i = tid; i < M; i += T) {
-        h16 y = (h16)gq_pin_f32((v[i] * sc) * L.SV32[i]);
-        if (L.resid) y = __builtin_bit_cast(h16, L.resid[i]) + y;
-        L.out[i] = __builtin_bit_cast(uint16_t, y);
-    }
+    qtip_transform_out(a.lin[blockIdx.x], reinterpret_cast<float *>(smem));
 }
 
 // ------------------------------------------------------------------------------------------------ transform with a Hadamard factor
@@ -1078,8 +1103,9 @@ extern "C" int gq_qtip_plan_ksplit(int n, const uint32_t *M, uint32_t K, int max
     return best;
 }
 
-extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
-                                 int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, void *stream) {
+namespace {
+int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R, int n,
+                        const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, const GqQtipOut *fin, void *counters, void *stream) {
     if (ksplit < 1 || ksplit > 4) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: ksplit must be 1..4.");
     if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 1..3 linears.");
     if (n_prev < 0 || n_prev > 2 || (n_prev && !prev)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 0..2 producing linears.");
@@ -1125,6 +1151,18 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
     if (prologue != GQ_QPRO_PRETRANSFORMED && K > 16u * waves * 64u) waves = 16u;  // (the in-place fp16 conversion: <= 2 units per thread)
     a.ksplit = (u32)ksplit;
     a.dbg = g_qdbg;
+    a.fin_ctr = nullptr;
+    if (fin) {
+        if (!counters || ((uintptr_t)counters & 3u)) return gq_fail(GQ_EINVAL, "gq_qtip_linear: counters (u32 [n], zeroed once) missing.");
+        for (int i = 0; i < n; i++) {
+            if (!fin[i].SV32 || !fin[i].out || fin[i].M != lin[i].M) return gq_fail(GQ_EINVAL, "gq_qtip_linear: finish descriptor (SV32, out, M) does not match the linear.");
+            if (!pow2(fin[i].M) || fin[i].M < 32u || fin[i].M > 16384u)
+                return gq_fail(GQ_ENOTSUP, "gq_qtip_linear: M must be a power of two in 32..16384 (other widths: gq_qtip_linear_in + gq_qtip_transform).");
+            a.fin[i] = QtipOut{lin[i].y32, fin[i].SV32, (const uint16_t *)fin[i].resid, (uint16_t *)fin[i].out, fin[i].M,
+                               (float)pow((double)fin[i].M, -0.5), (u32)ksplit};
+        }
+        a.fin_ctr = (u32 *)counters;
+    }
     a.nprev = (u32)n_prev;
     for (int i = 0; i < n_prev; i++) {
         if (!prev[i].y32 || !prev[i].SV32 || prev[i].M != K) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: producing linear must have M == K.");
@@ -1189,6 +1227,18 @@ extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm
 #undef GQ_LAUNCH_QIN_W
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
+}
+}  // namespace
+
+extern "C" int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R,
+                                 int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, void *stream) {
+    return qtip_linear_in_impl(x, x2, norm_weight, eps, prologue, K, R, n, lin, n_prev, prev, ksplit, nullptr, nullptr, stream);
+}
+
+extern "C" int gq_qtip_linear(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R, int n,
+                              const GqQtipIn *lin, const GqQtipOut *finish, int ksplit, void *counters, void *stream) {
+    if (!finish) return gq_fail(GQ_EINVAL, "gq_qtip_linear: finish descriptors missing.");
+    return qtip_linear_in_impl(x, x2, norm_weight, eps, prologue, K, R, n, lin, 0, nullptr, ksplit, finish, counters, stream);
 }
 
 extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {

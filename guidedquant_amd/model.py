@@ -489,6 +489,17 @@ class Transformer(nn.Module):
                     plan.append(("gq_qtip_linear_in", (xs16[i].data_ptr(), None, None, 0.0, 3, K, R, 1, arr, 0, None, ks)))
             p2 = [i for i, m in enumerate(mods) if m.K_right == 1]
             fac = [i for i, m in enumerate(mods) if m.K_right != 1]
+            # One launch for transform-in + matvec + transform-out (gq_qtip_linear: the block that finishes a linear last
+            # transforms it): every linear of the group has a power-of-two output width, nothing is folded or deferred
+            if (one_launch and defer is None and prev is None and not fac and plan and plan[-1][0] == "gq_qtip_linear_in"
+                    and all(m.out_features <= 16384 for m in mods)):
+                name, args = plan.pop()
+                fin = (_lib.GqQtipOut * len(mods))(*[_lib.GqQtipOut(ysl[i].data_ptr(), f32(mods[i].SV, 32.0), resid, outs[i], mods[i].out_features, ks)
+                                                     for i in range(len(mods))])
+                ctr = torch.zeros(4, dtype=torch.int32, device=dev)
+                keep.extend([fin, ctr])
+                plan.append(("gq_qtip_linear", args[:9] + (fin, ks, ctr.data_ptr())))
+                return plan
             if defer is not None:  # (a single linear with a power-of-two output width)
                 desc = _lib.GqQtipOut(ysl[0].data_ptr(), f32(mods[0].SV, 32.0), resid, outs[0], mods[0].out_features, ks)
                 arr = (_lib.GqQtipOut * 1)(desc)
@@ -515,6 +526,11 @@ class Transformer(nn.Module):
         # 4096-point transform and takes the slower prologue path -- measured 365 vs 385 tokens/s on the Llama-2-7b shape
         # (400 vs 422 with a power-of-two MLP), so it stays off.  Needs power-of-two widths on both sides of the fold.
         fold = os.environ.get("GQ_QTIP_FOLD", "0") != "0"
+        # GQ_QTIP_ONE_LAUNCH=1 (default OFF): transform-out inside the matvec launch (gq_qtip_linear, see group()).  Bit-identical,
+        # three launches per layer less -- and measured 302 vs 384 tokens/s on the Llama-2-7b shape: the device-scope release /
+        # acquire fences around the per-linear counter (L2 write-back + invalidate on 8 XCDs) cost ~7 us per launch, more than the
+        # launch they save.
+        one_launch = os.environ.get("GQ_QTIP_ONE_LAUNCH", "0") != "0"
         layers = []
         prev_down = None
         for b in self.layers:

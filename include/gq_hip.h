@@ -200,6 +200,15 @@ int gq_qtip_linear_in(const void *x, const void *x2, const void *norm_weight, fl
                       int n, const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, void *stream);
 int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
 int gq_qtip_plan_ksplit(int n, const uint32_t *M, uint32_t K, int max_ksplit); /* host-side helper, launches nothing */
+/*
+ * gq_qtip_linear_in + gq_qtip_linear_out in ONE launch: the block that finishes a linear LAST (a device-scope counter per
+ * linear; no block waits for another one) also runs that linear's transform-out -- the same code as gq_qtip_linear_out, so the
+ * results are bit-identical to the two-launch form.  finish[i] describes the output side of lin[i] (its y32 / parts fields are
+ * ignored: the launch's own sums and ksplit are used); every M a power of two <= 16384.  counters: u32 [n] in device memory,
+ * zero before the first call (the finishing block resets its counter; one array per stream of launches).
+ */
+int gq_qtip_linear(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R, int n,
+                   const GqQtipIn *lin, const GqQtipOut *finish, int ksplit, void *counters, void *stream);
 
 /*
  * Either side of a QTIP linear whose width n = Kf * P carries a non-power-of-two Hadamard factor (inference/lib/utils/

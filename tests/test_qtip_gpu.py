@@ -509,3 +509,46 @@ def test_plan_ksplit_is_a_valid_split():
         assert ks == 1 or (K // 32) // 4 // ks >= 16  # every range keeps 16 waves busy
     # one linear with 128 bands on a 256-unit chip: two ranges
     assert L.gq_qtip_plan_ksplit(1, (ctypes.c_uint32 * 1)(4096), 4096, 4) == 2
+
+
+@pytest.mark.parametrize("R", [2, 3])
+@pytest.mark.parametrize("Ms,K,pro,ks", [([4096, 1024, 1024], 4096, 1, 1), ([4096], 4096, 0, 2), ([2048], 8192, 2, 2), ([256], 128, 0, 1), ([4096], 2048, 0, 4)])
+def test_one_launch_linear_equals_two_launches(R, Ms, K, pro, ks):
+    """gq_qtip_linear (the block that finishes a linear last runs its transform-out) == gq_qtip_linear_in + gq_qtip_linear_out,
+    bit for bit, also with a residual and split K; repeated launches re-use the counters (the finishing block resets them)"""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    mods = [_rand_qlinear(K, M, R, seed=100 * R + i + M + K) for i, M in enumerate(Ms)]
+    g = torch.Generator(device="cpu").manual_seed(K + sum(Ms))
+    x = (torch.randn(K, generator=g) * 0.7).half().to(d)
+    x2 = torch.randn(K, generator=g).half().to(d)
+    normw = (1 + 0.2 * torch.randn(K, generator=g)).half().to(d)
+    resid = torch.randn(Ms[0], generator=g).half().to(d) if len(Ms) == 1 else None
+    su = [m.SU.float().contiguous() for m in mods]
+    sv = [(m.SV.float() * 32.0).contiguous() for m in mods]
+
+    def run(one):
+        y32 = [torch.full((ks * M,), float("nan"), dtype=torch.float32, device=d) for M in Ms]
+        outs = [torch.full((M,), float("nan"), dtype=torch.float16, device=d) for M in Ms]
+        ain = (_lib.GqQtipIn * len(Ms))(*[_lib.GqQtipIn(m.trellis.data_ptr(), su[i].data_ptr(), m.tlut.data_ptr(), y32[i].data_ptr(), Ms[i])
+                                           for i, m in enumerate(mods)])
+        aout = (_lib.GqQtipOut * len(Ms))(*[_lib.GqQtipOut(y32[i].data_ptr(), sv[i].data_ptr(), resid.data_ptr() if resid is not None else None,
+                                                           outs[i].data_ptr(), Ms[i], ks) for i in range(len(Ms))])
+        args = (x.data_ptr(), x2.data_ptr(), normw.data_ptr(), 1e-5, pro, K, R, len(Ms), ain)
+        if one:
+            ctr = torch.zeros(4, dtype=torch.int32, device=d)
+            for _ in range(3):  # the counters come back to zero after every launch
+                _lib.check(L.gq_qtip_linear(*args, aout, ks, ctr.data_ptr(), None), "one launch")
+            torch.cuda.synchronize()
+            assert int(ctr.abs().sum()) == 0
+        else:
+            _lib.check(L.gq_qtip_linear_in(*args, 0, None, ks, None), "in")
+            _lib.check(L.gq_qtip_linear_out(len(Ms), aout, None), "out")
+            torch.cuda.synchronize()
+        return outs
+
+    two, one = run(False), run(True)
+    for a, b in zip(two, one):
+        assert bool(torch.isfinite(a.float()).all())
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))

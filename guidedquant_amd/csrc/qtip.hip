@@ -188,8 +188,9 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     unsigned char *slot = stg + w * 1024u;
     // R = 2: the slot holds, per loader lane (tile block tb = lane / 16, unit rows 2 j, 2 j + 1), 16 bytes
     // {pack(2j, half 0), pack(2j + 1, half 0), pack(2j, half 1), pack(2j + 1, half 1)} at 256 tb + 16 j
-    const unsigned char *own_p = slot + (R == 2 ? 16u * (s >> 1) + 8u * a4 + 4u * (s & 1u) : s * (4u * R));
-    const unsigned char *nbr_p = slot + (R == 2 ? 16u * (sn >> 1) + 8u * a4 + 4u * (sn & 1u) : sn * (4u * R));
+    // R = 4: raw rows of four dword units; this lane wants units a4 and 2 + a4 (column tiles 0 / 1) of its row and the neighbour's
+    const unsigned char *own_p = slot + (R == 2 ? 16u * (s >> 1) + 8u * a4 + 4u * (s & 1u) : s * (4u * R) + (R == 4 ? 4u * a4 : 0u));
+    const unsigned char *nbr_p = slot + (R == 2 ? 16u * (sn >> 1) + 8u * a4 + 4u * (sn & 1u) : sn * (4u * R) + (R == 4 ? 4u * a4 : 0u));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)comp, 0, (int)comp_bytes, 0x00020000);
 #ifndef QT_PF
 #define QT_PF 2
@@ -268,6 +269,9 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
         if constexpr (R == 2) {
             t.own[0] = *reinterpret_cast<const u32 *>(own_p + tbk * 256u);
             t.nbr[0] = *reinterpret_cast<const u32 *>(nbr_p + tbk * 256u);
+        } else if constexpr (R == 4) {
+            const u32 *po = reinterpret_cast<const u32 *>(own_p + tbk * 512u), *pn = reinterpret_cast<const u32 *>(nbr_p + tbk * 512u);
+            t.own[0] = po[0], t.own[1] = po[2], t.nbr[0] = pn[0], t.nbr[1] = pn[2];  // (one ds_read2_b32 each)
         } else {
             u32 d0[R], d1[R];
 #pragma unroll
@@ -289,6 +293,15 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
             P[1] = ((pack << 4) & 0xFFF0FFF0u) | ((npack >> 12) & 0x000F000Fu);
             P[2] = __builtin_amdgcn_perm(pack, npack, 0x06030401u);
             P[3] = ((pack << 12) & 0xF000F000u) | ((npack >> 4) & 0x0FFF0FFFu);
+        } else if constexpr (R == 4) {
+            // byte-aligned windows of {unit : neighbour's unit}: states 0..2 inside the unit, state 3 = its last byte + the
+            // neighbour's first: six v_perm for both column tiles
+            const u32 u0 = t.own[0], u1 = t.own[1];
+            P[0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+            P[1] = __builtin_amdgcn_perm(u1, u0, 0x06050201u);
+            P[2] = __builtin_amdgcn_perm(u1, u0, 0x05040100u);
+            const u32 lo = __builtin_amdgcn_perm(u1, u0, 0x04040000u), hi = __builtin_amdgcn_perm(t.nbr[1], t.nbr[0], 0x07070303u);
+            P[3] = __builtin_amdgcn_perm(lo, hi, 0x07020500u);
         } else {
             const u64 comb0 = ((u64)t.own[0] << (8 * R)) | (u64)t.nbr[0], comb1 = ((u64)t.own[1] << (8 * R)) | (u64)t.nbr[1];
 #pragma unroll

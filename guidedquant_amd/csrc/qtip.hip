@@ -184,6 +184,7 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     const u32 g = l >> 4, a4 = (l >> 3) & 1u, a = l & 7u, s = 4u * a + g;
     const u32 sn = (s + 1u) & 31u;  // the window of unit s ends in unit s + 1 of the same tile (cyclic)
     const u32 lane4 = (l & 31u) * 4u, voff = l * (4u * LD);
+    const u32 sel3a = a4 ? 0x0C050403u : 0x0C020100u, sel3b = a4 ? 0x0C070605u : 0x0C040302u;  // (R = 3 unit selectors)
     const unsigned char *tabb = reinterpret_cast<const unsigned char *>(tab);
     unsigned char *slot = stg + w * 1024u;
     // R = 2: the slot holds, per loader lane (tile block tb = lane / 16, unit rows 2 j, 2 j + 1), 16 bytes
@@ -273,14 +274,16 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
             const u32 *po = reinterpret_cast<const u32 *>(own_p + tbk * 512u), *pn = reinterpret_cast<const u32 *>(nbr_p + tbk * 512u);
             t.own[0] = po[0], t.own[1] = po[2], t.nbr[0] = pn[0], t.nbr[1] = pn[2];  // (one ds_read2_b32 each)
         } else {
+            // R = 3: a row is 12 bytes, unit j its bytes 3j .. 3j + 2; this lane wants units a4 and 2 + a4: one v_perm each with a
+            // per-lane selector (0x0C = zero byte)
             u32 d0[R], d1[R];
 #pragma unroll
             for (int i = 0; i < R; i++) {
                 d0[i] = reinterpret_cast<const u32 *>(own_p + tbk * (128u * R))[i];
                 d1[i] = reinterpret_cast<const u32 *>(nbr_p + tbk * (128u * R))[i];
             }
-#pragma unroll
-            for (u32 a3 = 0; a3 < 2; a3++) t.own[a3] = unit_of<R>(d0, 2u * a3 + a4), t.nbr[a3] = unit_of<R>(d1, 2u * a3 + a4);
+            t.own[0] = __builtin_amdgcn_perm(d0[1], d0[0], sel3a), t.own[1] = __builtin_amdgcn_perm(d0[2], d0[1], sel3b);
+            t.nbr[0] = __builtin_amdgcn_perm(d1[1], d1[0], sel3a), t.nbr[1] = __builtin_amdgcn_perm(d1[2], d1[1], sel3b);
         }
     };
     auto stage_b = [&](const TbA &t, const uint16_t *xrow, TbB &o) {
@@ -303,12 +306,15 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
             const u32 lo = __builtin_amdgcn_perm(u1, u0, 0x04040000u), hi = __builtin_amdgcn_perm(t.nbr[1], t.nbr[0], 0x07070303u);
             P[3] = __builtin_amdgcn_perm(lo, hi, 0x07020500u);
         } else {
-            const u64 comb0 = ((u64)t.own[0] << (8 * R)) | (u64)t.nbr[0], comb1 = ((u64)t.own[1] << (8 * R)) | (u64)t.nbr[1];
-#pragma unroll
-            for (u32 i = 0; i < 4; i++) {
-                const u32 sh = 16 * R - 2 * R * i - 16;
-                P[i] = ((u32)(comb0 >> sh) & 0xFFFFu) | ((u32)(comb1 >> sh) << 16);
-            }
+            // R = 3: the 48-bit window {unit : neighbour's unit}; V = its bits 47..16, V2 = bits 39..8 (one v_perm each); the states
+            // are bits 47..32, 41..26, 35..20, 29..14 = V[31:16], V[25:10], V[19:4], V2[21:6]: a shift per column tile and a
+            // v_perm that pairs the two 16-bit results
+            const u32 V0 = __builtin_amdgcn_perm(t.own[0], t.nbr[0], 0x06050402u), V1 = __builtin_amdgcn_perm(t.own[1], t.nbr[1], 0x06050402u);
+            const u32 W0 = __builtin_amdgcn_perm(t.own[0], t.nbr[0], 0x05040201u), W1 = __builtin_amdgcn_perm(t.own[1], t.nbr[1], 0x05040201u);
+            P[0] = __builtin_amdgcn_perm(V1, V0, 0x07060302u);
+            P[1] = __builtin_amdgcn_perm(V1 >> 10, V0 >> 10, 0x05040100u);
+            P[2] = __builtin_amdgcn_perm(V1 >> 4, V0 >> 4, 0x05040100u);
+            P[3] = __builtin_amdgcn_perm(W1 >> 6, W0 >> 6, 0x05040100u);
         }
         u32 t0, t1;
         lookup2(P[0], t0, t1);

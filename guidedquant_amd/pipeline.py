@@ -261,7 +261,11 @@ class PipelinedDecoder:
         post_recv(0, 0)
         for step in range(n_tokens):
             for slot in range(S):
-                post_recv(*nxt(step, slot))  # lands while this tick computes
+                # the next tick's input is received while this one computes -- unless it is this slot's own next step (one
+                # sequence in flight: n_seq = 1): its buffer is in use until this tick has been computed and sent on
+                ahead = nxt(step, slot)
+                if ahead[1] != slot:
+                    post_recv(*ahead)
                 if self.first and step == 0:
                     self.tok[slot:slot + 1].fill_(self.bos_id)
                 elif self.first and w == 1:
@@ -282,6 +286,8 @@ class PipelinedDecoder:
                             send_req[slot].wait()
                         # the token leaves from the output row (stable storage: tok_out[slot] is rewritten next step)
                         send_req[slot] = isend(out[slot, step:step + 1], tok_stage[slot:slot + 1] if self.staged else None, 0, self.fb_group)
+                if ahead[1] == slot:
+                    post_recv(*ahead)
         for req in send_req:
             if req is not None:
                 req.wait()

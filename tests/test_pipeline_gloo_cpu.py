@@ -28,7 +28,7 @@ def _build_model():
     return Transformer(torch.float32, cfg).eval()
 
 
-def _worker(rank, world, port, ntok, q):
+def _worker(rank, world, port, ntok, q, n_seq=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, ntok, q):
         torch.set_num_threads(1)
         model = _build_model()
         rng = stage_ranges(model.config.n_layer, world)[rank]
-        dec = PipelinedDecoder(model, rank, world, rng, n_seq=world, max_new_tokens=ntok, temperature=0.0, top_k=8, bos_id=3,
+        dec = PipelinedDecoder(model, rank, world, rng, n_seq=n_seq or world, max_new_tokens=ntok, temperature=0.0, top_k=8, bos_id=3,
                                native=False)
         with torch.no_grad():
             out = dec.run(ntok)
@@ -59,19 +59,22 @@ def test_stage_ranges_cover_and_balance():
 
 
 @pytest.mark.timeout(300)
-def test_pipelined_decode_equals_single_process():
+@pytest.mark.parametrize("n_seq", [2, 1, 3])
+def test_pipelined_decode_equals_single_process(n_seq):
+    """n_seq = 1 is the reference's use case (one bs = 1 stream sharded over the GPUs, qtip/lib/utils/shard_model.py:44-68): a
+    slot's next receive may only be posted once its current tick has been computed and sent"""
     from guidedquant_amd.pipeline import PipelinedDecoder
     ntok = 6
     model = _build_model()
-    dec = PipelinedDecoder(model, 0, 1, range(0, model.config.n_layer), n_seq=2, max_new_tokens=ntok, temperature=0.0, top_k=8,
+    dec = PipelinedDecoder(model, 0, 1, range(0, model.config.n_layer), n_seq=n_seq, max_new_tokens=ntok, temperature=0.0, top_k=8,
                            bos_id=3, native=False)
     with torch.no_grad():
         want = dec.run(ntok).tolist()
-    assert want[0] == want[1]  # both sequences start from the same BOS and decode greedily
+    assert all(w == want[0] for w in want)  # every sequence starts from the same BOS and decodes greedily
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ntok, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ntok, q, n_seq)) for r in range(2)]
     for p in procs:
         p.start()
     try:

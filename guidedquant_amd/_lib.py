@@ -98,6 +98,9 @@ def lib():
     return _lib
 
 
+GQ_ENOTSUP = -95  # include/gq_hip.h: valid request this build has no kernel for
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().gq_last_error()

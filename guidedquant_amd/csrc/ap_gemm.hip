@@ -234,8 +234,7 @@ int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u
     static GqPerDeviceOnce once;
     auto kern = ap_gemm_kernel<BITS>;
     const size_t smem = 2u * STAGE_BYTES;
-    if (once.first_use())
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)smem));
     dim3 grid((N + BN - 1u) / BN, (S + BS - 1u) / BS), block(256);
     hipLaunchKernelGGL(kern, grid, block, smem, s, (const uint16_t *)x, (uint16_t *)out, qw, (const uint16_t *)lut, S, N, K, (u32)gq_env_int("GQ_GEMM_DBG", 0));
     GQ_HIP_CHECK(hipGetLastError());

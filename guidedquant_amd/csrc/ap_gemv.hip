@@ -457,10 +457,7 @@ template <int BITS, int D, int PRO>
 int launch_quad_inst(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
     static GqPerDeviceOnce once;
     auto kern = ap_gemv_quad_kernel<BITS, D, PRO>;
-    if (once.first_use()) {
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(160u * 1024u)));
-    }
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
     GQ_HIP_CHECK(hipGetLastError());

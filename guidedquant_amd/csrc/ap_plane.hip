@@ -19,6 +19,7 @@
 // ap_gemv.hip; gq_set_ap_mode() / GQ_AP_MODE choose.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "gq_internal.h"
 #include "plane_core.h"
@@ -84,6 +85,7 @@ __device__ __forceinline__ float wave_reduce(float v) {
 
 
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef uint16_t us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2v u2h2(u32 u) { return __builtin_bit_cast(h2v, u); }
 __device__ __forceinline__ u32 h22u(h2v h) { return __builtin_bit_cast(u32, h); }
 
@@ -166,6 +168,44 @@ __device__ __forceinline__ void load_tile(u32 (&Wd)[BITS][8], const unsigned cha
     }
 }
 
+// the 2^BITS - 1 MFMAs of one (nibble bit NB, word half HH) block of a step: FP4 A operands of the plane subsets, built on the
+// fly: the mask commutes with AND, so a subset's operand is the AND of its planes' masked words; a depth-first walk over the
+// subset lattice keeps only one partial product per level alive (no register-resident AND words: 4-bit would need 120 of
+// them).  Plane p holds code bit BITS-1-p; subset index cm = OR of the code bits.
+template <int BITS, int NB, int HH>
+__device__ __forceinline__ void mfma_bh(v4f (&acc)[(1 << BITS) - 1], const u32 (&Wd)[BITS][8], v8i Bv, int sb) {
+    v4i Mp[BITS];
+#pragma unroll
+    for (int p = 0; p < BITS; p++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) Mp[p][v] = (int)extract4(Wd[p][4 * HH + v], NB);
+    const int sa = scale_byte4(NB);
+#pragma unroll
+    for (int p0 = 0; p0 < BITS; p0++) {
+        const v4i A1 = Mp[p0];
+        const int c1 = 1 << (BITS - 1 - p0);
+        mfma_f4_bf8(acc[c1 - 1], A1, Bv, sa, sb);
+#pragma unroll
+        for (int p1 = p0 + 1; p1 < BITS; p1++) {
+            const v4i A2 = A1 & Mp[p1];
+            const int c2 = c1 | (1 << (BITS - 1 - p1));
+            mfma_f4_bf8(acc[c2 - 1], A2, Bv, sa, sb);
+#pragma unroll
+            for (int p2 = p1 + 1; p2 < BITS; p2++) {
+                const v4i A3 = A2 & Mp[p2];
+                const int c3 = c2 | (1 << (BITS - 1 - p2));
+                mfma_f4_bf8(acc[c3 - 1], A3, Bv, sa, sb);
+#pragma unroll
+                for (int p3 = p2 + 1; p3 < BITS; p3++) {
+                    const v4i A4 = A3 & Mp[p3];
+                    const int c4 = c3 | (1 << (BITS - 1 - p3));
+                    mfma_f4_bf8(acc[c4 - 1], A4, Bv, sa, sb);
+                }
+            }
+        }
+    }
+}
+
 // the 8 x (2^BITS - 1) MFMAs of one step.  bbase = this lane's 16 bytes of the chunk's (b = 0, h = 0) image block,
 // bstep = distance of the next (b, h) block, bhalf = distance of the lane's second 16 bytes (k + 64)
 template <int BITS>
@@ -174,9 +214,8 @@ __device__ __forceinline__ void mfma_chunk(v4f (&acc)[(1 << BITS) - 1], const u3
     // B operand (activation pieces) double-buffered over the 8 (nibble bit b, word half h) MFMAs per subset
     uint4 bn0 = *reinterpret_cast<const uint4 *>(bbase);
     uint4 bn1 = *reinterpret_cast<const uint4 *>(bbase + bhalf);
-#pragma unroll
-    for (int bh = 0; bh < 8; bh++) {
-        const int nb = bh >> 1, hh = bh & 1;
+    auto one = [&](auto BH) {
+        constexpr int bh = decltype(BH)::value;
         const uint4 b0 = bn0, b1 = bn1;
         if (bh < 7) {
             bn0 = *reinterpret_cast<const uint4 *>(bbase + (u32)(bh + 1) * bstep);
@@ -186,41 +225,121 @@ __device__ __forceinline__ void mfma_chunk(v4f (&acc)[(1 << BITS) - 1], const u3
         // MFMAs into a single B buffer and exposes the LDS latency 8 times per step)
         __builtin_amdgcn_sched_barrier(0);
         v8i Bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-        // FP4 A operands of the 2^BITS - 1 plane subsets, built on the fly: the mask commutes with AND, so a subset's
-        // operand is the AND of its planes' masked words; a depth-first walk over the subset lattice keeps only one
-        // partial product per level alive (no register-resident AND words: 4-bit would need 120 of them).
-        // Plane p holds code bit BITS-1-p; subset index cm = OR of the code bits.
+        mfma_bh<BITS, (bh >> 1), (bh & 1)>(acc, Wd, Bv, sb);
+    };
+    one(std::integral_constant<int, 0>{});
+    one(std::integral_constant<int, 1>{});
+    one(std::integral_constant<int, 2>{});
+    one(std::integral_constant<int, 3>{});
+    one(std::integral_constant<int, 4>{});
+    one(std::integral_constant<int, 5>{});
+    one(std::integral_constant<int, 6>{});
+    one(std::integral_constant<int, 7>{});
+}
+
+// ---- extracted ("hot") activations.  The matrix cores align the 128 products of a dot-product group to the largest exponent
+// and keep a window of ~17 bits (tools/plane_dynrange_probe.py): next to a channel 2^10 .. 2^14 times larger than the rest
+// (the massive activations of Llama hidden states) the group mates would lose their low pieces.  So every element with
+// |x| > tau = 64 x the vector's MEAN magnitude is taken out of the image and appended to a short list -- Markov: fewer than K / 64
+// such elements exist, the list cannot overflow; the mean (unlike the rms) is hardly moved by the largest channels, so smaller
+// massive channels are not shielded by larger ones: a channel is extracted as soon as it holds 1 / 64 of the vector's total
+// magnitude K * mean --; the wave that multiplies the element's chunk adds the list
+// entries of that chunk with one extra MFMA set per (b, h) block whose only non-zero products are the extracted ones: exact
+// products, fp32 accumulation, no alignment loss.  Who detects: in the shared-image kernel the idle late waves (scanners) or,
+// without a staged copy, the early waves from their own maxima; the image builders write every element, and the pieces of the
+// listed ones are cleared once the image is complete (one more barrier, only then).  The common case -- nothing above the
+// threshold; 64 x the mean (51 sigma of a Gaussian) is far outside what SiLU(gate) * up or normalised hidden states produce by
+// chance, and what stays in the image (<= 2^6 x the typical element) is below the ratio where the window starts to matter -- costs the early
+// waves one more sum in the statistics pass and every wave one scalar compare per step.
+//   entry = {key = chunk << 10 | (b * 2 + h) << 7 | k,  the 4 bf8 pieces of x * 2^ksh (byte p = piece p)}
+struct HotEnt {
+    u32 key, pieces;
+};
+typedef __attribute__((address_space(3))) u32 lds_u32;
+__device__ __forceinline__ void hot_append_inl(u32 *cnt_, HotEnt *list_, u32 cap, u32 key, uint16_t xh, uint16_t kh16) {
+    // explicit LDS pointers: through generic ones the counter becomes a FLAT atomic (vmcnt: the wave's plane stream drains)
+    lds_u32 *cnt = (lds_u32 *)cnt_, *list = (lds_u32 *)list_;
+    const u32 idx = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (idx >= cap) return;  // unreachable (Chebyshev bound), kept as a guard against memory corruption
+    _Float16 rem = __builtin_bit_cast(_Float16, xh) * __builtin_bit_cast(_Float16, kh16);
+    u32 pieces = 0;
+#pragma unroll
+    for (u32 p = 0; p < 4; p++) {
+        const uint16_t pb = __builtin_bit_cast(uint16_t, rem) & 0xFF00u;
+        pieces |= (u32)(pb >> 8) << (8u * p);
+        rem = rem - __builtin_bit_cast(_Float16, pb);
+    }
+    list[2u * idx] = key;
+    list[2u * idx + 1u] = pieces;
+}
+// out of line where the caller's loop is not unrolled (a call inside code that keeps register arrays alive costs spills)
+__device__ __attribute__((noinline)) void hot_append(u32 *cnt, HotEnt *list, u32 cap, u32 key, uint16_t xh, uint16_t kh16) {
+    hot_append_inl(cnt, list, cap, key, xh, kh16);
+}
+// the extracted elements of chunk `ckey` (wave-uniform), block by block in ascending (b, h) order: deterministic whatever
+// the order of the list
+template <int BITS>
+__device__ __forceinline__ void hot_step(v4f (&acc)[(1 << BITS) - 1], const u32 (&Wd)[BITS][8], const HotEnt *list, u32 nhot, u32 ckey,
+                                         int sbh, u32 col, u32 kb) {
+    u32 mask = 0;
+    for (u32 e = 0; e < nhot; e++) {
+        const u32 key = __builtin_amdgcn_readfirstlane(list[e].key);
+        if ((key >> 10) == ckey) mask |= 1u << ((key >> 7) & 7u);
+    }
+    while (mask) {
+        const u32 bh = (u32)__builtin_ctz(mask);
+        mask &= mask - 1u;
+        u32 B[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        for (u32 e = 0; e < nhot; e++) {
+            const u32 key = __builtin_amdgcn_readfirstlane(list[e].key);
+            if ((key >> 7) != ((ckey << 3) | bh)) continue;
+            const u32 pieces = __builtin_amdgcn_readfirstlane(list[e].pieces);
+            // lane (col = piece, kb) holds k = 64 (j / 16) + 16 kb + j % 16 as byte j of its 8 registers
+            const u32 k = key & 127u, j = ((k >> 6) << 4) | (k & 15u);
+            const bool mine = col < 4u && ((k >> 4) & 3u) == kb;
+            const u32 val = mine ? ((pieces >> (8u * (col & 3u))) & 0xFFu) << (8u * (j & 3u)) : 0u;
+#pragma unroll
+            for (u32 r = 0; r < 8; r++) B[r] |= (j >> 2) == r ? val : 0u;
+        }
+        const v8i Bv = {(int)B[0], (int)B[1], (int)B[2], (int)B[3], (int)B[4], (int)B[5], (int)B[6], (int)B[7]};
+        // one copy of the subset walk with run-time (b, h): eight specialised copies cost > 100 registers of live ranges
+        const u32 nb = bh >> 1, hh = bh & 1u;
+        const u32 msk = nb == 3u ? 0x44444444u : 0x11111111u << nb, sh = nb == 3u ? 1u : 0u;
         v4i Mp[BITS];
 #pragma unroll
         for (int p = 0; p < BITS; p++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) Mp[p][v] = (int)extract4(Wd[p][4 * hh + v], nb);
-        const int sa = scale_byte4(nb);
-#pragma unroll
-        for (int p0 = 0; p0 < BITS; p0++) {
-            const v4i A1 = Mp[p0];
-            const int c1 = 1 << (BITS - 1 - p0);
-            mfma_f4_bf8(acc[c1 - 1], A1, Bv, sa, sb);
-#pragma unroll
-            for (int p1 = p0 + 1; p1 < BITS; p1++) {
-                const v4i A2 = A1 & Mp[p1];
-                const int c2 = c1 | (1 << (BITS - 1 - p1));
-                mfma_f4_bf8(acc[c2 - 1], A2, Bv, sa, sb);
-#pragma unroll
-                for (int p2 = p1 + 1; p2 < BITS; p2++) {
-                    const v4i A3 = A2 & Mp[p2];
-                    const int c3 = c2 | (1 << (BITS - 1 - p2));
-                    mfma_f4_bf8(acc[c3 - 1], A3, Bv, sa, sb);
-#pragma unroll
-                    for (int p3 = p2 + 1; p3 < BITS; p3++) {
-                        const v4i A4 = A3 & Mp[p3];
-                        const int c4 = c3 | (1 << (BITS - 1 - p3));
-                        mfma_f4_bf8(acc[c4 - 1], A4, Bv, sa, sb);
-                    }
-                }
+            for (int v = 0; v < 4; v++) {
+                // (through opaque copies: a select of two array elements becomes a dynamically indexed -- scratch -- array)
+                u32 lo = Wd[p][v], hi = Wd[p][4 + v];
+                asm("" : "+v"(lo), "+v"(hi));
+                Mp[p][v] = (int)(((hh ? hi : lo) >> sh) & msk);
             }
+        const int sa = nb == 0u ? 128 : (nb == 1u ? 127 : 126);
+#pragma unroll
+        for (int cm = 1; cm < (1 << BITS); cm++) {
+            v4i A = {-1, -1, -1, -1};
+#pragma unroll
+            for (int p = 0; p < BITS; p++)
+                if (cm & (1 << (BITS - 1 - p))) A &= Mp[p];
+            mfma_f4_bf8(acc[cm - 1], A, Bv, sa, sbh);
         }
     }
+}
+// threshold of the extraction as an fp16 bit pattern (rounded up): 64 x the mean magnitude, 1 % above it for the roundings of the
+// estimate (sum1 = sum |x| over K elements)
+#define GQ_HOT_T 64.0f
+#ifndef HOT_ABL
+#define HOT_ABL 0  // ablation experiments (build-time): 1 no threshold, 2 no detection, 4 no extra MFMA sets
+#endif
+__device__ __forceinline__ u32 hot_tau_bits(float sum1, float K) {
+#if HOT_ABL & 1
+    return 0x7C00u;
+#endif
+    // the hardware reciprocal (1 ulp) is plenty next to the 1 % margin
+    const float tau = GQ_HOT_T * 1.01f * sum1 * __builtin_amdgcn_rcpf(K);
+    if (!(tau < 65000.f)) return 0x7C00u;  // nothing exceeds +inf: no extraction
+    return (u32)__builtin_bit_cast(uint16_t, (_Float16)tau) + 1u;
 }
 
 // item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
@@ -329,7 +448,10 @@ __device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
 //                block in the issue queue; they only wait for the image, through an LDS counter.
 // Items: i < L (= W - E late waves) -> the first item of late wave E + i; i >= L -> wave (i - L) mod W.
 template <int BITS, int PRO, int NI>
-__global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneArgs a) {
+#ifndef PL_WPE
+#define PL_WPE 4
+#endif
+__global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2) ap_plane_kernel(PlaneArgs a) {
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
     constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u, E = W / 2u, L = W - E;  // early / late waves
     // NI prologue passes over the (chunk, virtual lane, weight pair) items: pass n gives early wave w the chunk (w >> 1) + n * E / 2
@@ -344,7 +466,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     const u32 l = tid & 63u;
     const u32 CS = 1u << a.log2CS, cpi = a.cpi, S = a.S;
     const u32 nIt = a.RGB * CS;  // items of this block
-    // LDS: [A rings: W x S slots][LUT rows of the block][B image: nchunks * 4096][zero32 (64 B)][red: 60 floats, ctr: 4][part]
+    // LDS: [A rings: W x S slots][LUT rows of the block][B image: nchunks * 4096][zero32 (64 B)][red: 60 floats, ctr: 4][hot list: K / 64 x 8 B][part]
     unsigned char *ring = smem + (size_t)w * S * SLOT;
     const u32 lut_bytes = (a.RGB * 16u * (u32)NP * 2u + LPS * 1024u - 1u) / (LPS * 1024u) * (LPS * 1024u);  // whole pseudo steps
     unsigned char *lutb = smem + (size_t)W * S * SLOT;
@@ -352,8 +474,10 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     unsigned char *bimg = lutb + lut_bytes;
     unsigned char *zero32 = bimg + G.nchunks * 4096u;
     float *red = reinterpret_cast<float *>(zero32 + 64);
-    u32 *ctr = reinterpret_cast<u32 *>(red + 60);
-    float *part = red + 64;  // [item][subset][16 rows]
+    u32 *ctr = reinterpret_cast<u32 *>(red + 60);  // 0, 1, 3: software barriers; 2: extracted elements
+    HotEnt *hotl = reinterpret_cast<HotEnt *>(red + 64);
+    const u32 hot_cap = G.K / 64u;                    // Markov: |x| > 64 mean|x| holds for fewer than K / 64 elements
+    float *part = red + 64 + 2u * hot_cap;            // [item][subset][16 rows]
     const u32 rg0 = blockIdx.x * a.RGB;
     const u32 m = blockIdx.y;
     auto stamp = [&](int i) {
@@ -481,6 +605,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     float X = 0.f;
     int sb = 127;
     float nscale = 0.f, xmax = 0.f;
+    float mx_lane = 0.f;  // largest element of this lane's statistics pass (before the normalisation)
     if (early) {
     wait_vm<0>();  // the activation loads (an early wave has nothing else in flight)
     // ---------------------------------------------------------------- 1. statistics (+ staging) -> one early-wave barrier
@@ -488,17 +613,21 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     // With the LDS staging they are taken in the coalesced (raw) domain, before the copy is written, so the staging
     // barrier is also the statistics barrier; SiLU(gate) * up is applied there too and only the product is staged.
     {
-        float ss = 0.f, mx = 0.f;
-        u32 mxi = 0;
+        // RMSNorm: sum x^2 (ss) and, of v = x * w (fp32 products out of v_dot2 with the other half zeroed: no fp16 overflow): max |v|
+        // and sum |v| (s2); otherwise max |x'| (packed integer maximum of the bit patterns) and sum |x'| of the transformed vector
+        float ss = 0.f, s2 = 0.f, mxf = 0.f;
+        us2 mxp = {0, 0};  // |fp16| bit patterns order like unsigned integers
         auto stat = [&](u32 xw, u32 aw) {  // one packed pair of activations (and of norm weights)
             if constexpr (PRO == PRO_RMSNORM) {
-                const float p = h2f(xw & 0xFFFF), q = h2f(xw >> 16);
-                ss += p * p;
-                ss += q * q;
-                mx = fmaxf(mx, fmaxf(fabsf(p * h2f(aw & 0xFFFF)), fabsf(q * h2f(aw >> 16))));
+                ss = __builtin_amdgcn_fdot2(u2h2(xw), u2h2(xw), ss, false);
+                const float p = __builtin_amdgcn_fdot2(u2h2(xw), u2h2(aw & 0xFFFFu), 0.f, false);
+                const float q = __builtin_amdgcn_fdot2(u2h2(xw), u2h2(aw & 0xFFFF0000u), 0.f, false);
+                mxf = fmaxf(mxf, fmaxf(fabsf(p), fabsf(q)));
+                if (!(HOT_ABL & 64)) s2 = (s2 + fabsf(p)) + fabsf(q);
             } else {
-                const u32 ab = xw & 0x7FFF7FFFu;  // |fp16| bit patterns order like unsigned integers
-                mxi = max(mxi, max(ab & 0xFFFFu, ab >> 16));
+                const u32 ab = xw & 0x7FFF7FFFu;
+                mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, ab));
+                if (!(HOT_ABL & 64)) s2 = __builtin_amdgcn_fdot2(u2h2(ab), u2h2(0x3C003C00u), s2, false);
             }
         };
         if (a.rawx) {
@@ -536,12 +665,15 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
                 }
             }
         }
-        if constexpr (PRO != PRO_RMSNORM) mx = h2f((uint16_t)mxi);
+        float mx = PRO == PRO_RMSNORM ? mxf : h2f(max(mxp[0], mxp[1]));
+        mx_lane = mx;
         mx = wave_reduce<true>(mx);
         if constexpr (PRO == PRO_RMSNORM) ss = wave_reduce<false>(ss);
+        if (!(HOT_ABL & 64)) s2 = wave_reduce<false>(s2);
         if (l == 63) {
             red[w] = mx;
             if constexpr (PRO == PRO_RMSNORM) red[16 + w] = ss;
+            if (!(HOT_ABL & 64)) red[50 + w] = s2;
         }
         arrive(ctr + 0, l);
     }
@@ -551,7 +683,14 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     const bool helper = !early && a.himg;
     const u32 vw = early ? w : w - E;
     const u32 n0 = a.himg ? (early ? 0u : NIe) : 0u, n1 = a.himg ? (early ? NIe : (u32)NI) : (u32)NI;
-    if (early || helper) {
+    // Who looks for elements above the extraction threshold (hot_step): with the staged copy in LDS and idle late waves, the
+    // first half of the late waves (their tiles are requested, they only wait for the image: nothing is added to the early
+    // waves' serial chain, where every instruction costs 5-8 cycles); otherwise the early waves, from their own maxima.
+    constexpr u32 NSC = L >= 2u ? L / 2u : 1u;
+    const bool scan_late = a.rawx && !a.himg && !(HOT_ABL & 2) && !(HOT_ABL & 32);
+    const bool scanner = scan_late && !early && w - E < NSC;
+    const u32 img_arrivals = (a.himg ? W : E) + (scan_late ? NSC : 0u);
+    if (early || helper || scanner) {
     {
         wait_count(ctr + 0, E);
 #pragma unroll
@@ -563,6 +702,71 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
             nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
             xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
         }
+        if (!(HOT_ABL & 2) && !(HOT_ABL & 16) && (scanner || (!scan_late && early))) {
+            float tot2 = 0.f;
+#pragma unroll
+            for (u32 i = 0; i < E; i++) tot2 += red[50 + i];
+            if constexpr (PRO == PRO_RMSNORM) tot2 *= nscale;
+            const u32 tau = hot_tau_bits(tot2, (float)G.K);
+            const float tauf = h2f((uint16_t)tau);
+            const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;  // the staged copy (rawx)
+            const u32 first = early ? tid : tid - E * 64u, stride = early ? E * 64u : NSC * 64u;  // this lane's 16-byte units of it
+            float mine = mx_lane;
+            if (!early) {  // scanner: the largest of its units (RMSNorm: of the fp16 products x w, as in the statistics pass)
+                us2 m = {0, 0};
+                for (u32 idx = first; idx < G.K / 8u; idx += stride) {
+                    const u32x4 xv = *reinterpret_cast<const u32x4 *>(rx + 8u * idx);
+                    u32x4 wv = xv;
+                    if constexpr (PRO == PRO_RMSNORM) wv = *reinterpret_cast<const u32x4 *>(ra + 8u * idx);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const u32 v = PRO == PRO_RMSNORM ? h22u(u2h2(xv[k]) * u2h2(wv[k])) : xv[k];
+                        m = __builtin_elementwise_max(m, __builtin_bit_cast(us2, v & 0x7FFF7FFFu));
+                    }
+                }
+                mine = h2f(max(m[0], m[1]));
+            }
+            if constexpr (PRO == PRO_RMSNORM) mine = mine * nscale * 1.002f;
+            if (__builtin_expect(tau < 0x7C00u && !(mine <= tauf), 0)) {
+                // rare: some element of this lane exceeds the threshold.  Append it to the list; its pieces leave the image once that
+                // is complete (below)
+                const uint16_t k16h = pow2_f16(piece_shift(xmax));
+                auto consider = [&](u32 xh, u32 wh, u32 key, auto inl) {  // one element (and its norm weight) as fp16 bits
+                    if constexpr (PRO == PRO_RMSNORM) {
+                        const _Float16 hn = (_Float16)gq_pin_f32(h2f((uint16_t)xh) * nscale);  // the transform of the image builders
+                        xh = __builtin_bit_cast(uint16_t, (_Float16)(hn * __builtin_bit_cast(_Float16, (uint16_t)wh)));
+                    }
+                    if ((xh & 0x7FFFu) > tau) {
+                        if constexpr (decltype(inl)::value) hot_append_inl(ctr + 2, hotl, hot_cap, key, (uint16_t)xh, k16h);
+                        else hot_append(ctr + 2, hotl, hot_cap, key, (uint16_t)xh, k16h);
+                    }
+                };
+                if (a.rawx) {
+                    for (u32 idx = first; idx < G.K / 8u; idx += stride) {
+#pragma nounroll
+                        for (u32 j = 0; j < 8; j++) {
+                            const u32 e = 8u * idx + j;
+                            u32 chunk, bb, hh, k;
+                            locate_x4(G, e, chunk, bb, hh, k);
+                            consider(rx[e], PRO == PRO_RMSNORM ? ra[e] : 0u, (chunk << 10) | ((bb * 2u + hh) << 7) | k, std::false_type{});
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (u32 n = 0; n < (u32)NI; n++) {
+                        const u32 chunk = (w >> 1) + n * (E / 2u);
+                        if (chunk >= G.nchunks || pt >= G.tpw(chunk)) continue;
+#pragma unroll
+                        for (u32 c = 0; c < 4; c++)
+#pragma unroll
+                            for (u32 hf = 0; hf < 2; hf++)  // element (c, half): k = 32 g + 8 v + 2 (3 - c) + half
+                                consider((xr[n][c] >> (16u * hf)) & 0xFFFFu, PRO == PRO_RMSNORM ? (ar[n][c] >> (16u * hf)) & 0xFFFFu : 0u,
+                                         (chunk << 10) | ((pb * 2u + ((pt >> 2) & 1u)) << 7) | (32u * (pt >> 3) + 8u * (pt & 3u) + 2u * (3u - c) + hf), std::true_type{});
+                    }
+                }
+            }
+        }
+        if (!scanner)
         if (a.rawx) {
             // the staged copy is complete: gather this thread's items (for SiLU the staged vector is already the product)
             const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;
@@ -581,9 +785,13 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
             }
         }
     }
+    if (scanner) {
+        arrive(ctr + 1, l);
+    } else {
     stamp(7);
 
     // ---------------------------------------------------------------- 2. transform, scale, split, scatter
+    // one power of two for the whole vector, from its maximum (extracted elements included: their entries carry the same scale)
     const int ksh = piece_shift(xmax);
     {
         const uint16_t k16 = pow2_f16(ksh);
@@ -628,12 +836,27 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
     }
     stamp(1);
     arrive(ctr + 1, l);
-    }  // image builders
-    wait_count(ctr + 1, a.himg ? W : E);  // the B image is complete
+    }
+    }  // image builders, scanners
+    wait_count(ctr + 1, img_arrivals);  // the B image is complete
     stamp(2);
 #pragma unroll
     for (u32 i = 0; i < W; i++) X += red[32 + i];
     sb = (int)__builtin_bit_cast(u32, red[48]);
+    // (a plain LDS read, like red[]: a volatile / atomic access through the generic pointer compiles to a FLAT load whose
+    // s_waitcnt vmcnt(0) drains the wave's whole plane stream -- measured: w1w3 9.4 -> 10.3 us)
+    const u32 nhot_raw = (HOT_ABL & 256) ? 0u : __builtin_amdgcn_readfirstlane(__builtin_bit_cast(u32, red[62]));
+    const u32 nhot = nhot_raw < hot_cap ? nhot_raw : hot_cap;
+    if (!(HOT_ABL & 8) && __builtin_expect(nhot != 0u, 0)) {
+        // rare (the same for every wave: appends precede the appender's arrival at the image barrier): the extracted elements
+        // leave the image -- byte k of their (chunk, b, h) block in each of the 4 piece columns --, one more barrier
+        for (u32 e = tid; e < 4u * nhot; e += T) {
+            const u32 key = hotl[e >> 2].key;
+            bimg[(key >> 10) * 4096u + ((key >> 7) & 7u) * 512u + (e & 3u) * 128u + (key & 127u)] = 0;
+        }
+        arrive(ctr + 3, l);
+        wait_count(ctr + 3, W);
+    }
 
     // ---------------------------------------------------------------- 3. main loop: the steps of this wave
     // the rest of the ring is requested now: the first tiles of the block have (mostly) landed, the queues have room
@@ -662,6 +885,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
             const unsigned char *bbase = bcol ? bimg + bimg4_off(chunk, 0u, 0u, col) + 16u * kb : zero32;
             // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
             mfma_chunk<BITS>(acc, Wd, bbase, bcol ? 512u : 0u, bcol ? 64u : 0u, sb);
+            if (!(HOT_ABL & 4) && __builtin_expect(nhot != 0u, 0)) hot_step<BITS>(acc, Wd, hotl, nhot, chunk, sb, col, kb);
         } else if (a.xflags & 1u) {
             acc[0][0] += __builtin_bit_cast(float, Wd[0][0] ^ Wd[BITS - 1][7]);
         }
@@ -690,7 +914,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_kernel(PlaneA
 // the small matrices (N = 4096: 57 KiB of planes per CU), not the plane stream.
 //   items: wave w takes items w, w + W, ...; CS divides W, so all of them cover the same chunks cs * cpi .. + cpi - 1,
 //   cs = w mod CS, of different row groups.  Waves with the same cs build the same image redundantly (RGB > 1).
-//   LDS: [A rings: W x S slots][LUT rows][images: W x NC x 4096][red: 64 floats][part]
+//   LDS: [A rings: W x S slots][LUT rows][images: W x NC x 4096][red: 64 floats][hot lists: W x 16 NC x 8 B][part]
 template <int BITS, int PRO, int NC>
 __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(PlaneArgs a) {
     static_assert(PRO != PRO_RMSNORM, "the RMSNorm scale needs the whole vector");
@@ -711,7 +935,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     const u32 *lutl = reinterpret_cast<const u32 *>(lutb);
     unsigned char *img = lutb + lut_bytes + (size_t)w * NC * 4096u;
     float *red = reinterpret_cast<float *>(lutb + lut_bytes + (size_t)W * NC * 4096u);
-    float *part = red + 64;
+    // extracted elements of this wave's chunks (see hot_step): |x| > 64 x the mean magnitude of the wave's NC * 1024 elements, < 16 NC of them
+    constexpr u32 hot_cap = 16u * NC;
+    u32 *hot_cnt = reinterpret_cast<u32 *>(red) + w;
+    HotEnt *hotl = reinterpret_cast<HotEnt *>(red + 64) + (size_t)w * hot_cap;
+    float *part = red + 64 + 2u * W * hot_cap;
     const u32 rg0 = blockIdx.x * a.RGB;
     const u32 m = blockIdx.y;
     const u32 items_w = nIt > w ? (nIt - w + W - 1u) / W : 0u;
@@ -784,8 +1012,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     wait_vm_steps<LPS>(iq_n + nlut);  // the activation loads were issued first (host: S + nlut <= 4)
     stamp(7);
     int sb = 127;
+    u32 nhot = 0;
     if (items_w) {
-        u32 mxi = 0;
+        const h2v one2 = u2h2(0x3C003C00u);
+        us2 mxp = {0, 0};
+        float s2 = 0.f, xsum = 0.f;
 #pragma unroll
         for (u32 n = 0; n < (u32)NC; n++)
 #pragma unroll
@@ -796,15 +1027,53 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
                 for (int q = 0; q < 4; q++) {
                     if constexpr (PRO == PRO_SILUMUL) xv[n][k][q] = silu_mul2(xv[n][k][q], gv[n][k][q]);
                     const u32 ab = xv[n][k][q] & 0x7FFF7FFFu;  // |fp16| bit patterns order like unsigned integers
-                    mxi = max(mxi, max(ab & 0xFFFFu, ab >> 16));
+                    mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, ab));
+                    s2 = __builtin_amdgcn_fdot2(u2h2(ab), one2, s2, false);
+                    xsum = __builtin_amdgcn_fdot2(u2h2(xv[n][k][q]), one2, xsum, false);  // (loads outside the vector returned zeros)
                 }
             }
+        const u32 mxi = max(mxp[0], mxp[1]);
         const float mx = wave_reduce<true>(h2f((uint16_t)mxi));
+        s2 = wave_reduce<false>(s2);
         const float xmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 63));
-        const int ksh = piece_shift(xmax);
+        const float tot2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s2), 63));
+        const u32 tau = hot_tau_bits(tot2, (float)(NC * 1024u));
+        const int ksh = piece_shift(xmax);  // one scale for the image and the extracted elements
         sb = 127 - ksh;
-        const h2v kk = u2h2((u32)pow2_f16(ksh) * 0x10001u), one2 = u2h2(0x3C003C00u);
-        float xsum = 0.f;
+        const bool any_hot = !(HOT_ABL & 2) && __builtin_amdgcn_ballot_w64(mxi > tau) != 0ull;  // wave-uniform, no LDS traffic
+        if (__builtin_expect(any_hot, 0)) {
+            if (l == 0) *hot_cnt = 0u;  // LDS operations of one wave are served in order
+        }
+        if (__builtin_expect(any_hot, 0) && mxi > tau) {
+            // rare: unit u = (byte c, virtual lane t), word q = weights j = 2q, 2q + 1; plane bit s = 7 - j: b = s & 3,
+            // nibble i = 2 (3 - c) + (s >> 2), k = 32 (t / 8) + 8 (t % 4) + i, h = (t / 4) % 2
+#pragma unroll
+            for (u32 n = 0; n < (u32)NC; n++) {
+                const u32 chunk = chunk0 + n;
+                if (n >= cpi || chunk >= G.nchunks) continue;
+                const u32 tp = G.tpw(chunk);
+#pragma unroll
+                for (u32 k = 0; k < 2; k++) {
+                    const u32 u = l + 64u * k;
+                    if (u >= 4u * tp) continue;
+                    const u32 c = u / tp, t = u % tp;
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++)
+#pragma unroll
+                        for (u32 hf = 0; hf < 2; hf++) {
+                            const u32 xh = (xv[n][k][q] >> (16u * hf)) & 0xFFFFu;
+                            if ((xh & 0x7FFFu) > tau) {
+                                const u32 sbit = 7u - (2u * q + hf);
+                                const u32 kpos = 32u * (t >> 3) + 8u * (t & 3u) + 2u * (3u - c) + (sbit >> 2);
+                                hot_append_inl(hot_cnt, hotl, hot_cap, (n << 10) | (((sbit & 3u) * 2u + ((t >> 2) & 1u)) << 7) | kpos, (uint16_t)xh,
+                                           pow2_f16(ksh));
+                                xv[n][k][q] &= ~(0xFFFFu << (16u * hf));
+                            }
+                        }
+                }
+            }
+        }
+        const h2v kk = u2h2((u32)pow2_f16(ksh) * 0x10001u);
 #pragma unroll
         for (u32 n = 0; n < (u32)NC; n++) {
             const u32 chunk = chunk0 + n;
@@ -819,7 +1088,6 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const u32 xw = xv[n][k][q];
-                    xsum = __builtin_amdgcn_fdot2(u2h2(xw), one2, xsum, false);
                     h2v rem = u2h2(xw) * kk;
 #pragma unroll
                     for (u32 p = 0; p < 4; p++) {
@@ -859,6 +1127,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
         }
         xsum = wave_reduce<false>(xsum);
         if (l == 63) red[32 + w] = w < CS ? xsum : 0.f;  // sum(x): every chunk range counted once
+        if (__builtin_expect(any_hot, 0)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const u32 nh = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(u32, red[w]));  // plain LDS read (see the shared-image kernel)
+            nhot = nh < hot_cap ? nh : hot_cap;
+        }
     } else if (l == 63) {
         red[32 + w] = 0.f;
     }
@@ -884,7 +1157,10 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
             issue();
         }
         if (++cq_slot == S) cq_slot = 0;
-        if (chunk < G.nchunks) mfma_chunk<BITS>(acc, Wd, blane + cq_c * 4096u, 512u, 64u, sb);
+        if (chunk < G.nchunks) {
+            mfma_chunk<BITS>(acc, Wd, blane + cq_c * 4096u, 512u, 64u, sb);
+            if (!(HOT_ABL & 4) && __builtin_expect(nhot != 0u, 0)) hot_step<BITS>(acc, Wd, hotl, nhot, cq_c, sb, col, kb);
+        }
         if (++cq_c == cpi) {
             park_item<NP1>(acc, part + (size_t)cq_item * NP1 * 16u, col, kb);
             cq_c = 0;
@@ -935,7 +1211,7 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     const u32 np1 = (1u << bits) - 1u;
     const size_t lps_bytes = 2048u * (size_t)bits;  // LPS loads of 1 KiB
     const size_t lutb = ((size_t)rgb * 16u * (np1 + 1u) * 2u + lps_bytes - 1u) / lps_bytes * lps_bytes;
-    const size_t fixed = lutb + (size_t)nchunks * 4096u + 64u + 64u * 4u + (size_t)nIt * np1 * 16u * 4u;
+    const size_t fixed = lutb + (size_t)nchunks * 4096u + 64u + 64u * 4u + (size_t)(K / 64u) * 8u + (size_t)nIt * np1 * 16u * 4u;
     const size_t slot = 2048u * (size_t)bits, lds = 160u * 1024u;
     if (fixed + W * slot > lds) return false;
     u32 S = (u32)((lds - fixed) / (W * slot));
@@ -976,7 +1252,7 @@ bool pick_local_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     const size_t lps_bytes = 2048u * (size_t)bits, slot = lps_bytes, lds = 160u * 1024u;
     const size_t lutb = ((size_t)c.RGB * 16u * (np1 + 1u) * 2u + lps_bytes - 1u) / lps_bytes * lps_bytes;
     const u32 nlut = (u32)(lutb / lps_bytes);
-    const size_t fixed = lutb + (size_t)W * c.NI * 4096u + 64u * 4u + (size_t)nIt * np1 * 16u * 4u;
+    const size_t fixed = lutb + (size_t)W * c.NI * 4096u + 64u * 4u + (size_t)W * 16u * c.NI * 8u + (size_t)nIt * np1 * 16u * 4u;
     if (nlut > 2u || fixed + W * slot > lds) return false;
     u32 S = (u32)((lds - fixed) / (W * slot));
     if (S > 4u - nlut) S = 4u - nlut;  // the activation loads are waited for with everything else in flight (vmcnt immediates)
@@ -991,10 +1267,7 @@ template <int BITS, int PRO, int NC>
 int launch_local_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     static GqPerDeviceOnce once;
     auto kern = ap_plane_local_kernel<BITS, PRO, NC>;
-    if (once.first_use()) {
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(160u * 1024u)));
-    }
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
     GQ_HIP_CHECK(hipGetLastError());
@@ -1017,10 +1290,7 @@ template <int BITS, int PRO, int NI>
 int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     static GqPerDeviceOnce once;
     auto kern = ap_plane_kernel<BITS, PRO, NI>;
-    if (once.first_use()) {
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(160u * 1024u)));
-    }
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
     GQ_HIP_CHECK(hipGetLastError());

@@ -503,20 +503,14 @@ extern "C" int gq_attn_decode_split(const void *qkv, const int *pos, const void 
     const dim3 grid(n_head, n_split);
     if (head_dim == 128) {
         static GqPerDeviceOnce once;
-        if (once.first_use()) {
-            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_decode_kernel<128>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_decode_kernel<128>), 160 * 1024));
         hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
                            (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
         if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(n_head), dim3(128), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
     } else {
         static GqPerDeviceOnce once;
-        if (once.first_use()) {
-            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_decode_kernel<64>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_decode_kernel<64>), 160 * 1024));
         hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
                            (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
@@ -547,10 +541,7 @@ extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32
     rpb = ((rpb + 4u * RW - 1u) / (4u * RW)) * (4u * RW);
     const u32 grid = (N + rpb - 1u) / rpb;
     static GqPerDeviceOnce once;
-    if (once.first_use()) {
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dense_gemv_kernel<RW>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(dense_gemv_kernel<RW>), 160 * 1024));
     hipLaunchKernelGGL(dense_gemv_kernel<RW>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const uint16_t *)x,
                        (const uint16_t *)W, (uint16_t *)out, N, K, (const uint16_t *)norm_weight, eps, rpb);
     GQ_HIP_CHECK(hipGetLastError());

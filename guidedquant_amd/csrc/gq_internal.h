@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "../../include/gq_hip.h"
 
 int gq_fail(int code, const char *msg);            // records msg (thread-local) and returns code
@@ -12,15 +14,18 @@ int gq_cu_count();                                 // compute units of the CURRE
 // One-time per-DEVICE actions (function attributes such as the > 64 KiB dynamic-LDS opt-in are per device: a process that
 // drives several GPUs -- reference-style sequential sharding, device_map -- must repeat them on each one).
 struct GqPerDeviceOnce {
-    unsigned long long done[4] = {0, 0, 0, 0};
-    // true exactly once per device (racing threads may both see true: the guarded action is idempotent)
-    bool first_use() {
+    std::atomic<unsigned long long> done[4] = {{0}, {0}, {0}, {0}};
+    // raise the kernel's dynamic-LDS limit once per device.  A device is marked only AFTER the call succeeded: a failure (a sticky
+    // error, a call during capture) is reported and retried by the next launch instead of leaving the opt-in undone for good.
+    // Racing threads may both make the call: it is idempotent.
+    hipError_t max_dynamic_lds(const void *func, int bytes) {
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return true;
+        const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 256;
         const unsigned long long bit = 1ull << (dev & 63);
-        if (done[dev >> 6] & bit) return false;
-        done[dev >> 6] |= bit;
-        return true;
+        if (known && (done[dev >> 6].load(std::memory_order_acquire) & bit)) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && known) done[dev >> 6].fetch_or(bit, std::memory_order_release);
+        return e;
     }
 };
 

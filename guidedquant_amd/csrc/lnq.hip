@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(128) lnq_cd_block_kernel(const float *__restri
 extern "C" int gq_lnq_cd_block(const float *W, const float *B, const float *Hn, const float *C, uint8_t *assign, float *What, uint32_t N,
                                uint32_t d, uint32_t n_cluster, uint32_t group_rows, uint32_t col_start, uint32_t col_end, void *stream) {
     if (!W || !B || !Hn || !C || !assign || !What) return gq_fail(GQ_EINVAL, "null pointer argument.");
-    if (N == 0 || d == 0 || n_cluster < 2 || n_cluster > 16) return gq_fail(GQ_EINVAL, "gq_lnq_cd_block: n_cluster must be 2..16.");
+    if (N == 0 || d == 0 || n_cluster < 2) return gq_fail(GQ_EINVAL, "gq_lnq_cd_block: n_cluster must be >= 2.");
+    if (n_cluster > 16) return gq_fail(GQ_ENOTSUP, "gq_lnq_cd_block: more than 16 centroids (> 4 bits) are not served by the kernel.");
     if (col_start >= col_end || col_end > d || col_end - col_start > CB) return gq_fail(GQ_EINVAL, "gq_lnq_cd_block: a block is 1..128 columns.");
     if (group_rows == 0 || N % group_rows) return gq_fail(GQ_EINVAL, "gq_lnq_cd_block: N must be a multiple of the rows per Hessian group.");
     // rows per workgroup: the largest power of two <= 128 dividing the group size (a workgroup reads ONE group's Hessian)
@@ -85,8 +86,7 @@ extern "C" int gq_lnq_cd_block(const float *W, const float *B, const float *Hn, 
     if (TB < 32u) return gq_fail(GQ_ENOTSUP, "gq_lnq_cd_block: rows per Hessian group must be a multiple of 32.");
     const size_t smem = (size_t)(CB * CB + CB * TB) * 4u;
     static GqPerDeviceOnce once;
-    if (once.first_use())
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lnq_cd_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(lnq_cd_block_kernel), 160 * 1024));
     hipLaunchKernelGGL(lnq_cd_block_kernel, dim3((N + TB - 1u) / TB), dim3(TB), smem, (hipStream_t)stream, W, B, Hn, C, assign, What, N, d, n_cluster,
                        group_rows, col_start, col_end);
     GQ_HIP_CHECK(hipGetLastError());

@@ -220,10 +220,7 @@ extern "C" int gq_lutgemm_gemv(const void *x, void *out, const uint32_t *qweight
 #define GQ_LG_CASE(B)                                                                                                    \
     case B: {                                                                                                            \
         static GqPerDeviceOnce once;                                                                                         \
-        if (once.first_use()) {                                                                                                      \
-            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lutgemm_kernel<B>),                         \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(lutgemm_kernel<B>), 160 * 1024)); \
         hipLaunchKernelGGL(lutgemm_kernel<B>, grid, block, smem, st, (const uint16_t *)x, (uint16_t *)out, qweight,      \
                            (const uint16_t *)alpha, (const uint16_t *)q_bias, N, K, (u32)group_size);                    \
     } break;

@@ -1038,11 +1038,7 @@ extern "C" int gq_qtip_matvec(float *out, const uint32_t *compressed, const void
 #define GQ_LAUNCH_QTIP_W(RR, SS, WW)                                                                                  \
     do {                                                                                                              \
         static GqPerDeviceOnce once;                                                                                  \
-        if (once.first_use()) {                                                                                       \
-            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_matvec_kernel<RR, SS, WW>),          \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,                              \
-                                             (int)(QT_LDS - (size_t)QtipTab<SS>::WORDS * 4u - QT_STATIC_SLACK)));     \
-        }                                                                                                             \
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(qtip_matvec_kernel<RR, SS, WW>), (int)(QT_LDS - (size_t)QtipTab<SS>::WORDS * 4u - QT_STATIC_SLACK))); \
         hipLaunchKernelGGL((qtip_matvec_kernel<RR, SS, WW>), grid, block, smem, s, out, compressed, (const uint16_t *)x, \
                            (const uint16_t *)codebook, M, K, g_qdbg);                                                 \
     } while (0)
@@ -1213,11 +1209,7 @@ int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, 
 #define GQ_LAUNCH_QIN_W(RR, PP, SS, WW)                                                                               \
     do {                                                                                                              \
         static GqPerDeviceOnce once;                                                                                  \
-        if (once.first_use()) {                                                                                       \
-            GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_in_kernel<RR, PP, SS, WW>),   \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,                              \
-                                             (int)(QT_LDS - (size_t)QtipTab<SS>::WORDS * 4u - QT_STATIC_SLACK)));     \
-        }                                                                                                             \
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(qtip_linear_in_kernel<RR, PP, SS, WW>), (int)(QT_LDS - (size_t)QtipTab<SS>::WORDS * 4u - QT_STATIC_SLACK))); \
         hipLaunchKernelGGL((qtip_linear_in_kernel<RR, PP, SS, WW>), grid, block, smem, s, a);                         \
     } while (0)
 #define GQ_LAUNCH_QIN(RR, PP, SS)                       \
@@ -1275,10 +1267,7 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
     }
     const size_t smem = (size_t)maxM * 4u;
     static GqPerDeviceOnce once;
-    if (once.first_use()) {
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_linear_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-    }
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(qtip_linear_out_kernel), 160 * 1024));
     hipLaunchKernelGGL(qtip_linear_out_kernel, dim3((u32)n), dim3(1024), smem, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
@@ -1315,10 +1304,7 @@ extern "C" int gq_qtip_transform(int input_side, const void *x, const void *x2, 
     const size_t smem = ((size_t)n + 4u * (size_t)Kf + (size_t)KQ * a.RB * P) * 4u;
     if (smem > 150u * 1024u) return gq_fail(GQ_ENOTSUP, "gq_qtip_transform: n too large.");
     static GqPerDeviceOnce once;
-    if (once.first_use()) {
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qtip_transform_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         156 * 1024));
-    }
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(qtip_transform_kernel), 156 * 1024));
     hipLaunchKernelGGL(qtip_transform_kernel, dim3((Kf + a.RB - 1u) / a.RB, (u32)n_lin), dim3(1024), smem, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
@@ -1331,10 +1317,7 @@ extern "C" int gq_hadamard(const float *x, float *y, uint32_t rows, uint32_t n, 
     const size_t smem = (size_t)n * 4u;
     if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "hadamard: n too large (<= 32768).");
     static GqPerDeviceOnce once;
-    if (once.first_use()) {
-        GQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fwht_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-    }
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(fwht_kernel), 160 * 1024));
     const u32 T = n / 2u >= 1024u ? 1024u : (n / 2u >= 64u ? n / 2u : 64u);
     hipLaunchKernelGGL(fwht_kernel, dim3(rows), dim3(T), smem, (hipStream_t)stream, x, y, n, scale);
     GQ_HIP_CHECK(hipGetLastError());

@@ -91,6 +91,7 @@ class DecodeGraph:
             self._step()
         torch.cuda.synchronize()
         self._bound = self._signature()
+        self._gen = getattr(model, "_alloc_gen", 0)
 
     def _signature(self):
         """what the captured launches point at: the graph bakes in raw pointers (KV caches, RoPE tables, the native step's
@@ -124,7 +125,12 @@ class DecodeGraph:
 
     def step(self, advance=True):
         """replay one token step; by default feeds the sampled token back and advances the position on device"""
-        self.check_bound()
+        # one integer compare per token (the model bumps `_alloc_gen` whenever it re-allocates caches / native buffers); the
+        # pointer-by-pointer comparison runs only after such an event
+        gen = getattr(self.model, "_alloc_gen", 0)
+        if gen != self._gen:
+            self.check_bound()
+            self._gen = gen
         self.graph.replay()
         if advance and not self.native_sampling:
             self.tok.copy_(self.next_tok)

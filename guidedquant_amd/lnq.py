@@ -49,8 +49,11 @@ def _cd_block(W, B, Hn, C, assign, What, group_rows, st, end):
         with torch.cuda.device(W.device):
             rc = _lib.lib().gq_lnq_cd_block(W.data_ptr(), B.data_ptr(), Hn.data_ptr(), C.data_ptr(), assign.data_ptr(), What.data_ptr(), N, d,
                                             C.shape[1], group_rows, st, end, _lib.current_stream_ptr())
-        _lib.check(rc, "gq_lnq_cd_block")
-        return
+        if rc != _lib.GQ_ENOTSUP:
+            _lib.check(rc, "gq_lnq_cd_block")
+            return
+        # shapes the kernel does not serve (rows per Hessian group not a multiple of 32, more than 16 centroids): the same loop
+        # column by column with torch ops ON THE SAME DEVICE (the reference's own formulation, layerwise_quantize.py:93-118)
     G = Hn.shape[0]
     Bb = B[:, st:end].clone()
     Hrow = Hn[:, st:end, st:end].repeat_interleave(group_rows, dim=0) if G > 1 else None
@@ -113,8 +116,8 @@ def update_C(W: torch.Tensor, H: torch.Tensor, labels: torch.Tensor, C: torch.Te
     for a in range(ncl):
         Ma = torch.bmm(masks[a].view(G, group_rows, d), Hd).reshape(N, d)  # row i: sum of the rows of H with label a
         for b in range(ncl):
-            gram[:, a, b] = (Ma * masks[b]).sum(-1).double()
-        rhs[:, a] = (HW * masks[a]).sum(-1).double()
+            gram[:, a, b] = (Ma * masks[b]).sum(-1, dtype=torch.float64)  # d-long reductions accumulate in fp64
+        rhs[:, a] = (HW * masks[a]).sum(-1, dtype=torch.float64)
     gram += lambda_reg * torch.eye(ncl, dtype=torch.float64, device=dev)
     sol = torch.linalg.solve(gram, rhs.unsqueeze(-1)).squeeze(-1)
     if torch.isnan(sol).any():

@@ -269,8 +269,11 @@ def _unpair_on_export(module, state_dict, prefix, local_metadata):
         state_dict[prefix + "lut"] = state_dict[prefix + "lut"][inv].contiguous()
 
 
-def _incoming_is_reference_layout(module, *args, **kwargs):
-    module.gq_row_pairs = False  # load_state_dict brings [w1; w3]; the native state is rebuilt (and re-paired) lazily
+def _incoming_is_reference_layout(module, state_dict, prefix, *args, **kwargs):
+    # load_state_dict brings [w1; w3]; the native state is rebuilt (and re-paired) lazily.  Only when this module's tensors are
+    # actually in the incoming dict: a strict=False load without them leaves the paired rows (and the flag) as they are.
+    if prefix + "qweight" in state_dict or prefix + "lut" in state_dict:
+        module.gq_row_pairs = False
 
 
 class TransformerBlock(nn.Module):
@@ -316,6 +319,7 @@ class Transformer(nn.Module):
     def _reset_native(self):
         self._native = None
         self._native_kind_cache = None
+        self._alloc_gen = getattr(self, "_alloc_gen", 0) + 1  # captured graphs re-validate their pointers (generate.DecodeGraph.step)
 
     @classmethod
     def from_name(cls, dtype, name: str, linear_class=nn.Linear, linear_kwargs=None, halve_layers=False,
@@ -338,8 +342,7 @@ class Transformer(nn.Module):
         self.rope_cos, self.rope_sin = rope_tables(head_dim, max_seq_length, self.config.rope_base, device, dtype,
                                                    rope_scaling=self.config.rope_scaling)
         self.cache_initialized = True
-        self._native = None
-        self._native_kind_cache = None
+        self._reset_native()
 
     def forward(self, idx: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:
         assert self.cache_initialized, "Caches must be initialized first"
@@ -611,6 +614,9 @@ class Transformer(nn.Module):
         c = self.config
         b = self._native_state()
         h, y, qkv, gu, pairs = b["h"], b["y"], b["qkv"], b["gu"], b["pairs"]
+        if pairs:  # a load_state_dict into a sub-module bypasses _reset_native: the rows must still be paired at launch
+            for blk in self.layers[l0:l1]:
+                pair_gate_up_rows_(blk.feed_forward.w1w3)
         ck = _lib.check
         scale = 1.0 / math.sqrt(c.head_dim)
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2  # bytes per batch slot

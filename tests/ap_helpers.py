@@ -19,7 +19,7 @@ def _fast(force_plane=True, local=1):
         _lib.lib().gq_reset_env_cache()
 
 
-def _check_fast(got, x, q, lut, bits, oracle, rows=None, dyn_range_slack=False):
+def _check_fast(got, x, q, lut, bits, oracle, rows=None):
     """Fast (plane-MFMA) mode.  The reference kernel accumulates in fp16 and is itself ~1e-3 (rms, relative) away
     from the exact product, so a kernel that is MORE accurate cannot be elementwise within 1e-3 of it.  What is
     asserted instead, per element:
@@ -29,12 +29,10 @@ def _check_fast(got, x, q, lut, bits, oracle, rows=None, dyn_range_slack=False):
                     ||got - ref|| <= 1.05 * ||fp16(exact) - ref|| (+eps): all of the distance to the reference is
                     the reference's own fp16 accumulation error (anyprec.cu:495-512);
       (c) shapes the fast path does not serve (K % 256 != 0 or K > 32768) fall back to the exact kernels: bit-identical;
-          16384 < K <= 32768 runs as two K-halves chained through the residual epilogue (two fp16 roundings);
-      (d) dyn_range_slack (LNQ-like inputs with massive-activation channels only): the matrix cores align the 128 products of
-        one dot-product group to the largest exponent and keep a window of ~17 bits (measured, tools/
-        plane_dynrange_probe.py -> profiles/r02_plane_dynrange.txt), so the group mates of a channel that is 2^10 .. 2^14
-        times larger lose low bits: the envelope gets + 2^-11 * max|lut_n| * sum over groups of the group max|x|, about one
-        fp16 ulp of the hot activations themselves."""
+          16384 < K <= 32768 runs as two K-halves chained through the residual epilogue (two fp16 roundings).
+    No allowance for the dynamic range of x: elements above 8 x rms are taken out of the MFMA image and multiplied on their
+    own (ap_plane.hip hot_step), so massive-activation channels cost their group mates nothing (round 2 needed a slack term
+    here); test_hot_channels_* pins that against sum|w||x| of the NON-hot elements."""
     if rows is not None:
         q = np.ascontiguousarray(q[:, rows, :])
         lut = lut[rows]
@@ -52,25 +50,22 @@ def _check_fast(got, x, q, lut, bits, oracle, rows=None, dyn_range_slack=False):
     scale = W @ np.abs(np.asarray(x, dtype=np.float64).reshape(-1))
     g = got.astype(np.float64)
     err_exact = np.abs(g - y64)
-    dyn = 0.0
-    if dyn_range_slack:
-        assert K % 1024 == 0
-        ax = np.abs(np.asarray(x, dtype=np.float64).reshape(-1))
-        e = np.arange(K)
-        r = e % 1024
-        t, j = (r % 256) // 8, r % 8
-        gid = (e // 1024) * 8 + ((7 - j) & 3) * 2 + ((t >> 2) & 1)  # plane_core.h locate_x4: (chunk, b, h) = one 128-element MFMA group
-        gmax = np.zeros(K // 128)
-        np.maximum.at(gmax, gid, ax)
-        dyn = 2.0**-11 * np.abs(lut.astype(np.float64)).max(axis=1) * gmax.sum()
-    assert (err_exact <= nround * 2.0**-11 * np.abs(y64) * 1.001 + 1e-5 * scale + dyn + 1e-7).all(), (err_exact / (scale + 1e-30)).max()
+    assert (err_exact <= nround * 2.0**-11 * np.abs(y64) * 1.001 + 1e-5 * scale + 1e-7).all(), (err_exact / (scale + 1e-30)).max()
     e16 = y64.astype(np.float16).astype(np.float64)
     ulp = np.maximum(np.abs(np.spacing(y64.astype(np.float16))).astype(np.float64), 2.0**-24)
-    assert (np.abs(g - ref16) <= np.abs(e16 - ref16) + 2 * nround * ulp + 1e-5 * scale + dyn).all()
-    if not dyn_range_slack:
-        assert np.linalg.norm(g - ref16) <= (1.05 if nround == 1.0 else 1.15) * np.linalg.norm(e16 - ref16) + 1e-6 * np.linalg.norm(scale) + 1e-7
+    assert (np.abs(g - ref16) <= np.abs(e16 - ref16) + 2 * nround * ulp + 1e-5 * scale).all()
+    assert np.linalg.norm(g - ref16) <= (1.05 if nround == 1.0 else 1.15) * np.linalg.norm(e16 - ref16) + 1e-6 * np.linalg.norm(scale) + 1e-7
 
 
+def check_nonhot_accuracy(got, x, hot, q, lut, bits, oracle, tol=2e-5):
+    """|got - exact| in excess of the fp16 output rounding, in units of sum|w||x| over the NON-hot elements (the criterion of
+    tools/plane_dynrange_probe.py): the elements next to a massive channel keep fp32-class accuracy"""
+    y64 = oracle.ap_gemv_f64(x, q, lut, bits)[0]
+    xs = np.abs(np.asarray(x, dtype=np.float64).reshape(-1)).copy()
+    xs[hot] = 0
+    base = np.abs(oracle.ap_dequant(q, lut, bits).astype(np.float64)) @ xs
+    over = np.maximum(np.abs(got.astype(np.float64) - y64) - 2.0**-11 * np.abs(y64) * 1.001, 0)
+    assert (over <= tol * base + 1e-9).all(), (over / (base + 1e-30)).max()
 
 
 # ----------------------------------------------------------------------------- the decode step's element-wise ops, restated
@@ -100,7 +95,7 @@ def lnq_like_layer(N, K, bits, seed, oracle=None):
     """A layer shaped like what LNQ + GuidedQuant emits rather than uniform noise: a skewed code histogram (the inner
     centroids carry most of the mass), per-row centroids spread like a weight row's quantiles with a few rows holding
     outlier centroids 8-40x larger, and a heavy-tailed activation vector (Student-t, plus a handful of massive-activation
-    channels as Llama hidden states have).  Returns (qweight, lut, x)."""
+    channels, 2^10 .. 2^12 times the typical element, as Llama hidden states have).  Returns (qweight, lut, x)."""
     from guidedquant_amd import pack
     rng = np.random.default_rng(seed)
     L = 1 << bits
@@ -116,7 +111,7 @@ def lnq_like_layer(N, K, bits, seed, oracle=None):
     lut = base.astype(np.float16)
     x = rng.standard_t(3, K) * 0.5
     hot = rng.choice(K, 6, replace=False)
-    x[hot] *= rng.uniform(60, 300, 6)
+    x[hot] = np.sign(x[hot]) * 0.5 * 2.0**rng.uniform(10, 12, 6)   # 2^10 .. 2^12 x the typical element (Llama: 2^8 .. 2^11)
     return q, lut, np.clip(x, -6e4, 6e4).astype(np.float16)
 
 

@@ -199,20 +199,66 @@ def test_lnq_like_layers_fast_mode(oracle, bits, N, K, kind):
     # rows: the outlier-centroid rows must be in the sample
     big = np.argsort(-np.abs(lut.astype(np.float32)).max(axis=1))[:24]
     rows = np.unique(np.concatenate([big, _rows(rng, N, 96)]))
-    _check_fast(got, xin, q, lut, bits, oracle, rows=rows, dyn_range_slack=True)
+    _check_fast(got, xin, q, lut, bits, oracle, rows=rows)
     qs, ls = np.ascontiguousarray(q[:, rows, :]), lut[rows]
     ref = oracle.ap_gemv_f16(xin, qs, ls, bits)[0].astype(np.float64)
     y64 = oracle.ap_gemv_f64(xin, qs, ls, bits)[0]
     rel = np.linalg.norm(got[rows].astype(np.float64) - ref) / np.linalg.norm(ref)
     d_ref = np.linalg.norm(y64 - ref) / np.linalg.norm(ref)  # the reference-order kernel's own distance from the exact product
-    # north star: within 1e-3 (relative, norm-wise) of the reference-order result -- unless that result is itself farther
-    # than that from the exact product (heavy-tailed inputs: d_ref up to 1.2e-3 here); never more than the reference's own
-    # distance and the fp16 rounding of the output combined
-    assert rel <= max(1e-3, d_ref * 1.05)
-    assert rel <= np.hypot(d_ref, 5e-4) + 1e-5
-    # against the exact product: the fp16 output rounding (2-3e-4) plus the matrix cores' alignment loss next to the massive
-    # channels (ap_helpers._check_fast (d)); measured 4e-4 .. 7.5e-4 here, the reference-order kernel's own figure is d_ref
-    assert np.linalg.norm(got[rows].astype(np.float64) - y64) / np.linalg.norm(y64) <= 1e-3
+    # north star: within 1e-3 (relative, norm-wise) of the reference-order result -- unless that result is itself about that far
+    # from the exact product (heavy-tailed inputs: d_ref 0.9e-3 .. 1.2e-3 here); never more than the reference's own distance and
+    # the fp16 rounding of the output (asserted <= 4e-4 below) combined
+    assert rel <= max(1e-3, d_ref + 4e-4)  # (triangle inequality)
+    # against the exact product: the fp16 output rounding only (round 2: up to 7.5e-4 from the alignment loss next to the
+    # massive channels, before they were taken out of the MFMA image); the reference-order kernel's own figure is d_ref
+    assert np.linalg.norm(got[rows].astype(np.float64) - y64) / np.linalg.norm(y64) <= 4e-4
+
+
+@pytest.mark.parametrize("local", [1, 0])
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("nhot", [1, 6, 16])
+def test_hot_channels_plain(oracle, bits, nhot, local):
+    """1, 6, 16 channels 2^8 .. 2^14 times the rest (the probe of tools/plane_dynrange_probe.py as a test): the error in excess
+    of the fp16 output rounding stays <= 2e-5 of sum|w||x| over the OTHER elements, on both plane kernels.  (The threshold is 64 x
+    the mean magnitude INCLUDING the hot channels: a channel is extracted once it holds 1 / 64 of the vector's -- in the local-image
+    kernel of its wave's 1024-element chunk's -- total magnitude.)"""
+    from ap_helpers import check_nonhot_accuracy
+    N, K = 256, 4096
+    rng, q, lut = _layer(N, K, bits, 77 + bits)
+    _fast(local=local)
+    for lr in (8, 10, 12, 14):
+        x = rng.normal(0, 1, K)
+        hot = rng.choice(K, nhot, replace=False)
+        if nhot == 6:
+            hot[1] = hot[0] ^ 8   # two extracted elements in the same 128-element MFMA group
+        x[hot] = 2.0**lr * np.sign(x[hot]) * rng.uniform(0.75, 1.0, nhot)
+        x = x.astype(np.float16)
+        got = run_fused(x, q, lut, bits)
+        check_nonhot_accuracy(got, x, hot, q, lut, bits, oracle)
+        _check_fast(got, x, q, lut, bits, oracle)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (1024, 4352), (512, 14336)])
+def test_hot_channels_rmsnorm_and_tails(oracle, bits, N, K):
+    """the same through the RMSNorm prologue (shared-image kernel, threshold from the statistics of the normalised vector), with
+    a 256-weight tail chunk (K = 4352: the virtual-lane geometry of a short chunk), and with the late-wave image helpers (14336)"""
+    from ap_helpers import check_nonhot_accuracy
+    rng, q, lut = _layer(N, K, bits, 5 * bits + K)
+    rows = _rows(rng, N)
+    qs, ls = np.ascontiguousarray(q[:, rows, :]), lut[rows]
+    _fast()
+    for lr in (9, 13):
+        x = rng.normal(0, 1, K)
+        hot = np.concatenate([rng.choice(K, 3, replace=False), [K - 1, K - 250]])
+        x[hot] = 2.0**lr * np.sign(x[hot])
+        x = (x / 64).astype(np.float16)
+        nw = (1 + 0.1 * rng.normal(0, 1, K)).astype(np.float16)
+        got = run_fused(x, q, lut, bits, norm_weight=nw, eps=EPS)[rows]
+        xn = rmsnorm_ref(x, nw, EPS)
+        check_nonhot_accuracy(got, xn, hot, qs, ls, bits, oracle)
+        got = run_fused(x, q, lut, bits)[rows]
+        check_nonhot_accuracy(got, x, hot, qs, ls, bits, oracle)
 
 
 @pytest.mark.parametrize("mode", ["default", "exact"])

@@ -605,7 +605,12 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     float X = 0.f;
     int sb = 127;
     float nscale = 0.f, xmax = 0.f;
-    float mx_lane = 0.f;  // largest element of this lane's statistics pass (before the normalisation)
+    // Who looks for elements above the extraction threshold (hot_step): with the staged copy in LDS and idle late waves, the
+    // first half of the late waves -- their tiles are requested, they only wait for the image: nothing is added to the early
+    // waves' serial chain, where every instruction costs 5-8 cycles; they also take the mean magnitude the threshold needs --;
+    // otherwise the early waves, from their own maxima and one more sum in the statistics pass.
+    constexpr u32 NSC = L >= 2u ? L / 2u : 1u;
+    const bool scan_late = a.rawx && !a.himg && !(HOT_ABL & 2) && !(HOT_ABL & 32);
     if (early) {
     wait_vm<0>();  // the activation loads (an early wave has nothing else in flight)
     // ---------------------------------------------------------------- 1. statistics (+ staging) -> one early-wave barrier
@@ -613,21 +618,17 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // With the LDS staging they are taken in the coalesced (raw) domain, before the copy is written, so the staging
     // barrier is also the statistics barrier; SiLU(gate) * up is applied there too and only the product is staged.
     {
-        // RMSNorm: sum x^2 (ss) and, of v = x * w (fp32 products out of v_dot2 with the other half zeroed: no fp16 overflow): max |v|
-        // and sum |v| (s2); otherwise max |x'| (packed integer maximum of the bit patterns) and sum |x'| of the transformed vector
-        float ss = 0.f, s2 = 0.f, mxf = 0.f;
+        // RMSNorm: sum x^2 (ss) and max |x w| (fp32); otherwise max |x'| (packed integer maximum of the bit patterns)
+        float ss = 0.f, mxf = 0.f;
         us2 mxp = {0, 0};  // |fp16| bit patterns order like unsigned integers
         auto stat = [&](u32 xw, u32 aw) {  // one packed pair of activations (and of norm weights)
             if constexpr (PRO == PRO_RMSNORM) {
-                ss = __builtin_amdgcn_fdot2(u2h2(xw), u2h2(xw), ss, false);
-                const float p = __builtin_amdgcn_fdot2(u2h2(xw), u2h2(aw & 0xFFFFu), 0.f, false);
-                const float q = __builtin_amdgcn_fdot2(u2h2(xw), u2h2(aw & 0xFFFF0000u), 0.f, false);
-                mxf = fmaxf(mxf, fmaxf(fabsf(p), fabsf(q)));
-                if (!(HOT_ABL & 64)) s2 = (s2 + fabsf(p)) + fabsf(q);
+                const float p = h2f(xw & 0xFFFF), q = h2f(xw >> 16);
+                ss += p * p;
+                ss += q * q;
+                mxf = fmaxf(mxf, fmaxf(fabsf(p * h2f(aw & 0xFFFF)), fabsf(q * h2f(aw >> 16))));
             } else {
-                const u32 ab = xw & 0x7FFF7FFFu;
-                mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, ab));
-                if (!(HOT_ABL & 64)) s2 = __builtin_amdgcn_fdot2(u2h2(ab), u2h2(0x3C003C00u), s2, false);
+                mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, xw & 0x7FFF7FFFu));
             }
         };
         if (a.rawx) {
@@ -666,14 +667,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             }
         }
         float mx = PRO == PRO_RMSNORM ? mxf : h2f(max(mxp[0], mxp[1]));
-        mx_lane = mx;
         mx = wave_reduce<true>(mx);
         if constexpr (PRO == PRO_RMSNORM) ss = wave_reduce<false>(ss);
-        if (!(HOT_ABL & 64)) s2 = wave_reduce<false>(s2);
         if (l == 63) {
             red[w] = mx;
             if constexpr (PRO == PRO_RMSNORM) red[16 + w] = ss;
-            if (!(HOT_ABL & 64)) red[50 + w] = s2;
         }
         arrive(ctr + 0, l);
     }
@@ -683,14 +681,78 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     const bool helper = !early && a.himg;
     const u32 vw = early ? w : w - E;
     const u32 n0 = a.himg ? (early ? 0u : NIe) : 0u, n1 = a.himg ? (early ? NIe : (u32)NI) : (u32)NI;
-    // Who looks for elements above the extraction threshold (hot_step): with the staged copy in LDS and idle late waves, the
-    // first half of the late waves (their tiles are requested, they only wait for the image: nothing is added to the early
-    // waves' serial chain, where every instruction costs 5-8 cycles); otherwise the early waves, from their own maxima.
-    constexpr u32 NSC = L >= 2u ? L / 2u : 1u;
-    const bool scan_late = a.rawx && !a.himg && !(HOT_ABL & 2) && !(HOT_ABL & 32);
     const bool scanner = scan_late && !early && w - E < NSC;
     const u32 img_arrivals = (a.himg ? W : E) + (scan_late ? NSC : 0u);
-    if (early || helper || scanner) {
+    // ---- elements above the extraction threshold (see hot_step): scanner waves, or the early waves when there are none.  Needs the
+    // staged copy (without it -- K = 16384 behind RMSNorm -- nothing is extracted: round-2 behaviour there).
+    auto detect = [&]() {
+        const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;  // the staged copy
+        // in the RMSNorm prologue everything up to the rare path works on the products x w BEFORE the normalisation: the common
+        // factor cancels in |x'| > 64 mean|x'|
+        // each detecting wave takes a strided sample of the vector -- K / ND elements, its own mean: no exchange between the waves;
+        // Markov holds per sample
+        const u32 ND = early ? E : NSC;
+        const u32 first = (early ? w : w - E) * 64u + l, stride = ND * 64u;
+        float s1 = 0.f, mine = 0.f;
+        for (u32 idx = first; idx < G.K / 8u; idx += stride) {
+            const u32x4 xv = *reinterpret_cast<const u32x4 *>(rx + 8u * idx);
+            u32x4 wv = xv;
+            if constexpr (PRO == PRO_RMSNORM) wv = *reinterpret_cast<const u32x4 *>(ra + 8u * idx);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float p = fabsf(h2f(xv[k] & 0xFFFF)), q = fabsf(h2f(xv[k] >> 16));
+                if constexpr (PRO == PRO_RMSNORM) p *= fabsf(h2f(wv[k] & 0xFFFF)), q *= fabsf(h2f(wv[k] >> 16));
+                s1 = (s1 + p) + q;
+                mine = fmaxf(mine, fmaxf(p, q));
+            }
+        }
+        s1 = wave_reduce<false>(s1);
+        const float sum1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s1), 63));
+        const float cnt = (float)((G.K + ND - 1u) / ND);  // (>= the sample size: a lower threshold, the bound on the count stands)
+        const float tau_raw = GQ_HOT_T * 1.01f * sum1 * __builtin_amdgcn_rcpf(cnt);
+        if (__builtin_expect(!(mine * 1.002f <= tau_raw), 0)) {
+            // rare: some element of this lane may exceed the threshold (or the vector holds inf / NaN: no threshold then).  The exact
+            // test on the transformed element; what passes is appended to the list and leaves the image once that is complete
+            float ns = 1.f, xm = 0.f;
+#pragma unroll
+            for (u32 i = 0; i < E; i++) xm = fmaxf(xm, red[i]);
+            if constexpr (PRO == PRO_RMSNORM) {  // (the builders' own formulas: identical values)
+                float tot = 0.f;
+#pragma unroll
+                for (u32 i = 0; i < E; i++) tot += red[16 + i];
+                ns = 1.0f / sqrtf(tot / (float)G.K + a.eps);
+                xm = xm * ns * 1.002f;
+            }
+            const float tau_f = tau_raw * ns;
+            const u32 tau = (HOT_ABL & 1) || !(tau_f < 65000.f) ? 0x7C00u : (u32)__builtin_bit_cast(uint16_t, (_Float16)tau_f) + 1u;
+            const uint16_t k16h = pow2_f16(piece_shift(xm));
+            auto consider = [&](u32 xh, u32 wh, u32 key) {  // one element (and its norm weight) as fp16 bits
+                if constexpr (PRO == PRO_RMSNORM) {
+                    const _Float16 hn = (_Float16)gq_pin_f32(h2f((uint16_t)xh) * ns);  // the transform of the image builders
+                    xh = __builtin_bit_cast(uint16_t, (_Float16)(hn * __builtin_bit_cast(_Float16, (uint16_t)wh)));
+                }
+                if ((xh & 0x7FFFu) > tau) hot_append(ctr + 2, hotl, hot_cap, key, (uint16_t)xh, k16h);
+            };
+            if (tau < 0x7C00u) {
+                {
+                    for (u32 idx = first; idx < G.K / 8u; idx += stride) {
+#pragma nounroll
+                        for (u32 j = 0; j < 8; j++) {
+                            const u32 e = 8u * idx + j;
+                            u32 chunk, bb, hh, k;
+                            locate_x4(G, e, chunk, bb, hh, k);
+                            consider(rx[e], PRO == PRO_RMSNORM ? ra[e] : 0u, (chunk << 10) | ((bb * 2u + hh) << 7) | k);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (scanner) {
+        wait_count(ctr + 0, E);
+        if (!(HOT_ABL & 16)) detect();
+        arrive(ctr + 1, l);
+    } else if (early || helper) {
     {
         wait_count(ctr + 0, E);
 #pragma unroll
@@ -702,71 +764,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
             xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
         }
-        if (!(HOT_ABL & 2) && !(HOT_ABL & 16) && (scanner || (!scan_late && early))) {
-            float tot2 = 0.f;
-#pragma unroll
-            for (u32 i = 0; i < E; i++) tot2 += red[50 + i];
-            if constexpr (PRO == PRO_RMSNORM) tot2 *= nscale;
-            const u32 tau = hot_tau_bits(tot2, (float)G.K);
-            const float tauf = h2f((uint16_t)tau);
-            const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;  // the staged copy (rawx)
-            const u32 first = early ? tid : tid - E * 64u, stride = early ? E * 64u : NSC * 64u;  // this lane's 16-byte units of it
-            float mine = mx_lane;
-            if (!early) {  // scanner: the largest of its units (RMSNorm: of the fp16 products x w, as in the statistics pass)
-                us2 m = {0, 0};
-                for (u32 idx = first; idx < G.K / 8u; idx += stride) {
-                    const u32x4 xv = *reinterpret_cast<const u32x4 *>(rx + 8u * idx);
-                    u32x4 wv = xv;
-                    if constexpr (PRO == PRO_RMSNORM) wv = *reinterpret_cast<const u32x4 *>(ra + 8u * idx);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const u32 v = PRO == PRO_RMSNORM ? h22u(u2h2(xv[k]) * u2h2(wv[k])) : xv[k];
-                        m = __builtin_elementwise_max(m, __builtin_bit_cast(us2, v & 0x7FFF7FFFu));
-                    }
-                }
-                mine = h2f(max(m[0], m[1]));
-            }
-            if constexpr (PRO == PRO_RMSNORM) mine = mine * nscale * 1.002f;
-            if (__builtin_expect(tau < 0x7C00u && !(mine <= tauf), 0)) {
-                // rare: some element of this lane exceeds the threshold.  Append it to the list; its pieces leave the image once that
-                // is complete (below)
-                const uint16_t k16h = pow2_f16(piece_shift(xmax));
-                auto consider = [&](u32 xh, u32 wh, u32 key, auto inl) {  // one element (and its norm weight) as fp16 bits
-                    if constexpr (PRO == PRO_RMSNORM) {
-                        const _Float16 hn = (_Float16)gq_pin_f32(h2f((uint16_t)xh) * nscale);  // the transform of the image builders
-                        xh = __builtin_bit_cast(uint16_t, (_Float16)(hn * __builtin_bit_cast(_Float16, (uint16_t)wh)));
-                    }
-                    if ((xh & 0x7FFFu) > tau) {
-                        if constexpr (decltype(inl)::value) hot_append_inl(ctr + 2, hotl, hot_cap, key, (uint16_t)xh, k16h);
-                        else hot_append(ctr + 2, hotl, hot_cap, key, (uint16_t)xh, k16h);
-                    }
-                };
-                if (a.rawx) {
-                    for (u32 idx = first; idx < G.K / 8u; idx += stride) {
-#pragma nounroll
-                        for (u32 j = 0; j < 8; j++) {
-                            const u32 e = 8u * idx + j;
-                            u32 chunk, bb, hh, k;
-                            locate_x4(G, e, chunk, bb, hh, k);
-                            consider(rx[e], PRO == PRO_RMSNORM ? ra[e] : 0u, (chunk << 10) | ((bb * 2u + hh) << 7) | k, std::false_type{});
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (u32 n = 0; n < (u32)NI; n++) {
-                        const u32 chunk = (w >> 1) + n * (E / 2u);
-                        if (chunk >= G.nchunks || pt >= G.tpw(chunk)) continue;
-#pragma unroll
-                        for (u32 c = 0; c < 4; c++)
-#pragma unroll
-                            for (u32 hf = 0; hf < 2; hf++)  // element (c, half): k = 32 g + 8 v + 2 (3 - c) + half
-                                consider((xr[n][c] >> (16u * hf)) & 0xFFFFu, PRO == PRO_RMSNORM ? (ar[n][c] >> (16u * hf)) & 0xFFFFu : 0u,
-                                         (chunk << 10) | ((pb * 2u + ((pt >> 2) & 1u)) << 7) | (32u * (pt >> 3) + 8u * (pt & 3u) + 2u * (3u - c) + hf), std::true_type{});
-                    }
-                }
-            }
-        }
-        if (!scanner)
+        if (!(HOT_ABL & 2) && !scan_late && a.rawx && early) detect();
         if (a.rawx) {
             // the staged copy is complete: gather this thread's items (for SiLU the staged vector is already the product)
             const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;
@@ -785,9 +783,6 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             }
         }
     }
-    if (scanner) {
-        arrive(ctr + 1, l);
-    } else {
     stamp(7);
 
     // ---------------------------------------------------------------- 2. transform, scale, split, scatter
@@ -836,8 +831,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     }
     stamp(1);
     arrive(ctr + 1, l);
-    }
-    }  // image builders, scanners
+    }  // image builders
     wait_count(ctr + 1, img_arrivals);  // the B image is complete
     stamp(2);
 #pragma unroll

@@ -239,10 +239,12 @@ def test_hot_channels_plain(oracle, bits, nhot, local):
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
-@pytest.mark.parametrize("N,K", [(6144, 4096), (1024, 4352), (512, 14336)])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (1024, 4352), (10240, 8192), (512, 14336)])
 def test_hot_channels_rmsnorm_and_tails(oracle, bits, N, K):
-    """the same through the RMSNorm prologue (shared-image kernel, threshold from the statistics of the normalised vector), with
-    a 256-weight tail chunk (K = 4352: the virtual-lane geometry of a short chunk), and with the late-wave image helpers (14336)"""
+    """the same through the RMSNorm prologue (shared-image kernel: the scanner waves take the threshold from the products x w
+    before the normalisation), with a 256-weight tail chunk (K = 4352: the virtual-lane geometry of a short chunk), at the 70B
+    width (8192), and -- plain prologue -- with the late-wave image helpers / one chunk per wave (14336).  K = 14336 is not a
+    model width: behind RMSNorm its staged copy does not fit next to the rings and nothing is extracted (ap_plane.hip `detect`)."""
     from ap_helpers import check_nonhot_accuracy
     rng, q, lut = _layer(N, K, bits, 5 * bits + K)
     rows = _rows(rng, N)
@@ -253,10 +255,11 @@ def test_hot_channels_rmsnorm_and_tails(oracle, bits, N, K):
         hot = np.concatenate([rng.choice(K, 3, replace=False), [K - 1, K - 250]])
         x[hot] = 2.0**lr * np.sign(x[hot])
         x = (x / 64).astype(np.float16)
-        nw = (1 + 0.1 * rng.normal(0, 1, K)).astype(np.float16)
-        got = run_fused(x, q, lut, bits, norm_weight=nw, eps=EPS)[rows]
-        xn = rmsnorm_ref(x, nw, EPS)
-        check_nonhot_accuracy(got, xn, hot, qs, ls, bits, oracle)
+        if K != 14336:
+            nw = (1 + 0.1 * rng.normal(0, 1, K)).astype(np.float16)
+            got = run_fused(x, q, lut, bits, norm_weight=nw, eps=EPS)[rows]
+            xn = rmsnorm_ref(x, nw, EPS)
+            check_nonhot_accuracy(got, xn, hot, qs, ls, bits, oracle)
         got = run_fused(x, q, lut, bits)[rows]
         check_nonhot_accuracy(got, x, hot, qs, ls, bits, oracle)
 

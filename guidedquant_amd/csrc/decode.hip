@@ -5,9 +5,11 @@
 // All entry points read the token id / position from DEVICE memory so a captured hipGraph can be replayed for
 // every token without re-recording.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "gq_internal.h"
+#include "fwht.h"
 
 namespace {
 
@@ -49,10 +51,22 @@ __global__ void embed_kernel(const int *tok, const uint16_t *table, uint16_t *ou
 // token are written to the cache at `pos` (KVCache.update, model.py:69-79) by the first head of each KV group.
 // Scores / softmax / weighted sum run in fp32 from the fp16 operands; the output is rounded to fp16 once.
 constexpr int ATTN_WAVES = 8;  // 8 waves x 4 positions x 4 in flight = 128 positions per pass (HD = 128)
-template <int HD>
+// QT (QTIP models): q / k / v are not read as fp16 vectors but rebuilt from the trellis matvecs' fp32 sums -- the transform-out of
+// BitshiftLinear.forward (inference/lib/codebook/bitshift.py:470: hadamard(y) * m^-1/2 * (SV * 32) -> fp16), i.e. what
+// gq_qtip_linear_out computes in a launch of its own.  A head needs HD of the M outputs of each vector and the Sylvester matrix
+// factors, H_M = H_(M / HD) (x) H_HD: combine the M / HD segments with the signs of the head's row first, then ONE HD-point
+// transform.  (Keeping the order of the full transform -- segment-local stages of ALL segments first, then a tree over the
+// segments: bit-identical -- was built and measured: every head block repeats 7/12 of the whole vector's butterflies with half
+// the threads gq_qtip_linear_out has per vector, 366 vs 385 tokens/s.)
+struct AttnQt {
+    const float *y32[3], *sv32[3];  // q, k, v: sums [parts][M] and SV * 32 [M]
+    u32 M[3], parts[3];
+    float mscale[3];                // (float)M^-1/2
+};
+template <int HD, bool QT>
 __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint16_t *qkv, const int *pos_ptr, const uint16_t *cos_t,
                                                           const uint16_t *sin_t, uint16_t *kc, uint16_t *vc, uint16_t *out,
-                                                          u32 H, u32 Hkv, u32 max_seq, float scale, u32 nsplit, float *ws) {
+                                                          u32 H, u32 Hkv, u32 max_seq, float scale, u32 nsplit, float *ws, AttnQt qt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 NW = ATTN_WAVES;
     float *sc = reinterpret_cast<float *>(smem);  // [2 * NW * 64 / (HD / 8)] running max / sum of the position streams
@@ -66,6 +80,72 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
     const uint16_t *q = qkv + (size_t)h * HD;
     const uint16_t *k = qkv + (size_t)H * HD + (size_t)g * HD;
     const uint16_t *v = qkv + (size_t)(H + Hkv) * HD + (size_t)g * HD;
+    if constexpr (QT) {
+        // LDS behind the attention's own arrays: 3 x HD floats (the combined segments), then 3 x HD fp16 results
+        float *tv = red2 + (size_t)NW * (64u / (HD / 8u)) * HD;
+        uint16_t *res16 = reinterpret_cast<uint16_t *>(tv + 3 * HD);
+        // H_M = H_(M / HD) (x) H_HD: the HD outputs of segment `seg` are the HD-point transform of  z[b] = sum_c s(c) y[c HD + b],
+        // s(c) = (-1)^popcount(c & seg)  (row `seg` of the M / HD-point Sylvester matrix): 4096 signed additions and ONE short
+        // transform instead of the whole vector's butterflies.  The additions are those of the full transform in another order
+        // (segments first): the result equals gq_qtip_linear_out's up to fp32 rounding, not bit for bit.
+        // every thread takes 16-byte units of the three vectors (all loads of a thread in flight together: one round trip to L2):
+        // unit u of a vector = segment c = u / (HD / 4), elements 4 (u % (HD / 4)) ..; a thread's units of one vector share the
+        // element group (T is a multiple of HD / 4), so it keeps one signed partial sum per vector; the T / (HD / 4) partial sums
+        // of an element are added in a fixed order behind the barrier
+        {
+            constexpr u32 Q = HD / 4u;
+            const u32 T = blockDim.x, G = T / Q;  // G thread groups per element group
+            float *ps = tv + 3 * HD + 3 * HD / 2;  // [3][G][HD] partial sums (behind the fp16 results)
+            float4 y[3][4];
+            u32 cnt[3];
+#pragma unroll
+            for (u32 vi = 0; vi < 3; vi++) {
+                const u32 M4 = qt.M[vi] / 4u;
+                cnt[vi] = 0;
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    const u32 u = tid + k * T;
+                    y[vi][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (u < M4) {
+                        float4 t = reinterpret_cast<const float4 *>(qt.y32[vi])[u];
+                        for (u32 p = 1; p < qt.parts[vi]; p++) {  // split-K parts, ascending
+                            const float4 t2 = reinterpret_cast<const float4 *>(qt.y32[vi])[(size_t)p * M4 + u];
+                            t = make_float4(t.x + t2.x, t.y + t2.y, t.z + t2.z, t.w + t2.w);
+                        }
+                        y[vi][k] = t;
+                    }
+                }
+            }
+#pragma unroll
+            for (u32 vi = 0; vi < 3; vi++) {
+                const u32 seg = vi == 0u ? h : g;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    const u32 c = (tid + k * T) / Q;
+                    const float sg = (__builtin_popcount(c & seg) & 1) ? -1.f : 1.f;  // (units past the vector hold zeros)
+                    acc = make_float4(acc.x + sg * y[vi][k].x, acc.y + sg * y[vi][k].y, acc.z + sg * y[vi][k].z, acc.w + sg * y[vi][k].w);
+                }
+                reinterpret_cast<float4 *>(ps + ((size_t)vi * G + tid / Q) * HD)[tid % Q] = acc;
+            }
+            __syncthreads();
+            if (tid < 3u * HD) {
+                const u32 vi = tid / HD, b = tid % HD;
+                float z = 0.f;
+                for (u32 gi = 0; gi < G; gi++) z += ps[((size_t)vi * G + gi) * HD + b];
+                tv[tid] = z;
+            }
+        }
+        __syncthreads();
+        gq_fwht::fwht_lds(tv, 3u * HD, (u32)HD);  // the three HD-point transforms (barrier behind)
+        if (tid < 3u * HD) {
+            const u32 vi = tid / HD, b = tid % HD, seg = vi == 0u ? h : g;
+            const h16 o = (h16)gq_pin_f32((tv[tid] * qt.mscale[vi]) * qt.sv32[vi][(size_t)seg * HD + b]);
+            res16[tid] = h2u(o);
+        }
+        __syncthreads();
+        q = res16, k = res16 + HD, v = res16 + 2 * HD;
+    }
     // q / k / v do not depend on the position: their loads are issued before the position is read, so the two
     // dependent round trips (position -> cos / sin rows) overlap with them
     uint16_t qd_b = 0, kd_b = 0, qr_b = 0, kr_b = 0, vd_b = 0;
@@ -490,34 +570,67 @@ extern "C" int gq_embed_lookup(const int *token, const void *table, void *out, u
     return GQ_OK;
 }
 
-extern "C" int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
-                                    void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
-                                    float scale, uint32_t n_split, float *workspace, void *stream) {
-    if (!qkv || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
+namespace {
+template <bool QT>
+int attn_launch(const void *qkv, const AttnQt &qt, const int *pos, const void *cos_table, const void *sin_table, void *k_cache, void *v_cache,
+                void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, float scale, uint32_t n_split,
+                float *workspace, void *stream) {
+    if ((!QT && !qkv) || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (n_kv_head == 0 || n_head % n_kv_head) return gq_fail(GQ_EINVAL, "n_head must be a multiple of n_kv_head.");
     if (head_dim != 64 && head_dim != 128) return gq_fail(GQ_ENOTSUP, "head_dim must be 64 or 128.");
     if (n_split < 1u || n_split > 64u || (n_split > 1u && !workspace)) return gq_fail(GQ_EINVAL, "n_split in 1..64, with a workspace when > 1.");
     const u32 nstreams = (u32)ATTN_WAVES * 64u / (head_dim / 8u);
-    const size_t smem = ((size_t)2u * nstreams + 7u * head_dim + 2u * ATTN_WAVES + 16u + (size_t)nstreams * head_dim) * 4u;
+    size_t smem = ((size_t)2u * nstreams + 7u * head_dim + 2u * ATTN_WAVES + 16u + (size_t)nstreams * head_dim) * 4u;
+    if (QT) smem += 3u * (size_t)head_dim * 4u + 3u * head_dim * 2u + 3u * (size_t)(64u * ATTN_WAVES / (head_dim / 4u)) * head_dim * 4u;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(n_head, n_split);
     if (head_dim == 128) {
         static GqPerDeviceOnce once;
-        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_decode_kernel<128>), 160 * 1024));
-        hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_decode_kernel<128, QT>), 160 * 1024));
+        hipLaunchKernelGGL((attn_decode_kernel<128, QT>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
-                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
+                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace, qt);
         if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(n_head), dim3(128), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
     } else {
         static GqPerDeviceOnce once;
-        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_decode_kernel<64>), 160 * 1024));
-        hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_decode_kernel<64, QT>), 160 * 1024));
+        hipLaunchKernelGGL((attn_decode_kernel<64, QT>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)qkv, pos,
                            (const uint16_t *)cos_table, (const uint16_t *)sin_table, (uint16_t *)k_cache, (uint16_t *)v_cache,
-                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
+                           (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace, qt);
         if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(n_head), dim3(64), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
     }
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
+}
+}  // namespace
+
+extern "C" int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                                    void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                                    float scale, uint32_t n_split, float *workspace, void *stream) {
+    return attn_launch<false>(qkv, AttnQt{}, pos, cos_table, sin_table, k_cache, v_cache, out, n_head, n_kv_head, head_dim, max_seq, scale, n_split,
+                              workspace, stream);
+}
+
+// QTIP models: the same attention with the transform-out of the q, k and v linears folded in (qkv_lin[0..2]: the GqQtipOut
+// descriptors gq_qtip_linear_out would take; resid / out unused).  Bit-identical to gq_qtip_linear_out + gq_attn_decode_split.
+extern "C" int gq_attn_decode_qtip(const GqQtipOut *qkv_lin, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                                   void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                                   float scale, uint32_t n_split, float *workspace, void *stream) {
+    if (!qkv_lin) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    AttnQt qt{};
+    for (int i = 0; i < 3; i++) {
+        const uint32_t want = (i == 0 ? n_head : n_kv_head) * head_dim, M = qkv_lin[i].M;
+        if (M != want || (M & (M - 1u)) || !qkv_lin[i].y32 || !qkv_lin[i].SV32 || (((uintptr_t)qkv_lin[i].y32 | (uintptr_t)qkv_lin[i].SV32) & 15u) ||
+            qkv_lin[i].parts > 4u || M > 16u * 64u * ATTN_WAVES)
+            return gq_fail(GQ_ENOTSUP, "gq_attn_decode_qtip: q / k / v widths must be n_head (n_kv_head) * head_dim, powers of two, 16-byte aligned sums.");
+        qt.y32[i] = qkv_lin[i].y32;
+        qt.sv32[i] = qkv_lin[i].SV32;
+        qt.M[i] = M;
+        qt.parts[i] = qkv_lin[i].parts ? qkv_lin[i].parts : 1u;
+        qt.mscale[i] = (float)pow((double)M, -0.5);
+    }
+    return attn_launch<true>(nullptr, qt, pos, cos_table, sin_table, k_cache, v_cache, out, n_head, n_kv_head, head_dim, max_seq, scale, n_split,
+                             workspace, stream);
 }
 
 extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,

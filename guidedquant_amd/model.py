@@ -461,7 +461,7 @@ class Transformer(nn.Module):
 
         y32, xs16 = st["y32"], st["xs16"]
 
-        def group(mods, xp, x2p, normw, pro, outs, resid, prev=None, defer=None):
+        def group(mods, xp, x2p, normw, pro, outs, resid, prev=None, defer=None, out_to=None):
             """launches of one group: mods share the input vector xp (x2p for silu*mul); outs[i] fp16 destinations.
             prev: GqQtipOut of the linear that PRODUCES xp, its transform-out folded into this group's first launch (which then
             stores xp itself); defer = row of y32: this group's own transform-out is left to the consumer (-> returned descriptor)"""
@@ -503,6 +503,14 @@ class Transformer(nn.Module):
                 keep.extend([fin, ctr])
                 plan.append(("gq_qtip_linear", args[:9] + (fin, ks, ctr.data_ptr())))
                 return plan
+            if out_to is not None and not fac:
+                # the consumer rebuilds the outputs itself (q / k / v: gq_attn_decode_qtip, the transform-out inside the attention
+                # launch): descriptors instead of the gq_qtip_linear_out launch
+                arr = (_lib.GqQtipOut * len(mods))(*[_lib.GqQtipOut(ysl[i].data_ptr(), f32(mods[i].SV, 32.0), None, outs[i], mods[i].out_features, ks)
+                                                     for i in range(len(mods))])
+                keep.append(arr)
+                out_to.append(arr)
+                return plan
             if defer is not None:  # (a single linear with a power-of-two output width)
                 desc = _lib.GqQtipOut(ysl[0].data_ptr(), f32(mods[0].SV, 32.0), resid, outs[0], mods[0].out_features, ks)
                 arr = (_lib.GqQtipOut * 1)(desc)
@@ -534,6 +542,10 @@ class Transformer(nn.Module):
         # acquire fences around the per-linear counter (L2 write-back + invalidate on 8 XCDs) cost ~7 us per launch, more than the
         # launch they save.
         one_launch = os.environ.get("GQ_QTIP_ONE_LAUNCH", "0") != "0"
+        # GQ_QTIP_ATTN_FOLD (default ON): the transform-out of q / k / v runs inside the attention launch -- every head block needs
+        # head_dim of the outputs: the segments combined with the signs of its row, then one head_dim-point transform (equal to
+        # gq_qtip_linear_out up to fp32 rounding) --: one launch (4.8 us) per layer less.  Needs power-of-two q / k / v widths.
+        attn_fold = os.environ.get("GQ_QTIP_ATTN_FOLD", "1") != "0" and not one_launch and c.head_dim in (64, 128)
         layers = []
         prev_down = None
         for b in self.layers:
@@ -541,10 +553,15 @@ class Transformer(nn.Module):
             qkv_outs = [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e]
             can_o = fold and at.wo.K_right == 1 and ff.w1.K_left == 1
             can_d = fold and ff.w2.K_right == 1 and at.wq.K_left == 1
-            d = dict(qkv=group([at.wq, at.wk, at.wv], x.data_ptr(), None, b.input_layernorm.weight.data_ptr(), 1, qkv_outs, None))
+        
+            fold_here = attn_fold and all(m.K_right == 1 for m in (at.wq, at.wk, at.wv))
+            desc = [] if fold_here else None
+            d = dict(qkv=group([at.wq, at.wk, at.wv], x.data_ptr(), None, b.input_layernorm.weight.data_ptr(), 1, qkv_outs, None, out_to=desc))
             # (q / k / v of this layer with the previous layer's down folded in; the first layer of a range takes the plain form)
-            d["qkv_f"] = group([at.wq, at.wk, at.wv], None, None, b.input_layernorm.weight.data_ptr(), 1, qkv_outs, None, prev=prev_down) \
+            desc_f = [] if fold_here else None
+            d["qkv_f"] = group([at.wq, at.wk, at.wv], None, None, b.input_layernorm.weight.data_ptr(), 1, qkv_outs, None, prev=prev_down, out_to=desc_f) \
                 if prev_down is not None else None
+            d["attn_qt"] = desc[0] if fold_here else None
             if can_o:
                 d["o"], desc_o, _ = group([at.wo], y.data_ptr(), None, None, 0, [h.data_ptr()], x.data_ptr(), defer=3)
                 d["gu"] = group([ff.w1, ff.w3], None, None, b.post_attention_layernorm.weight.data_ptr(), 1,
@@ -589,10 +606,16 @@ class Transformer(nn.Module):
                 if pending is not None:
                     run(pending)
                 run(d["qkv"])
-            ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
-                                      at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
-                                      y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
-                                      b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, sp), "attn")
+            if d["attn_qt"] is not None:
+                ck(L.gq_attn_decode_qtip(d["attn_qt"], pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
+                                         at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
+                                         y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
+                                         b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, sp), "attn_qtip")
+            else:
+                ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
+                                          at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
+                                          y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
+                                          b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, sp), "attn")
             run(d["o"])
             run(d["gu"])
             run(d["d"])

@@ -231,6 +231,20 @@ int gq_qtip_transform(int input_side, const void *x, const void *x2, const void 
                       int n_lin, const GqQtipXf *lin, uint32_t n, uint32_t Kf, int transpose, void *stream);
 
 /*
+ * Single-query attention of a QTIP model with the transform-out of its q, k and v linears folded in: qkv_lin[0..2] are the
+ * descriptors gq_qtip_linear_out would take (y32 sums, SV32, M, parts; resid / out are ignored), every other argument as in
+ * gq_attn_decode_split (declared below).  Each head rebuilds its head_dim outputs of q (its KV group's of k and v): the
+ * M / head_dim segments of the sums combined with the signs of the head's row of the Sylvester matrix, then one
+ * head_dim-point transform, * M^-1/2 * SV32 -> fp16 (inference/lib/codebook/bitshift.py:470, inference/model.py:206-241).
+ * The additions of the full transform in another order: equal to gq_qtip_linear_out + gq_attn_decode_split up to fp32
+ * rounding (not bit for bit), one launch per layer less.  M[0] = n_head * head_dim, M[1] = M[2] = n_kv_head * head_dim,
+ * powers of two (GQ_ENOTSUP else).
+ */
+int gq_attn_decode_qtip(const GqQtipOut *qkv_lin, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
+                        void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                        float scale, uint32_t n_split, float *workspace, void *stream);
+
+/*
  * Fused decode-step variant of the AP GEMV, M = 1: optional prologue on x
  * (RMSNorm, or SiLU(gate)*up of a fused gate/up vector) and optional residual-add epilogue, with the same
  * fp16 rounding points as the reference's separate kernels (inference/model.py:151-166,259-266,281-292).

@@ -341,6 +341,47 @@ def test_qtip_native_decode_matches_module_forward():
             assert int(got.argmax()) == int(ref[p].argmax()) or err < 5e-3
 
 
+@pytest.mark.parametrize("heads", [(8, 4, 1024), (32, 32, 4096), (16, 2, 2048)])
+def test_attention_with_the_qkv_transform_out_folded_in(monkeypatch, heads):
+    """gq_attn_decode_qtip (the transform-out of q / k / v inside the attention launch: per head, the segments of the sums combined
+    with the signs of its row of the Sylvester matrix, then one head_dim-point transform) against gq_qtip_linear_out +
+    gq_attn_decode_split: the same additions in another order -- rotated keys and logits of a decode step agree to fp32 / fp16
+    rounding noise; MHA (Llama-2-7b head layout), GQA, several positions"""
+    from guidedquant_amd import model as gm
+    from guidedquant_amd.generate import load_model
+    H, Hkv, dim = heads
+    gm.transformer_configs["qtip-fold-test"] = dict(model_name="llama-qtip-fold-test", block_size=128, vocab_size=512, n_layer=2,
+                                                    n_head=H, dim=dim, intermediate_size=2048, n_local_heads=Hkv)
+    outs = {}
+    try:
+        for fold in ("1", "0"):
+            monkeypatch.setenv("GQ_QTIP_ATTN_FOLD", fold)
+            torch.manual_seed(7)
+            m = load_model("qtip-fold-test", "cuda:0", "qtip", 2, random_init=True)
+            with torch.device("cuda:0"):
+                m.setup_caches(max_batch_size=1, max_seq_length=64)
+            st = m._native_state()
+            assert (st["qtip_layers"][0]["attn_qt"] is not None) == (fold == "1")
+            res = []
+            for p, t in enumerate([1, 17, 200, 5, 9]):
+                got = m.decode_native(torch.tensor([t], dtype=torch.int32, device="cuda:0"), torch.tensor([p], dtype=torch.int32, device="cuda:0"))
+                torch.cuda.synchronize()
+                res.append(got.reshape(-1).clone())
+                res.append(m.layers[1].attention.kv_cache.k_cache[0, :, p].reshape(-1).clone())
+            outs[fold] = res
+            del m
+    finally:
+        del gm.transformer_configs["qtip-fold-test"]
+    for i, (a, b) in enumerate(zip(outs["1"], outs["0"])):
+        a, b = a.float(), b.float()
+        assert bool(torch.isfinite(a).all())
+        # keys: fp16 values from fp32 sums that differ in the last bits -- a one-ulp flip here and there; logits: fp16 noise on top
+        tol = 2e-3 if i % 2 else 1e-2
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6, (i, float((a - b).abs().max()), float(b.abs().max()))
+        if i % 2 == 0:
+            assert int(a.argmax()) == int(b.argmax())
+
+
 # ----------------------------------------------------------------------------- widths with a Hadamard factor (gq_qtip_transform)
 @pytest.mark.parametrize("name", ["had_n11008", "had_n14336"])
 def test_factor_transform_goldens(name):

@@ -821,13 +821,14 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
                     if (p < 3) rem = rem - u2h2(P[p][c]);
                 }
             }
-            unsigned char *img = bimg + bimg4_off(chunk, pb, hh, 0u) + 32u * g + 8u * vA;
+            unsigned char *img = bimg + bimg4_off(chunk, pb, hh, 0u) + 8u * vA;
 #pragma unroll
             for (u32 p = 0; p < 4; p++) {
                 // k = 32g + 8v + i, nibble i = 2 (3 - c) + (s >> 2): bytes (i = 0..3) = c3.j(7-b), c3.j(3-b), c2.j(7-b), c2.j(3-b);
                 // the bf8 of weight 7 - b is byte 1 of P (low half), of weight 3 - b byte 3 (high half)
-                *reinterpret_cast<u32 *>(img + p * 128u) = __builtin_amdgcn_perm(P[p][2], P[p][3], 0x07050301u);
-                *reinterpret_cast<u32 *>(img + p * 128u + 4u) = __builtin_amdgcn_perm(P[p][0], P[p][1], 0x07050301u);
+                // (pieces 2, 3 keep byte k at k ^ 32: see bimg_swz)
+                *reinterpret_cast<u32 *>(img + p * 128u + ((32u * g) ^ bimg_swz(p))) = __builtin_amdgcn_perm(P[p][2], P[p][3], 0x07050301u);
+                *reinterpret_cast<u32 *>(img + p * 128u + ((32u * g) ^ bimg_swz(p)) + 4u) = __builtin_amdgcn_perm(P[p][0], P[p][1], 0x07050301u);
             }
         }
         xsum = wave_reduce<false>(xsum);
@@ -853,7 +854,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         // leave the image -- byte k of their (chunk, b, h) block in each of the 4 piece columns --, one more barrier
         for (u32 e = tid; e < 4u * nhot; e += T) {
             const u32 key = hotl[e >> 2].key;
-            bimg[(key >> 10) * 4096u + ((key >> 7) & 7u) * 512u + (e & 3u) * 128u + (key & 127u)] = 0;
+            bimg[(key >> 10) * 4096u + ((key >> 7) & 7u) * 512u + (e & 3u) * 128u + ((key & 127u) ^ bimg_swz(e & 3u))] = 0;
         }
         arrive(ctr + 3, l);
         wait_count(ctr + 3, W);
@@ -883,7 +884,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         }
         if (++cq_slot == S) cq_slot = 0;
         if (chunk < G.nchunks && !(a.xflags & 1u)) {
-            const unsigned char *bbase = bcol ? bimg + bimg4_off(chunk, 0u, 0u, col) + 16u * kb : zero32;
+            const unsigned char *bbase = bcol ? bimg + bimg4_off(chunk, 0u, 0u, col) + ((16u * kb) ^ bimg_swz(col)) : zero32;
             // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
             mfma_chunk<BITS>(acc, Wd, bbase, bcol ? 512u : 0u, bcol ? 64u : 0u, sb);
             if (!(HOT_ABL & 4) && __builtin_expect(nhot != 0u, 0)) hot_step<BITS>(acc, Wd, hotl, nhot, chunk, sb, col, kb);
@@ -1131,14 +1132,15 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
                 if (u >= 4u * tp) continue;
                 // weight j has plane bit s = 7 - j: nibble bit b = s & 3, nibble i = 2 (3 - c) + (s >> 2), k = 32 g + 8 v + i.
                 // For b: the bytes at i = 2(3-c), 2(3-c)+1 are j = 7 - b (byte 1 or 3 of word (7-b)/2) and j = 3 - b.
-                unsigned char *dst = img + n * 4096u + (((t >> 2) & 1u) << 9) + 32u * (t >> 3) + 8u * (t & 3u) + 2u * (3u - c);
+                unsigned char *dst = img + n * 4096u + (((t >> 2) & 1u) << 9) + 8u * (t & 3u) + 2u * (3u - c);
 #pragma unroll
                 for (u32 p = 0; p < 4; p++) {
                     // b = 0: j = 7, 3 (byte 3 of words 3, 1); b = 1: j = 6, 2 (byte 1 of words 3, 1)
                     const u32 v01 = __builtin_amdgcn_perm(P[p][1], P[p][3], 0x05010703u);  // lo half: b = 0, hi half: b = 1
                     // b = 2: j = 5, 1 (byte 3 of words 2, 0); b = 3: j = 4, 0 (byte 1 of words 2, 0)
                     const u32 v23 = __builtin_amdgcn_perm(P[p][0], P[p][2], 0x05010703u);
-                    unsigned char *d = dst + p * 128u;  // (b, h) blocks are 4 pieces * 128 B = 512 B apart, b major: b * 1024 + h * 512
+                    // (b, h) blocks are 4 pieces * 128 B = 512 B apart, b major: b * 1024 + h * 512; pieces 2, 3 keep byte k at k ^ 32
+                    unsigned char *d = dst + p * 128u + ((32u * (t >> 3)) ^ bimg_swz(p));
                     *reinterpret_cast<uint16_t *>(d) = (uint16_t)v01;
                     *reinterpret_cast<uint16_t *>(d + 1024u) = (uint16_t)(v01 >> 16);
                     *reinterpret_cast<uint16_t *>(d + 2048u) = (uint16_t)v23;
@@ -1153,7 +1155,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
             if (n >= cpi || chunk >= G.nchunks || G.tpw(chunk) == 32u) continue;
             const u32 tp = G.tpw(chunk);
             for (u32 o = l; o < 1024u; o += 64u) {  // dword o of the chunk image: block o / 32, k = 4 (o % 32) -> t = 8 (k/32) + 4 h + (k%32)/8
-                const u32 blk = o >> 5, k4 = (o & 31u) * 4u, hh = (blk >> 2) & 1u;
+                const u32 blk = o >> 5, k4 = ((o & 31u) * 4u) ^ bimg_swz(blk & 3u), hh = (blk >> 2) & 1u;  // (logical k of the stored position)
                 const u32 t = 8u * (k4 >> 5) + 4u * hh + ((k4 & 31u) >> 3);
                 if (t >= tp) reinterpret_cast<u32 *>(img + n * 4096u)[o] = 0u;
             }
@@ -1176,7 +1178,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     // ---- 2. the steps of this wave
     const u32 r = l & 15u, kb = l >> 4, col = l & 15u;
     const u32 offA0 = atile_unit(r, 2u * kb) * 16u, offA1 = atile_unit(r, 2u * kb + 1u) * 16u;
-    const unsigned char *blane = img + ((col & 3u) << 7) + 16u * kb;  // columns 4..15 repeat 0..3 (their sums are never read)
+    const unsigned char *blane = img + ((col & 3u) << 7) + ((16u * kb) ^ bimg_swz(col & 3u));  // columns 4..15 repeat 0..3 (their sums are never read)
     v4f acc[NP1];
 #pragma unroll
     for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};

@@ -60,6 +60,12 @@ GQP_HD int scale_byte4(int b) { return b == 0 ? 128 : (b == 1 ? 127 : 126); }
 // B image: [chunk][b][h][piece][k = 0..127] bytes, k = 32 g + 8 v + i; lane (col = piece, kb) of the MFMA reads the 16
 // bytes at 16 kb and the 16 bytes at 64 + 16 kb.
 GQP_HD u32 bimg4_off(u32 chunk, u32 b, u32 h, u32 piece) { return chunk * 4096u + (((b * 2u + h) * 4u + piece) << 7); }
+// Bank swizzle of the image: the 4 piece rows of a (b, h) block are 128 B apart, so the MFMA lanes of one ds_read_b128 lane
+// group -- pieces 0..3 at the same 16-byte unit kb -- would hit pieces 0 / 2 and 1 / 3 in the same banks (64 banks x 4 B = 256 B:
+// measured 40 % of the LDS cycles of the 2-bit w1w3 kernel as bank conflicts).  Pieces 2 and 3 therefore keep byte k at
+// k ^ 32 (16-byte unit kb ^ 2): units {0, 8, 2, 10} of the 16 per bank row.  Writers, the clearing of extracted / tail
+// elements and the readers apply the same XOR; the lane still receives the bytes of ITS k range.
+GQP_HD u32 bimg_swz(u32 piece) { return (piece & 2u) << 4; }
 // activation e -> chunk, b, h, k  (inverse of the above)
 GQP_HD void locate_x4(const Geom &G, u32 e, u32 &chunk, u32 &b, u32 &h, u32 &k) {
     u32 r, tp;

@@ -26,7 +26,7 @@ Output: ONE JSON line on rank 0 (schema in the task contract) with
   `roofline`           dominant quantized kernel (the w1w3 AP-GEMV exactly as the decode graph launches it: RMSNorm prologue,
                        gate/up pair epilogue), algorithmic bytes B_ap / average launch duration, HIP events on the launch stream
                        over all layers' distinct weights; `traffic` = HBM bytes per launch from the committed PMC passes of
-                       the SAME kernel template and mode (profiles/r02_w1w3_traffic.json), else null
+                       the SAME kernel template and mode (profiles/r03_w1w3_traffic.json), else null
   `roofline_by_shape`  the four Llama-3-8B GEMV shapes x 2/3/4 bits (BASELINE.json metric: "+3/4-bit sweep"), default dispatch
   `exact_mode_tok_s`   the same decode with every quantized GEMV in the bit-exact (reference fp16 order) mode
   `cpu_baseline`       oracle ports timed on the host cores on a bounded sample (N = 1 only)
@@ -346,12 +346,12 @@ def ap_roofline(model, bits, mode_arg):
     # HBM bytes per launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
     # tools/prof_bench.sh) for one kernel template, launch form and shape -- reported only when this run launches the same
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_w1w3_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_w1w3_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             t = json.load(f)
         if (not exact and t.get("bits") == bits and t.get("N") == 2 * I and t.get("K") == D and t.get("launch") == ("norm_pairs" if paired else "norm")):
-            traffic, traffic_src = t.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/r02_w1w3_traffic.json)" % t.get("kernel")
+            traffic, traffic_src = t.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/r03_w1w3_traffic.json)" % t.get("kernel")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "AP-GEMV w1w3 %dx%d %d-bit, RMSNorm prologue%s (%s kernels)" % (2 * I, D, bits, " + gate/up pair epilogue" if paired else "",
@@ -380,9 +380,17 @@ def qtip_roofline(cfg, R, shape=None):
 
     us = graph_time_us(run, n, 100)
     gbs = b_qtip(R, M, K) / us / 1e3
+    # HBM bytes per launch from the PMC counters: offline --pmc passes of the same kernel / shape (tools/prof_qtip_traffic.sh)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r03_qtip_matvec_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            t = json.load(f)
+        if t.get("M") == M and t.get("K") == K and t.get("R") == R:
+            traffic, traffic_src = t.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/r03_qtip_matvec_traffic.json)" % t.get("kernel")
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBPS, 4),
-            "traffic": None, "kernel": "QTIP trellis matvec %dx%d R=%d (gq_qtip_matvec)" % (M, K, R), "avg_launch_us": round(us, 3),
-            "algorithmic_bytes_per_launch": b_qtip(R, M, K)}
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": "QTIP trellis matvec %dx%d R=%d (gq_qtip_matvec)" % (M, K, R),
+            "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": b_qtip(R, M, K)}
 
 
 # ---------------------------------------------------------------------------------------------------------- other configs

@@ -34,6 +34,8 @@ def main():
     st = _lib.current_stream_ptr
     tl = (torch.randn(1024, device=d) * 0.5).half()
     shapes = ((4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096))
+    if os.environ.get("MV_SHAPE"):  # one shape only, "MxK" (PMC passes: every dispatch of the kernel is the same launch)
+        shapes = (tuple(int(v) for v in os.environ["MV_SHAPE"].split("x")),)
     for M, K in (shapes[:3] if os.environ.get("MV_ONLY") else shapes):
         per = R * M * K // 8
         n = max(2, min(64, (512 << 20) // per))

@@ -51,6 +51,7 @@ struct PlaneArgs {
     u32 rawx;    // the activations are staged through LDS (coalesced 16-byte loads into the early waves' still unused ring slots)
     u32 himg;    // the late waves build the second half of the image passes (needs rawx; they have little to request)
     u32 pairs;   // GQ_EPI_SILU_PAIRS: rows are (gate, up) pairs, out[i] = silu(y[2i]) * y[2i+1]
+    u32 MB, M;   // batch rows per block (one-pass multi-row kernel instances; else 1) and in total
     u32 xflags;  // ablation experiments (GQ_PL_XFLAGS): 1 no MFMA work, 2 no steps at all, 8 no activation loads, 16 no LUT, 32 empty kernel,
                  // 256 late waves request only their first item up front, 1024 no plane loads (the MFMA phase runs on stale LDS)
     float eps;
@@ -251,7 +252,7 @@ __device__ __forceinline__ void mfma_chunk(v4f (&acc)[(1 << BITS) - 1], const u3
 // threshold; 64 x the mean (51 sigma of a Gaussian) is far outside what SiLU(gate) * up or normalised hidden states produce by
 // chance, and what stays in the image (<= 2^6 x the typical element) is below the ratio where the window starts to matter -- costs the early
 // waves one more sum in the statistics pass and every wave one scalar compare per step.
-//   entry = {key = chunk << 10 | (b * 2 + h) << 7 | k,  the 4 bf8 pieces of x * 2^ksh (byte p = piece p)}
+//   entry = {key = row << 16 | chunk << 10 | (b * 2 + h) << 7 | k,  the 4 bf8 pieces of x * 2^ksh (byte p = piece p)}
 struct HotEnt {
     u32 key, pieces;
 };
@@ -284,7 +285,7 @@ __device__ __forceinline__ void hot_step(v4f (&acc)[(1 << BITS) - 1], const u32 
     u32 mask = 0;
     for (u32 e = 0; e < nhot; e++) {
         const u32 key = __builtin_amdgcn_readfirstlane(list[e].key);
-        if ((key >> 10) == ckey) mask |= 1u << ((key >> 7) & 7u);
+        if (((key >> 10) & 63u) == ckey) mask |= 1u << ((key >> 7) & 7u);
     }
     while (mask) {
         const u32 bh = (u32)__builtin_ctz(mask);
@@ -292,11 +293,11 @@ __device__ __forceinline__ void hot_step(v4f (&acc)[(1 << BITS) - 1], const u32 
         u32 B[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         for (u32 e = 0; e < nhot; e++) {
             const u32 key = __builtin_amdgcn_readfirstlane(list[e].key);
-            if ((key >> 7) != ((ckey << 3) | bh)) continue;
+            if (((key >> 7) & 511u) != ((ckey << 3) | bh)) continue;
             const u32 pieces = __builtin_amdgcn_readfirstlane(list[e].pieces);
             // lane (col = piece, kb) holds k = 64 (j / 16) + 16 kb + j % 16 as byte j of its 8 registers
             const u32 k = key & 127u, j = ((k >> 6) << 4) | (k & 15u);
-            const bool mine = col < 4u && ((k >> 4) & 3u) == kb;
+            const bool mine = (col >> 2) == (key >> 16) && ((k >> 4) & 3u) == kb;  // (key >> 16: batch row of the multi-row instances)
             const u32 val = mine ? ((pieces >> (8u * (col & 3u))) & 0xFFu) << (8u * (j & 3u)) : 0u;
 #pragma unroll
             for (u32 r = 0; r < 8; r++) B[r] |= (j >> 2) == r ? val : 0u;
@@ -345,7 +346,7 @@ __device__ __forceinline__ u32 hot_tau_bits(float sum1, float K) {
 // item done: add the 4 piece columns (lanes col = 0..3 of each 16-lane group), park 16 x NP1 sums in LDS
 // (pitem[subset][row]: lane (col 0, kb) owns rows 4kb..4kb+3) and clear the accumulators
 template <int NP1>
-__device__ __forceinline__ void park_item(v4f (&acc)[NP1], float *pitem, u32 col, u32 kb) {
+__device__ __forceinline__ void park_item(v4f (&acc)[NP1], float *pitem, u32 col, u32 kb, u32 MB = 1u) {
 #pragma unroll
     for (int cm = 0; cm < NP1; cm++) {
         v4f v = acc[cm];
@@ -356,7 +357,8 @@ __device__ __forceinline__ void park_item(v4f (&acc)[NP1], float *pitem, u32 col
             f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
             v[q4] = f;
         }
-        if (col == 0u) *reinterpret_cast<v4f *>(pitem + (size_t)cm * 16u + 4u * kb) = v;
+        // (batch row mm = col / 4 of the multi-row instances: pitem[row][subset][16])
+        if ((col & 3u) == 0u && (col >> 2) < MB) *reinterpret_cast<v4f *>(pitem + ((size_t)(col >> 2) * NP1 + cm) * 16u + 4u * kb) = v;
         acc[cm] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
 }
@@ -365,8 +367,8 @@ __device__ __forceinline__ void park_item(v4f (&acc)[NP1], float *pitem, u32 col
 // terms of a row sit in NP adjacent lanes and are added by a fixed DPP tree (deterministic order)
 template <int BITS>
 __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lutl, const float *part, float X, u32 rg0, u32 m, u32 tid,
-                                               u32 T) {
-    constexpr int NP = 1 << BITS, NP1 = NP - 1;
+                                               u32 T, u32 PS /* floats between the K-split items of a row group */) {
+    constexpr int NP = 1 << BITS;
     const u32 CS = 1u << a.log2CS;
     for (u32 e = tid; e < a.RGB * 16u * (u32)NP; e += T) {
         const u32 i = e / (u32)NP, c = e % (u32)NP;
@@ -388,8 +390,7 @@ __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lu
             // the K-split partial sums, added in item order; all loads of a batch are in flight together (a plain loop
             // pays the LDS latency once per partial: 2000 cycles for 16 of them)
             term = 0.f;
-            const float *pp = part + (((size_t)(rgl << a.log2CS)) * NP1 + (c - 1u)) * 16u + rr;
-            constexpr u32 PS = NP1 * 16u;
+            const float *pp = part + ((size_t)(rgl << a.log2CS)) * PS + (c - 1u) * 16u + rr;
             if (CS >= 8u) {
                 for (u32 cs = 0; cs < CS; cs += 8u) {
                     float v[8];
@@ -448,7 +449,6 @@ __device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
 //   late waves : request their first item at t = 0 (right behind the activation loads of the early waves) and may
 //                block in the issue queue; they only wait for the image, through an LDS counter.
 // Items: i < L (= W - E late waves) -> the first item of late wave E + i; i >= L -> wave (i - L) mod W.
-template <int BITS, int PRO, int NI>
 #ifndef PL_WPE
 #define PL_WPE 4
 #endif
@@ -458,7 +458,13 @@ template <int BITS, int PRO, int NI>
 #ifndef PL_PRIO
 #define PL_PRIO 4  // local-image prologue: 4 priority graded by start order (default), 0 one raised level, 1 none
 #endif
+// MBT > 1: up to MBT batch rows in ONE pass over the planes (the reference's multi_row GEMV, anyprec.cu:381,425,494-506: M = 2..8
+// rows from one read of the weight words): row mm of the block's a.MB rows has its own activation image and uses the MFMA columns
+// 4 mm .. 4 mm + 3 (a row needs 4 of the 16: its bf8 pieces), its own E8M0 scale (supplied per lane) and statistics; the images
+// are built one after the other through the same staged copy.  Plain prologue only; gridDim.y = ceil(M / a.MB).
+template <int BITS, int PRO, int NI, int MBT = 1>
 __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2) ap_plane_kernel(PlaneArgs a) {
+    static_assert(MBT == 1 || PRO == PRO_NONE, "several rows per pass: plain prologue only");
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
     constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u, E = W / 2u, L = W - E;  // early / late waves
     // NI prologue passes over the (chunk, virtual lane, weight pair) items: pass n gives early wave w the chunk (w >> 1) + n * E / 2
@@ -473,20 +479,25 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     const u32 l = tid & 63u;
     const u32 CS = 1u << a.log2CS, cpi = a.cpi, S = a.S;
     const u32 nIt = a.RGB * CS;  // items of this block
-    // LDS: [A rings: W x S slots][LUT rows of the block][B image: nchunks * 4096][zero32 (64 B)][red: 60 floats, ctr: 4][hot list: K / 64 x 8 B][part]
+    // LDS: [A rings: W x S slots][LUT rows of the block][B images: rows x (nchunks * 4096 (+ 64))][zero32 (64 B)][red: rows x 64 floats, ctr in row 0's][hot list: rows x K / 64 x 8 B][part]
     unsigned char *ring = smem + (size_t)w * S * SLOT;
     const u32 lut_bytes = (a.RGB * 16u * (u32)NP * 2u + LPS * 1024u - 1u) / (LPS * 1024u) * (LPS * 1024u);  // whole pseudo steps
     unsigned char *lutb = smem + (size_t)W * S * SLOT;
     const u32 *lutl = reinterpret_cast<const u32 *>(lutb);  // fp16 [RGB * 16][NP]
+    const u32 m = MBT == 1 ? blockIdx.y : blockIdx.y * a.MB;                   // first batch row of this block
+    const u32 MB = MBT == 1 ? 1u : min(a.MB, a.M - m);                         // ... and how many it serves
+    const u32 MBA = MBT == 1 ? 1u : a.MB;                                      // (layout: rows allocated)
     unsigned char *bimg = lutb + lut_bytes;
-    unsigned char *zero32 = bimg + G.nchunks * 4096u;
-    float *red = reinterpret_cast<float *>(zero32 + 64);
+    // image stride: + 64 B between the rows' images, so that the MFMA lanes of a ds_read_b128 group -- columns of different
+    // rows at the same piece / unit -- fall into different banks (units {0,8,2,10} + 4 mm of the 16 per bank row)
+    const u32 IMGS = G.nchunks * 4096u + (MBT > 1 ? 64u : 0u);
+    unsigned char *zero32 = bimg + MBA * IMGS;
+    float *red = reinterpret_cast<float *>(zero32 + 64);  // 64 floats per batch row (statistics, sums, scale); the counters in row 0's
     u32 *ctr = reinterpret_cast<u32 *>(red + 60);  // 0, 1, 3: software barriers; 2: extracted elements
-    HotEnt *hotl = reinterpret_cast<HotEnt *>(red + 64);
-    const u32 hot_cap = G.K / 64u;                    // Markov: |x| > 64 mean|x| holds for fewer than K / 64 elements
-    float *part = red + 64 + 2u * hot_cap;            // [item][subset][16 rows]
+    HotEnt *hotl = reinterpret_cast<HotEnt *>(red + 64u * MBA);
+    const u32 hot_cap = G.K / 64u * MBA;              // Markov: |x| > 64 mean|x| holds for fewer than K / 64 elements of a row
+    float *part = red + 64u * MBA + 2u * hot_cap;     // [item][batch row][subset][16 rows]
     const u32 rg0 = blockIdx.x * a.RGB;
-    const u32 m = blockIdx.y;
     auto stamp = [&](int i) {
         if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
     };
@@ -502,19 +513,23 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // too small for the copy, 16-bit loads straight into the item layout (each line requested up to 9 times: measured 7300
     // cycles instead of ~1500 until the K = 14336 vector has landed).
     u32 xr[NI][4], ar[NI][4], xh[NI][4], ah[NI][4];
-    u32x4 rawv[NI], rawa[NI];
+    u32x4 rawv[MBT][NI], rawa[NI];
     const u32 pt = l & 31u, pb = ((w & 1u) << 1) | (l >> 5);  // the same for every pass (E * 64 is a multiple of 128)
     if (early) {
         const u32x4 rsx = make_rsrc(a.x + (size_t)m * a.x_ld, (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
         const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
         if (a.rawx) {
 #pragma unroll
-            for (u32 n = 0; n < (u32)NI; n++) {
-                const u32 idx = tid + n * (E * 64u);  // 16-byte unit of the vector
-                const u32 voff = (idx < G.K / 8u && !(a.xflags & 8u)) ? 16u * idx : OOB;
-                rawv[n] = bload128(rsx, voff, 0u);
-                if constexpr (PRO == PRO_RMSNORM) rawa[n] = bload128(rsa, voff, 0u);
-                if constexpr (PRO == PRO_SILUMUL) rawa[n] = bload128(rsx, voff, 2u * G.K);
+            for (u32 mm = 0; mm < (u32)MBT; mm++) {  // (every row's loads are in flight before the first one is used)
+                const u32x4 rsm = MBT == 1 ? rsx : make_rsrc(a.x + (size_t)(m + mm) * a.x_ld, mm < MB ? 2u * G.K : 0u);
+#pragma unroll
+                for (u32 n = 0; n < (u32)NI; n++) {
+                    const u32 idx = tid + n * (E * 64u);  // 16-byte unit of the vector
+                    const u32 voff = (idx < G.K / 8u && !(a.xflags & 8u)) ? 16u * idx : OOB;
+                    rawv[mm][n] = bload128(rsm, voff, 0u);
+                    if constexpr (PRO == PRO_RMSNORM) rawa[n] = bload128(rsa, voff, 0u);
+                    if constexpr (PRO == PRO_SILUMUL) rawa[n] = bload128(rsx, voff, 2u * G.K);
+                }
             }
         } else {
 #pragma unroll
@@ -587,7 +602,8 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // the block is issued before the first plane load; this barrier (the LDS counters are zero behind it) costs the
     // launch skew of the last wave, ~800 cycles.
     if (tid < 4) ctr[tid] = 0u;
-    if (tid < 16) red[32 + tid] = 0.f;
+    if (tid < 16)
+        for (u32 mm = 0; mm < MB; mm++) red[64u * mm + 32u + tid] = 0.f;
     if (tid < 16) reinterpret_cast<u32 *>(zero32)[tid] = 0u;
     __syncthreads();
     // The LUT rows of the block ride in the queue of the last wave as nlut pseudo steps of exactly LPS loads each
@@ -618,71 +634,6 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // otherwise the early waves, from their own maxima and one more sum in the statistics pass.
     constexpr u32 NSC = L >= 2u ? L / 2u : 1u;
     const bool scan_late = a.rawx && !a.himg && !(HOT_ABL & 2) && !(HOT_ABL & 32);
-    if (early) {
-    wait_vm<0>();  // the activation loads (an early wave has nothing else in flight)
-    // ---------------------------------------------------------------- 1. statistics (+ staging) -> one early-wave barrier
-    // RMSNorm: sum x^2 and max |x * w| (bounds the normalised maximum); otherwise max |x'| of the transformed vector.
-    // With the LDS staging they are taken in the coalesced (raw) domain, before the copy is written, so the staging
-    // barrier is also the statistics barrier; SiLU(gate) * up is applied there too and only the product is staged.
-    {
-        // RMSNorm: sum x^2 (ss) and max |x w| (fp32); otherwise max |x'| (packed integer maximum of the bit patterns)
-        float ss = 0.f, mxf = 0.f;
-        us2 mxp = {0, 0};  // |fp16| bit patterns order like unsigned integers
-        auto stat = [&](u32 xw, u32 aw) {  // one packed pair of activations (and of norm weights)
-            if constexpr (PRO == PRO_RMSNORM) {
-                const float p = h2f(xw & 0xFFFF), q = h2f(xw >> 16);
-                ss += p * p;
-                ss += q * q;
-                mxf = fmaxf(mxf, fmaxf(fabsf(p * h2f(aw & 0xFFFF)), fabsf(q * h2f(aw >> 16))));
-            } else {
-                mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, xw & 0x7FFF7FFFu));
-            }
-        };
-        if (a.rawx) {
-            unsigned char *raw = smem;  // the early waves' ring slots
-#pragma unroll
-            for (u32 n = 0; n < (u32)NI; n++) {
-                tie128(rawv[n]);
-                if constexpr (PRO != PRO_NONE) tie128(rawa[n]);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if constexpr (PRO == PRO_SILUMUL) rawv[n][k] = silu_mul2(rawv[n][k], rawa[n][k]);
-                    stat(rawv[n][k], PRO == PRO_RMSNORM ? rawa[n][k] : 0u);
-                }
-                const u32 idx = tid + n * (E * 64u);
-                if (idx < G.K / 8u) {
-                    *reinterpret_cast<u32x4 *>(raw + 16u * idx) = rawv[n];
-                    if constexpr (PRO == PRO_RMSNORM) *reinterpret_cast<u32x4 *>(raw + 2u * G.K + 16u * idx) = rawa[n];
-                }
-            }
-        } else {
-#pragma unroll
-            for (u32 n = 0; n < (u32)NI; n++) {
-                tie4(xr[n]);
-                tie4(xh[n]);
-                if constexpr (PRO != PRO_NONE) {
-                    tie4(ar[n]);
-                    tie4(ah[n]);
-                }
-#pragma unroll
-                for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
-                    xr[n][c] |= xh[n][c] << 16;
-                    if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
-                    if constexpr (PRO == PRO_SILUMUL) xr[n][c] = silu_mul2(xr[n][c], ar[n][c]);
-                    stat(xr[n][c], PRO == PRO_RMSNORM ? ar[n][c] : 0u);
-                }
-            }
-        }
-        float mx = PRO == PRO_RMSNORM ? mxf : h2f(max(mxp[0], mxp[1]));
-        mx = wave_reduce<true>(mx);
-        if constexpr (PRO == PRO_RMSNORM) ss = wave_reduce<false>(ss);
-        if (l == 63) {
-            red[w] = mx;
-            if constexpr (PRO == PRO_RMSNORM) red[16 + w] = ss;
-        }
-        arrive(ctr + 0, l);
-    }
-    }  // early: staging + statistics
     // image passes: early wave w takes passes [0, NIe), with a.himg late wave w the passes [NIe, NI) of early wave w - E
     constexpr u32 NIe = (NI + 1) / 2;
     const bool helper = !early && a.himg;
@@ -692,7 +643,9 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     const u32 img_arrivals = (a.himg ? W : E) + (scan_late ? NSC : 0u);
     // ---- elements above the extraction threshold (see hot_step): scanner waves, or the early waves when there are none.  Needs the
     // staged copy (without it -- K = 16384 behind RMSNorm -- nothing is extracted: round-2 behaviour there).
+    u32 mmv = 0;  // the batch row being processed (detect, builders)
     auto detect = [&]() {
+        const float *redm = red + 64u * mmv;
         const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;  // the staged copy
         // in the RMSNorm prologue everything up to the rare path works on the products x w BEFORE the normalisation: the common
         // factor cancels in |x'| > 64 mean|x'|
@@ -722,11 +675,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             // test on the transformed element; what passes is appended to the list and leaves the image once that is complete
             float ns = 1.f, xm = 0.f;
 #pragma unroll
-            for (u32 i = 0; i < E; i++) xm = fmaxf(xm, red[i]);
+            for (u32 i = 0; i < E; i++) xm = fmaxf(xm, redm[i]);
             if constexpr (PRO == PRO_RMSNORM) {  // (the builders' own formulas: identical values)
                 float tot = 0.f;
 #pragma unroll
-                for (u32 i = 0; i < E; i++) tot += red[16 + i];
+                for (u32 i = 0; i < E; i++) tot += redm[16 + i];
                 ns = 1.0f / sqrtf(tot / (float)G.K + a.eps);
                 xm = xm * ns * 1.002f;
             }
@@ -748,26 +701,98 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
                             const u32 e = 8u * idx + j;
                             u32 chunk, bb, hh, k;
                             locate_x4(G, e, chunk, bb, hh, k);
-                            consider(rx[e], PRO == PRO_RMSNORM ? ra[e] : 0u, (chunk << 10) | ((bb * 2u + hh) << 7) | k);
+                            consider(rx[e], PRO == PRO_RMSNORM ? ra[e] : 0u, (mmv << 16) | (chunk << 10) | ((bb * 2u + hh) << 7) | k);
                         }
                     }
                 }
             }
         }
     };
+    if (early) wait_vm<0>();  // the activation loads of every row (an early wave has nothing else in flight)
+#pragma unroll
+    for (u32 mm = 0; mm < (u32)MBT; mm++) {  // batch rows of this block, one after the other through the same staged copy
+    if (mm < MB) {
+    mmv = mm;
+    float *redm = red + 64u * mm;
+    unsigned char *bimgm = bimg + mm * IMGS;
+    if (early) {
+    // ---------------------------------------------------------------- 1. statistics (+ staging) -> one early-wave barrier
+    // RMSNorm: sum x^2 and max |x * w| (bounds the normalised maximum); otherwise max |x'| of the transformed vector.
+    // With the LDS staging they are taken in the coalesced (raw) domain, before the copy is written, so the staging
+    // barrier is also the statistics barrier; SiLU(gate) * up is applied there too and only the product is staged.
+    {
+        // RMSNorm: sum x^2 (ss) and max |x w| (fp32); otherwise max |x'| (packed integer maximum of the bit patterns)
+        float ss = 0.f, mxf = 0.f;
+        us2 mxp = {0, 0};  // |fp16| bit patterns order like unsigned integers
+        auto stat = [&](u32 xw, u32 aw) {  // one packed pair of activations (and of norm weights)
+            if constexpr (PRO == PRO_RMSNORM) {
+                const float p = h2f(xw & 0xFFFF), q = h2f(xw >> 16);
+                ss += p * p;
+                ss += q * q;
+                mxf = fmaxf(mxf, fmaxf(fabsf(p * h2f(aw & 0xFFFF)), fabsf(q * h2f(aw >> 16))));
+            } else {
+                mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, xw & 0x7FFF7FFFu));
+            }
+        };
+        if (a.rawx) {
+            unsigned char *raw = smem;  // the early waves' ring slots
+#pragma unroll
+            for (u32 n = 0; n < (u32)NI; n++) {
+                tie128(rawv[mm][n]);
+                if constexpr (PRO != PRO_NONE) tie128(rawa[n]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if constexpr (PRO == PRO_SILUMUL) rawv[mm][n][k] = silu_mul2(rawv[mm][n][k], rawa[n][k]);
+                    stat(rawv[mm][n][k], PRO == PRO_RMSNORM ? rawa[n][k] : 0u);
+                }
+                const u32 idx = tid + n * (E * 64u);
+                if (idx < G.K / 8u) {
+                    *reinterpret_cast<u32x4 *>(raw + 16u * idx) = rawv[mm][n];
+                    if constexpr (PRO == PRO_RMSNORM) *reinterpret_cast<u32x4 *>(raw + 2u * G.K + 16u * idx) = rawa[n];
+                }
+            }
+        } else {
+#pragma unroll
+            for (u32 n = 0; n < (u32)NI; n++) {
+                tie4(xr[n]);
+                tie4(xh[n]);
+                if constexpr (PRO != PRO_NONE) {
+                    tie4(ar[n]);
+                    tie4(ah[n]);
+                }
+#pragma unroll
+                for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
+                    xr[n][c] |= xh[n][c] << 16;
+                    if constexpr (PRO != PRO_NONE) ar[n][c] |= ah[n][c] << 16;
+                    if constexpr (PRO == PRO_SILUMUL) xr[n][c] = silu_mul2(xr[n][c], ar[n][c]);
+                    stat(xr[n][c], PRO == PRO_RMSNORM ? ar[n][c] : 0u);
+                }
+            }
+        }
+        float mx = PRO == PRO_RMSNORM ? mxf : h2f(max(mxp[0], mxp[1]));
+        mx = wave_reduce<true>(mx);
+        if constexpr (PRO == PRO_RMSNORM) ss = wave_reduce<false>(ss);
+        if (l == 63) {
+            redm[w] = mx;
+            if constexpr (PRO == PRO_RMSNORM) redm[16 + w] = ss;
+        }
+        arrive(ctr + 0, l);
+    }
+    }  // early: staging + statistics
     if (scanner) {
-        wait_count(ctr + 0, E);
+        wait_count(ctr + 0, E * (mm + 1u));
         if (!(HOT_ABL & 16)) detect();
         arrive(ctr + 1, l);
     } else if (early || helper) {
     {
-        wait_count(ctr + 0, E);
+        wait_count(ctr + 0, E * (mm + 1u));
+        xmax = 0.f;
 #pragma unroll
-        for (u32 i = 0; i < E; i++) xmax = fmaxf(xmax, red[i]);
+        for (u32 i = 0; i < E; i++) xmax = fmaxf(xmax, redm[i]);
         if constexpr (PRO == PRO_RMSNORM) {
             float tot = 0.f;
 #pragma unroll
-            for (u32 i = 0; i < E; i++) tot += red[16 + i];
+            for (u32 i = 0; i < E; i++) tot += redm[16 + i];
             nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
             xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
         }
@@ -821,7 +846,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
                     if (p < 3) rem = rem - u2h2(P[p][c]);
                 }
             }
-            unsigned char *img = bimg + bimg4_off(chunk, pb, hh, 0u) + 8u * vA;
+            unsigned char *img = bimgm + bimg4_off(chunk, pb, hh, 0u) + 8u * vA;
 #pragma unroll
             for (u32 p = 0; p < 4; p++) {
                 // k = 32g + 8v + i, nibble i = 2 (3 - c) + (s >> 2): bytes (i = 0..3) = c3.j(7-b), c3.j(3-b), c2.j(7-b), c2.j(3-b);
@@ -833,18 +858,32 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         }
         xsum = wave_reduce<false>(xsum);
         if (l == 63) {
-            red[32 + w] = xsum;
-            if (w == 0) red[48] = __builtin_bit_cast(float, (u32)(127 - ksh));  // E8M0 scale of every B block, for the late waves
+            redm[32 + w] = xsum;
+            if (w == 0) redm[48] = __builtin_bit_cast(float, (u32)(127 - ksh));  // E8M0 scale of every B block, for the late waves
         }
     }
     stamp(1);
     arrive(ctr + 1, l);
     }  // image builders
-    wait_count(ctr + 1, img_arrivals);  // the B image is complete
+    // the staged copy is free for the next row once every builder and scanner is done with this one
+    if (MBT > 1 && mm + 1u < MB && (early || scanner)) wait_count(ctr + 1, img_arrivals * (mm + 1u));
+    }
+    }
+    wait_count(ctr + 1, img_arrivals * MB);  // the B images are complete
     stamp(2);
+    // per batch row: sum(x) and the E8M0 scale of its image; a lane's scale operand is that of ITS column's row
+    float Xr[MBT];
+    const u32 mcol = (l & 15u) >> 2;
 #pragma unroll
-    for (u32 i = 0; i < W; i++) X += red[32 + i];
-    sb = (int)__builtin_bit_cast(u32, red[48]);
+    for (u32 mm = 0; mm < (u32)MBT; mm++) {
+        Xr[mm] = 0.f;
+        if (mm < MB) {
+#pragma unroll
+            for (u32 i = 0; i < W; i++) Xr[mm] += red[64u * mm + 32u + i];
+            if (mm == 0u || mm == mcol) sb = (int)__builtin_bit_cast(u32, red[64u * mm + 48u]);
+        }
+    }
+    X = Xr[0];
     // (a plain LDS read, like red[]: a volatile / atomic access through the generic pointer compiles to a FLAT load whose
     // s_waitcnt vmcnt(0) drains the wave's whole plane stream -- measured: w1w3 9.4 -> 10.3 us)
     const u32 nhot_raw = (HOT_ABL & 256) ? 0u : __builtin_amdgcn_readfirstlane(__builtin_bit_cast(u32, red[62]));
@@ -854,7 +893,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         // leave the image -- byte k of their (chunk, b, h) block in each of the 4 piece columns --, one more barrier
         for (u32 e = tid; e < 4u * nhot; e += T) {
             const u32 key = hotl[e >> 2].key;
-            bimg[(key >> 10) * 4096u + ((key >> 7) & 7u) * 512u + (e & 3u) * 128u + ((key & 127u) ^ bimg_swz(e & 3u))] = 0;
+            bimg[(key >> 16) * IMGS + ((key >> 10) & 63u) * 4096u + ((key >> 7) & 7u) * 512u + (e & 3u) * 128u + ((key & 127u) ^ bimg_swz(e & 3u))] = 0;
         }
         arrive(ctr + 3, l);
         wait_count(ctr + 3, W);
@@ -865,7 +904,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     while (iq_n < my_steps && iq_n < S) issue();
     const u32 r = l & 15u, kb = l >> 4;
     const u32 col = l & 15u;
-    const bool bcol = col < 4u;
+    const bool bcol = col < 4u * MB;
     const u32 offA0 = atile_unit(r, 2u * kb) * 16u, offA1 = atile_unit(r, 2u * kb + 1u) * 16u;
     v4f acc[NP1];
 #pragma unroll
@@ -884,7 +923,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         }
         if (++cq_slot == S) cq_slot = 0;
         if (chunk < G.nchunks && !(a.xflags & 1u)) {
-            const unsigned char *bbase = bcol ? bimg + bimg4_off(chunk, 0u, 0u, col) + ((16u * kb) ^ bimg_swz(col)) : zero32;
+            const unsigned char *bbase = bcol ? bimg + mcol * IMGS + bimg4_off(chunk, 0u, 0u, col & 3u) + ((16u * kb) ^ bimg_swz(col & 3u)) : zero32;
             // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
             mfma_chunk<BITS>(acc, Wd, bbase, bcol ? 512u : 0u, bcol ? 64u : 0u, sb);
             if (!(HOT_ABL & 4) && __builtin_expect(nhot != 0u, 0)) hot_step<BITS>(acc, Wd, hotl, nhot, chunk, sb, col, kb);
@@ -892,7 +931,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             acc[0][0] += __builtin_bit_cast(float, Wd[0][0] ^ Wd[BITS - 1][7]);
         }
         if (++cq_c == cpi) {
-            park_item<NP1>(acc, part + (size_t)cq_item * NP1 * 16u, col, kb);  // part[item][subset][row]
+            park_item<NP1>(acc, part + (size_t)cq_item * MB * NP1 * 16u, col, kb, MB);  // part[item][batch row][subset][row]
             cq_c = 0;
             cq_item = item_after(cq_item);
         }
@@ -903,7 +942,10 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     stamp(4);
 
     // ---------------------------------------------------------------- 4. epilogue: coefficients x plane sums
-    plane_epilogue<BITS>(a, lutl, part, X, rg0, m, tid, T);
+#pragma unroll
+    for (u32 mm = 0; mm < (u32)MBT; mm++)
+        if (mm < MB) plane_epilogue<BITS>(a, lutl, part + (size_t)mm * NP1 * 16u, Xr[mm], rg0, m + mm, tid, T, MB * NP1 * 16u);
+    (void)X;
     stamp(5);
 }
 
@@ -1211,7 +1253,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     float X = 0.f;
 #pragma unroll
     for (u32 i = 0; i < W; i++) X += red[32 + i];
-    plane_epilogue<BITS>(a, lutl, part, X, rg0, m, tid, T);
+    plane_epilogue<BITS>(a, lutl, part, X, rg0, m, tid, T, NP1 * 16u);
     stamp(5);
 }
 
@@ -1222,7 +1264,7 @@ struct PlaneCfg {
 
 int cus() { return gq_cu_count(); }
 
-bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
+bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c, u32 MB = 1u) {
     if (K % 256u || K > 16384u) return false;
     const u32 nchunks = K / 1024u + ((K % 1024u) ? 1u : 0u);
     const u32 RGt = (N + 15u) / 16u;
@@ -1248,7 +1290,9 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     const u32 np1 = (1u << bits) - 1u;
     const size_t lps_bytes = 2048u * (size_t)bits;  // LPS loads of 1 KiB
     const size_t lutb = ((size_t)rgb * 16u * (np1 + 1u) * 2u + lps_bytes - 1u) / lps_bytes * lps_bytes;
-    const size_t fixed = lutb + (size_t)nchunks * 4096u + 64u + 64u * 4u + (size_t)(K / 64u) * 8u + (size_t)nIt * np1 * 16u * 4u;
+    // (MB batch rows per pass: MB images 64 B apart, MB x the statistics / list / partial-sum areas)
+    const size_t fixed = lutb + (size_t)MB * ((size_t)nchunks * 4096u + (MB > 1u ? 64u : 0u)) + 64u + (size_t)MB * 64u * 4u + (size_t)MB * (K / 64u) * 8u +
+                         (size_t)MB * nIt * np1 * 16u * 4u;
     const size_t slot = 2048u * (size_t)bits, lds = 160u * 1024u;
     if (fixed + W * slot > lds) return false;
     u32 S = (u32)((lds - fixed) / (W * slot));
@@ -1323,15 +1367,23 @@ int launch_local(const PlaneArgs &a, const PlaneCfg &c, u32 M, int pro, hipStrea
     return launch_local_inst<BITS, PRO_NONE, 4>(a, c, M, s);
 }
 
-template <int BITS, int PRO, int NI>
+template <int BITS, int PRO, int NI, int MBT = 1>
 int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     static GqPerDeviceOnce once;
-    auto kern = ap_plane_kernel<BITS, PRO, NI>;
+    auto kern = ap_plane_kernel<BITS, PRO, NI, MBT>;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
-    dim3 grid(c.grid, M), block(c.T);
+    dim3 grid(c.grid, MBT == 1 ? M : (M + a.MB - 1u) / a.MB), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
+}
+
+// several batch rows per pass (plain prologue, staged copy, NI <= 2: K <= 8192 at 2 bits, K <= 4096 at 3 / 4 bits)
+template <int BITS>
+int launch_plane_rows(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
+    if (c.NI <= 1) return launch_plane_inst<BITS, PRO_NONE, 1, 4>(a, c, M, s);
+    if (c.NI == 2) return launch_plane_inst<BITS, PRO_NONE, 2, 4>(a, c, M, s);
+    return GQ_ENOTSUP;
 }
 
 template <int BITS, int PRO>
@@ -1365,8 +1417,21 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
                        uint32_t k0, uint32_t Ks, int bits, const void *normw, float eps, const void *resid, int pro, int pairs,
                        hipStream_t stream) {
     PlaneCfg c;
-    const bool local = pro != PRO_RMSNORM && gq_env_int("GQ_PL_LOCAL", 1) && pick_local_cfg(N, Ks, bits, c);
-    if (!local && !pick_plane_cfg(N, Ks, bits, c)) return GQ_ENOTSUP;
+    // M = 2 .. 8 batch rows: up to 4 of them share ONE pass over the planes (shared-image kernel, one image per row) when the images
+    // fit LDS next to the rings and the staged copy -- K <= 4096 for 4 rows, K <= 8192 for 2 --; else one block row per batch row
+    u32 MB = 1u;
+    if (M >= 2u && pro == PRO_NONE && !pairs && gq_env_int("GQ_PL_ONEPASS", 1)) {
+        for (u32 mb = M < 4u ? M : 4u; mb >= 2u && MB == 1u; mb--) {
+            PlaneCfg cm;
+            if (!pick_plane_cfg(N, Ks, bits, cm, mb) || cm.NI > 2u) continue;
+            const size_t need = (size_t)Ks * 2u, have = (size_t)(cm.T / 128u) * cm.S * 2048u * (size_t)bits;
+            if (need > have) continue;
+            MB = mb;
+            c = cm;
+        }
+    }
+    const bool local = MB == 1u && pro != PRO_RMSNORM && gq_env_int("GQ_PL_LOCAL", 1) && pick_local_cfg(N, Ks, bits, c);
+    if (MB == 1u && !local && !pick_plane_cfg(N, Ks, bits, c)) return GQ_ENOTSUP;
     PlaneArgs a{};
     a.qw = qweight;
     a.lut = (const uint16_t *)lut;
@@ -1384,10 +1449,21 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
     a.cpi = c.cpi;
     a.S = c.S;
     a.pairs = pairs ? 1u : 0u;
+    a.MB = MB;
+    a.M = M;
     {
         const size_t need = (size_t)Ks * 2u * (pro == PRO_RMSNORM ? 2u : 1u), have = (size_t)(c.T / 128u) * c.S * 2048u * (size_t)bits;
         a.rawx = (need <= have && gq_env_int("GQ_PL_RAWX", 1)) ? 1u : 0u;
         a.himg = (a.rawx && c.NI >= 2u && c.S == 1u && gq_env_int("GQ_PL_HIMG", 1)) ? 1u : 0u;
+    }
+    if (MB > 1u) {
+        a.rawx = 1u;
+        a.himg = 0u;
+        switch (bits) {
+            case 2: return launch_plane_rows<2>(a, c, M, stream);
+            case 3: return launch_plane_rows<3>(a, c, M, stream);
+            default: return launch_plane_rows<4>(a, c, M, stream);
+        }
     }
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);
     a.eps = eps;

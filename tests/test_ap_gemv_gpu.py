@@ -322,6 +322,41 @@ def test_fast_mode_multi_batch(oracle, N, K):
         _check_fast(got[mm], X[mm], q, lut, bits, oracle)
 
 
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(4, 28672, 4096), (2, 6144, 4096), (3, 4096, 4096), (8, 512, 4096), (7, 1024, 2048), (2, 1024, 8192), (4, 256, 4352)])
+def test_fast_mode_rows_share_one_pass(oracle, monkeypatch, bits, M, N, K):
+    """M = 2 .. 8 batch rows, up to 4 per pass over the planes (the reference's multi_row kernel, anyprec.cu:381,425,494-506): one
+    image per row in MFMA columns 4 mm .. 4 mm + 3.  The arithmetic of a row is that of the one-row launch: results bit-identical
+    to GQ_PL_ONEPASS=0 (one block row per batch row, same image builders), row by row within the fast-mode envelope; one row carries massive channels
+    (extraction list entries tagged with their row).  Shapes whose images do not fit (K = 8192 at 3 / 4 bits) fall back."""
+    from guidedquant_amd import _lib, pack
+    rng = np.random.default_rng(bits * 31 + M + N + K)
+    q = pack.random_planes(N, K, bits, seed=M + K)
+    lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float16), axis=1)
+    X = rng.normal(0, 1, (M, K))
+    hot = rng.choice(K, 3, replace=False)
+    X[M - 1, hot] *= 2.0**11
+    X[0, hot[0]] *= 2.0**9
+    X = X.astype(np.float16)
+    _fast()
+    got = _run_gemv(X, q, lut, bits, M=M)
+    monkeypatch.setenv("GQ_PL_ONEPASS", "0")
+    # the same kernel and image builders for the reference run: the local-image variant (own scale per wave) and the late-wave image
+    # helpers (sum(x) partials split differently) give last-bit differences
+    monkeypatch.setenv("GQ_PL_HIMG", "0")
+    _fast(local=0)
+    ref = _run_gemv(X, q, lut, bits, M=M)
+    monkeypatch.delenv("GQ_PL_HIMG")
+    _fast()
+    ref_dflt = _run_gemv(X, q, lut, bits, M=M)  # (what a shape whose images do not fit falls back to: the default one-row dispatch)
+    monkeypatch.delenv("GQ_PL_ONEPASS")
+    _lib.lib().gq_reset_env_cache()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)) or np.array_equal(got.view(np.uint16), ref_dflt.view(np.uint16))
+    rows = np.unique(np.concatenate([np.arange(0, 24), np.arange(N - 24, N), rng.integers(0, N, 48)]))
+    for mm in (0, M - 1):
+        _check_fast(got[mm], X[mm], q, lut, bits, oracle, rows=rows)
+
+
 @pytest.mark.parametrize("bits,N,K", [(2, 28672, 4096), (2, 4096, 14336), (3, 28672, 4096), (4, 28672, 4096)])
 def test_fast_mode_within_north_star_tolerance_of_reference_order(oracle, bits, N, K):
     """north_star: "outputs within 1e-3 rel-fp16 of the CUDA reference".  Norm-wise, the plane-MFMA result is within

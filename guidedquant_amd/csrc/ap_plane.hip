@@ -504,6 +504,9 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     stamp(0);
     if (a.xflags & 32u) return;
     const bool early = w < E;
+    auto stamp2 = [&](int i) {  // finer stamps of the prologue (second table of tools/phase_timing.py)
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[128u + w * 16u + (u32)i] = __builtin_readcyclecounter();
+    };
 
     // ---------------------------------------------------------------- 0. activation loads, then the first tiles
     // prologue item = (chunk, virtual lane t, nibble bit b): the weights j = 7 - b and j = 3 - b (plane bits b and b + 4 of
@@ -515,6 +518,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     u32 xr[NI][4], ar[NI][4], xh[NI][4], ah[NI][4];
     u32x4 rawv[MBT][NI], rawa[NI];
     const u32 pt = l & 31u, pb = ((w & 1u) << 1) | (l >> 5);  // the same for every pass (E * 64 is a multiple of 128)
+    stamp2(5);
     if (early) {
         const u32x4 rsx = make_rsrc(a.x + (size_t)m * a.x_ld, (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
         const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
@@ -555,6 +559,21 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             }
         }
     }
+    stamp2(6);
+    // The CU's vector-memory pipe serves requests in order across waves: an activation load (an L2 hit) queued behind
+    // another wave's plane loads waits for HBM (measured: 5000 cycles instead of 1200).  So every activation load of
+    // the block is issued before the first plane load; this barrier (the LDS counters are zero behind it) costs the
+    // launch skew of the last wave, ~800 cycles.
+    if (tid < 4) ctr[tid] = 0u;
+    if (tid < 16)
+        for (u32 mm = 0; mm < MB; mm++) red[64u * mm + 32u + tid] = 0.f;
+    if (tid < 16) reinterpret_cast<u32 *>(zero32)[tid] = 0u;
+    stamp2(7);
+    __syncthreads();
+    // (everything a wave needs only behind the barrier is computed behind it: the barrier ends with the last-started wave -- launch
+    // skew ~800 cycles -- and every instruction that wave runs before it keeps the early waves, whose activations have landed by
+    // then, waiting: ~1,850 -> ~1,100 cycles from the start of the block)
+    __builtin_amdgcn_sched_barrier(0);
     // plane stream of this wave: its items in order (late wave: item w - E first), cpi steps each, ring slot = step % S
     const u32 first_late = (!early && w - E < nIt) ? 1u : 0u;
     const u32 items_w = first_late + (nIt > L + w ? (nIt - L - w + W - 1u) / W : 0u);
@@ -597,15 +616,6 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         if (++iq_slot == S) iq_slot = 0;
         iq_n++;
     };
-    // The CU's vector-memory pipe serves requests in order across waves: an activation load (an L2 hit) queued behind
-    // another wave's plane loads waits for HBM (measured: 5000 cycles instead of 1200).  So every activation load of
-    // the block is issued before the first plane load; this barrier (the LDS counters are zero behind it) costs the
-    // launch skew of the last wave, ~800 cycles.
-    if (tid < 4) ctr[tid] = 0u;
-    if (tid < 16)
-        for (u32 mm = 0; mm < MB; mm++) red[64u * mm + 32u + tid] = 0.f;
-    if (tid < 16) reinterpret_cast<u32 *>(zero32)[tid] = 0u;
-    __syncthreads();
     // The LUT rows of the block ride in the queue of the last wave as nlut pseudo steps of exactly LPS loads each
     // (padded with out-of-range loads), behind its first item: loads return in order, so its vmcnt bookkeeping stays in
     // units of steps, and the LUT is in LDS once it has seen its last tile.
@@ -708,7 +718,9 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             }
         }
     };
+    stamp2(0);
     if (early) wait_vm<0>();  // the activation loads of every row (an early wave has nothing else in flight)
+    stamp2(1);
 #pragma unroll
     for (u32 mm = 0; mm < (u32)MBT; mm++) {  // batch rows of this block, one after the other through the same staged copy
     if (mm < MB) {
@@ -776,6 +788,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             redm[w] = mx;
             if constexpr (PRO == PRO_RMSNORM) redm[16 + w] = ss;
         }
+        stamp2(2);
         arrive(ctr + 0, l);
     }
     }  // early: staging + statistics
@@ -786,6 +799,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     } else if (early || helper) {
     {
         wait_count(ctr + 0, E * (mm + 1u));
+        stamp2(3);
         xmax = 0.f;
 #pragma unroll
         for (u32 i = 0; i < E; i++) xmax = fmaxf(xmax, redm[i]);
@@ -796,6 +810,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             nscale = 1.0f / sqrtf(tot / (float)G.K + a.eps);
             xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
         }
+        stamp2(4);
         if (!(HOT_ABL & 2) && !scan_late && a.rawx && early) detect();
         if (a.rawx) {
             // the staged copy is complete: gather this thread's items (for SiLU the staged vector is already the product)

@@ -34,7 +34,7 @@ for name in sys.argv[2:] or list(SH):
         if t[w].max() > 0:
             print("  wave", w, [int(v - t0) if v > 0 else None for v in t[w]])
     t2 = raw[128:].reshape(16, 16)
-    print("  extra stamps (consumer: per step [wait start, tile ready], item end; producer: tile publishes)")
+    print("  prologue stamps [before x wait, x landed, statistics done, after statistics barrier, scale known]")
     for w in range(16):
         if t2[w].max() > 0:
             print("  wave", w, [int(v - t0) for v in t2[w] if v > 0])

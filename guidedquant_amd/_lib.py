@@ -17,7 +17,7 @@ EXPORTS = [
     "gq_version", "gq_last_error", "gq_device_count", "gq_anyprec_gemv", "gq_anyprec_dequant", "gq_lutgemm_gemv",
     "gq_qtip_matvec", "gq_hadamard", "gq_anyprec_gemv_fused", "gq_set_ap_mode", "gq_embed_lookup", "gq_attn_decode",
     "gq_dense_gemv_f16", "gq_sample_topk", "gq_qtip_linear_in", "gq_qtip_linear_out", "gq_qtip_transform", "gq_lutgemm_gemv_ws", "gq_attn_decode_split",
-    "gq_attn_decode_qtip",
+    "gq_attn_decode_qtip", "gq_qtip_linear_out_seg",
     "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
 ]
 _VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer")
@@ -73,6 +73,7 @@ def lib():
         L.gq_hadamard.argtypes = [vp, vp, u32, u32, f32, vp]
         L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, ctypes.POINTER(GqQtipOut), i32, vp]
         L.gq_qtip_linear_out.argtypes = [i32, ctypes.POINTER(GqQtipOut), vp]
+        L.gq_qtip_linear_out_seg.argtypes = [i32, ctypes.POINTER(GqQtipOut), vp]
         L.gq_qtip_plan_ksplit.argtypes = [i32, ctypes.POINTER(u32), u32, i32]
         L.gq_qtip_linear.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), ctypes.POINTER(GqQtipOut), i32, vp, vp]
         L.gq_qtip_transform.argtypes = [i32, vp, vp, vp, f32, i32, i32, ctypes.POINTER(GqQtipXf), u32, u32, i32, vp]

@@ -778,6 +778,68 @@ __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     qtip_transform_out(a.lin[blockIdx.x], reinterpret_cast<float *>(smem));
 }
 
+// The same transform-out spread over M / 128 blocks per linear (gq_qtip_linear_out_seg).  H_M = H_(M / 128) (x) H_128: block `seg`
+// combines the M / 128 segments of the sums with the signs of row `seg` of the Sylvester matrix -- every thread takes 16-byte units
+// of the vector, one round trip -- and runs ONE 128-point transform: no block repeats work another one does (the segment
+// combination is what the last log2(M / 128) stages of the full transform do for this segment), and the launch ends after one
+// load round trip and seven butterfly stages instead of twelve stages of a single block.  The additions of the full transform in
+// another order: equal to qtip_transform_out up to fp32 rounding, not bit for bit (decode.hip's attention prologue does the same
+// for q / k / v).
+constexpr u32 QSEG = 128u, QSEG_T = 512u;
+__global__ void __launch_bounds__(QSEG_T) qtip_linear_out_seg_kernel(QtipOutArgs a) {
+    __shared__ __attribute__((aligned(16))) float ps[QSEG_T / (QSEG / 4u) * QSEG];  // [thread group][128] partial sums
+    __shared__ __attribute__((aligned(16))) float tv[QSEG];
+    const QtipOut L = a.lin[blockIdx.y];
+    const u32 tid = threadIdx.x, seg = blockIdx.x, M4 = L.M / 4u;
+    if (seg * QSEG >= L.M) return;
+    constexpr u32 Q = QSEG / 4u, G = QSEG_T / Q;
+    // scale and residual of this thread's output element: requested before the sums (nothing else hides their latency)
+    float sv = 0.f;
+    uint16_t rs = 0;
+    if (tid < QSEG) {
+        sv = L.SV32[seg * QSEG + tid];
+        if (L.resid) rs = L.resid[seg * QSEG + tid];
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        float4 y[4];
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {  // M <= 8192: at most 4 units per thread, all in flight together
+            const u32 u = tid + k * QSEG_T;
+            y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < M4) {
+                float4 t = reinterpret_cast<const float4 *>(L.y32)[u];
+                for (u32 p = 1; p < L.parts; p++) {  // split-K parts, ascending
+                    const float4 t2 = reinterpret_cast<const float4 *>(L.y32)[(size_t)p * M4 + u];
+                    t = make_float4(t.x + t2.x, t.y + t2.y, t.z + t2.z, t.w + t2.w);
+                }
+                y[k] = t;
+            }
+        }
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 c = (tid + k * QSEG_T) / Q;
+            const float sg = (__builtin_popcount(c & seg) & 1) ? -1.f : 1.f;  // (units past the vector hold zeros)
+            acc = make_float4(acc.x + sg * y[k].x, acc.y + sg * y[k].y, acc.z + sg * y[k].z, acc.w + sg * y[k].w);
+        }
+    }
+    reinterpret_cast<float4 *>(ps + (size_t)(tid / Q) * QSEG)[tid % Q] = acc;
+    __syncthreads();
+    if (tid < QSEG) {
+        float z = 0.f;
+#pragma unroll
+        for (u32 gi = 0; gi < G; gi++) z += ps[(size_t)gi * QSEG + tid];
+        tv[tid] = z;
+    }
+    __syncthreads();
+    fwht_lds(tv, QSEG);
+    if (tid < QSEG) {
+        h16 y = (h16)gq_pin_f32((tv[tid] * L.mscale) * sv);
+        if (L.resid) y = __builtin_bit_cast(h16, rs) + y;
+        L.out[seg * QSEG + tid] = __builtin_bit_cast(uint16_t, y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ transform with a Hadamard factor
 // Widths n = Kf * P with a non-power-of-two Hadamard factor Kf (matmul_had.py:13-67; Llama-2's 11008 = 172 * 64): the
 // transform is the P-point Sylvester transform of every row of the [Kf][P] view followed by hadK @ (or hadK^T @) over
@@ -1173,6 +1235,25 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
     static GqPerDeviceOnce once;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(qtip_linear_out_kernel), 160 * 1024));
     hipLaunchKernelGGL(qtip_linear_out_kernel, dim3((u32)n), dim3(1024), smem, (hipStream_t)stream, a);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_qtip_linear_out_seg(int n, const GqQtipOut *lin, void *stream) {
+    if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_seg: 1..3 linears.");
+    QtipOutArgs a{};
+    u32 maxM = 0;
+    for (int i = 0; i < n; i++) {
+        if (!lin[i].y32 || !lin[i].SV32 || !lin[i].out) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_seg: null pointer argument.");
+        if (!pow2(lin[i].M) || lin[i].M < QSEG || lin[i].M > 16u * QSEG_T)
+            return gq_fail(GQ_ENOTSUP, "gq_qtip_linear_out_seg: M must be a power of two in 128..8192 (else gq_qtip_linear_out).");
+        if (lin[i].parts > 4u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_seg: parts must be 0..4.");
+        if (((uintptr_t)lin[i].y32) & 15u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_seg: the sums must be 16-byte aligned.");
+        a.lin[i] = QtipOut{lin[i].y32, lin[i].SV32, (const uint16_t *)lin[i].resid, (uint16_t *)lin[i].out, lin[i].M,
+                           (float)pow((double)lin[i].M, -0.5), lin[i].parts ? lin[i].parts : 1u};
+        if (lin[i].M > maxM) maxM = lin[i].M;
+    }
+    hipLaunchKernelGGL(qtip_linear_out_seg_kernel, dim3(maxM / QSEG, (u32)n), dim3(QSEG_T), 0, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

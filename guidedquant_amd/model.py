@@ -520,7 +520,9 @@ class Transformer(nn.Module):
                 arr = (_lib.GqQtipOut * len(p2))(*[_lib.GqQtipOut(ysl[i].data_ptr(), f32(mods[i].SV, 32.0), resid, outs[i], mods[i].out_features, ks)
                                                    for i in p2])
                 keep.append(arr)
-                plan.append(("gq_qtip_linear_out", (len(p2), arr)))
+                # M / 128 blocks per linear instead of one (GQ_QTIP_OUT_SEG, default ON; equal up to fp32 rounding): 2.9 vs 4.6 us
+                seg = out_seg and all(128 <= mods[i].out_features <= 8192 for i in p2)
+                plan.append(("gq_qtip_linear_out_seg" if seg else "gq_qtip_linear_out", (len(p2), arr)))
             for Kf, M in sorted({(mods[i].K_right, mods[i].out_features) for i in fac}):
                 idx = [i for i in fac if (mods[i].K_right, mods[i].out_features) == (Kf, M)]
                 xf = (_lib.GqQtipXf * len(idx))(*[_lib.GqQtipXf(ysl[i].data_ptr(), f32(mods[i].SV, 32.0), table(mods[i].had_right), resid, outs[i])
@@ -542,6 +544,7 @@ class Transformer(nn.Module):
         # acquire fences around the per-linear counter (L2 write-back + invalidate on 8 XCDs) cost ~7 us per launch, more than the
         # launch they save.
         one_launch = os.environ.get("GQ_QTIP_ONE_LAUNCH", "0") != "0"
+        out_seg = os.environ.get("GQ_QTIP_OUT_SEG", "1") != "0"
         # GQ_QTIP_ATTN_FOLD (default ON): the transform-out of q / k / v runs inside the attention launch -- every head block needs
         # head_dim of the outputs: the segments combined with the signs of its row, then one head_dim-point transform (equal to
         # gq_qtip_linear_out up to fp32 rounding) --: one launch (4.8 us) per layer less.  Needs power-of-two q / k / v widths.

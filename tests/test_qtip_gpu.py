@@ -341,6 +341,34 @@ def test_qtip_native_decode_matches_module_forward():
             assert int(got.argmax()) == int(ref[p].argmax()) or err < 5e-3
 
 
+@pytest.mark.parametrize("Ms,parts,resid", [([4096], 1, True), ([4096, 1024, 1024], 1, False), ([8192], 2, True), ([128], 1, False), ([2048, 4096], 3, True)])
+def test_segmented_transform_out_matches_the_one_block_form(Ms, parts, resid):
+    """gq_qtip_linear_out_seg (M / 128 blocks per linear: segments combined with the signs of the block's Sylvester row, one 128-point
+    transform) against gq_qtip_linear_out (one block, the full butterflies): the same additions in another order -- outputs agree to
+    fp32 rounding, i.e. a one-ulp fp16 flip here and there"""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d).manual_seed(sum(Ms) + parts)
+    outs = {}
+    ys = [torch.randn(parts, M, device=d, generator=g) * 3 for M in Ms]
+    svs = [(torch.randn(M, device=d, generator=g) * 0.3 + 1) * 32 for M in Ms]
+    res = [torch.randn(M, device=d, generator=g).half() if resid else None for M in Ms]
+    for name in ("gq_qtip_linear_out", "gq_qtip_linear_out_seg"):
+        o = [torch.full((M,), float("nan"), dtype=torch.float16, device=d) for M in Ms]
+        arr = (_lib.GqQtipOut * len(Ms))(*[_lib.GqQtipOut(ys[i].data_ptr(), svs[i].data_ptr(), res[i].data_ptr() if resid else None, o[i].data_ptr(), M, parts)
+                                           for i, M in enumerate(Ms)])
+        _lib.check(getattr(L, name)(len(Ms), arr, _lib.current_stream_ptr()), name)
+        torch.cuda.synchronize()
+        outs[name] = [t.float() for t in o]
+    for a, b in zip(outs["gq_qtip_linear_out"], outs["gq_qtip_linear_out_seg"]):
+        assert bool(torch.isfinite(b).all())
+        # one fp16 ulp of the larger magnitude
+        tol = torch.maximum(a.abs(), b.abs()) * 2.0**-10 + 1e-6
+        assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
+        assert float((a != b).float().mean()) < 0.02  # and rarely at all
+
+
 @pytest.mark.parametrize("heads", [(8, 4, 1024), (32, 32, 4096), (16, 2, 2048)])
 def test_attention_with_the_qkv_transform_out_folded_in(monkeypatch, heads):
     """gq_attn_decode_qtip (the transform-out of q / k / v inside the attention launch: per head, the segments of the sums combined

@@ -100,9 +100,10 @@ def anyprec_dequant(qweight, lut, bitwidth):
 def anyprec_gemm_supported(x, qweight, bitwidth):
     """True when a seq_len > 1 call should take the fused prefill GEMM (gq_anyprec_gemm).  It serves GPU fp16 tensors, 2..4
     bits, K % 64 == 0.  GQ_PREFILL_FUSED=1 sends every such call to it, =0 none; by default ("auto") only the calls it was
-    measured faster on than the reference's two steps (dequantise + hipBLASLt GEMM; profiles/r02_prefill_gemm.txt): large
-    matrices with short prompts, where writing and re-reading the dense copy of W dominates (8B gate/up at S <= 128: 1.1-1.3x;
-    at S = 2048 the fused kernel reaches 0.25-0.31 of the fp16 MFMA peak against ~0.48 for hipBLASLt)."""
+    measured faster on than the reference's two steps (dequantise + hipBLASLt GEMM; profiles/r03_prefill_gemm.txt): large
+    matrices with prompts up to a few hundred tokens, where writing and re-reading the dense copy of W dominates (8B gate/up,
+    2 / 3 / 4 bits: 2.0 / 1.9 / 1.7x at S = 128, 1.2x at S = 512; at S = 2048 the fused kernel reaches 0.37-0.44 of the fp16
+    MFMA peak against ~0.5 for hipBLASLt and loses by 12-30 %)."""
     import os
     if not (x.is_cuda and qweight.is_cuda and x.dtype == torch.float16 and 2 <= int(bitwidth) <= 4 and x.shape[-1] % 64 == 0):
         return False
@@ -110,7 +111,7 @@ def anyprec_gemm_supported(x, qweight, bitwidth):
     if mode in ("0", "1"):
         return mode == "1"
     rows = x.numel() // x.shape[-1]
-    return rows <= 160 and qweight.size(1) * x.shape[-1] >= 100_000_000
+    return rows <= 640 and qweight.size(1) * x.shape[-1] >= 100_000_000
 
 
 def anyprec_gemm(x, qweight, lut, bitwidth):

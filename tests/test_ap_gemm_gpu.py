@@ -73,6 +73,31 @@ def test_gemm_full_size_sampled_rows(oracle, bits, N, K, S):
     _check(got, X, q, lut, bits, oracle, rows=rows)
 
 
+@pytest.fixture
+def _shape_env():
+    from guidedquant_amd import _lib
+    yield
+    os.environ.pop("GQ_GEMM_SHAPE", None)
+    _lib.lib().gq_reset_env_cache()
+
+
+@pytest.mark.parametrize("shape", [0, 14, 24, 18, 28])
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_gemm_every_tile_shape(oracle, _shape_env, bits, shape):
+    """the dispatcher picks a wave / block tile per problem (csrc/ap_gemm.hip::launch_gemm); here every one of them is forced
+    (GQ_GEMM_SHAPE) on problems with row, token and K tails (K % 256 == 0: the pipelined kernel; 4-bit 24 falls back to 14)"""
+    from guidedquant_amd import _lib
+    os.environ["GQ_GEMM_SHAPE"] = str(shape)
+    _lib.lib().gq_reset_env_cache()
+    for N, K, S in [(520, 2304, 300), (260, 4096, 257), (96, 768, 130)]:
+        rng = np.random.default_rng(bits * 131 + shape + N)
+        codes = rng.integers(0, 1 << bits, (N, K), dtype=np.uint8)
+        q = oracle.ap_pack(codes, bits)
+        lut = (rng.normal(0, 1, (N, 1 << bits)) * 10.0**rng.integers(-3, 1, (N, 1))).astype(np.float16)
+        X = (rng.normal(0, 1, (S, K)) * np.where(rng.random((S, K)) < 0.02, 20.0, 1.0)).astype(np.float16)
+        _check(_gemm(X, q, lut, bits), X, q, lut, bits, oracle)
+
+
 def test_gemm_is_deterministic_and_row_independent(oracle):
     """size-independent properties: replays are bit-identical; a token's output row does not depend on what else is in the batch"""
     from guidedquant_amd import pack

@@ -439,7 +439,44 @@ def other_config_records(dev, steps=200, warmup=40):
         out["llama33_70b_2bit_1gpu"] = one(PP_MODEL, "ap", 2)[0]
     except Exception as e:
         out["llama33_70b_2bit_1gpu"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    try:  # the seq_len > 1 branch of APLinear.forward on the 8B gate/up matrix
+        out["prefill_gemm_w1w3_2bit"] = prefill_records(dev)
+    except Exception as e:
+        out["prefill_gemm_w1w3_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return out
+
+
+def prefill_records(dev, bits=2, N=28672, K=4096):
+    """the fused-dequant MFMA GEMM (gq_anyprec_gemm) against the reference's two steps (anyprec_dequant -> matmul = hipBLASLt) at
+    three prompt lengths; HIP events over 20 back-to-back launches, best of 3; `frac` of the 2.5 PFLOP/s dense fp16 MFMA peak"""
+    import torch
+    from guidedquant_amd import ap_gemv
+    q = torch.randint(-2**31, 2**31 - 1, (bits, N, K // 32), dtype=torch.int32, device=dev)
+    lut = (torch.randn(N, 1 << bits, device=dev) * 0.02).half().sort(dim=1).values.contiguous()
+
+    def timed(fn, iters=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(3):
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+        return best
+
+    rows = []
+    for S in (128, 512, 2048):
+        x = torch.randn(S, K, device=dev).half()
+        t_f = timed(lambda: ap_gemv.anyprec_gemm(x, q, lut, bits))
+        t_r = timed(lambda: torch.matmul(x, ap_gemv.anyprec_dequant(q, lut, bits).T))
+        fl = 2.0 * S * N * K
+        rows.append({"S": S, "fused_us": round(t_f, 1), "dequant_matmul_us": round(t_r, 1), "fused_TFLOPs": round(fl / t_f / 1e6, 1),
+                     "roofline": {"bound": "mfma", "achieved": round(fl / t_f / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / t_f / 1e6 / 2500.0, 4)}})
+    return {"N": N, "K": K, "bits": bits, "dtype": "f16", "by_prompt_length": rows}
 
 
 # ---------------------------------------------------------------------------------------------------------- pipeline

@@ -98,12 +98,13 @@ def anyprec_dequant(qweight, lut, bitwidth):
 
 
 def anyprec_gemm_supported(x, qweight, bitwidth):
-    """True when a seq_len > 1 call should take the fused prefill GEMM (gq_anyprec_gemm).  It serves GPU fp16 tensors, 2..4
+    """True when a seq_len > 1 call should take the fused prefill GEMM (gq_anyprec_gemm_ws).  It serves GPU fp16 tensors, 2..4
     bits, K % 64 == 0.  GQ_PREFILL_FUSED=1 sends every such call to it, =0 none; by default ("auto") only the calls it was
-    measured faster on than the reference's two steps (dequantise + hipBLASLt GEMM; profiles/r03_prefill_gemm.txt): large
-    matrices with prompts up to a few hundred tokens, where writing and re-reading the dense copy of W dominates (8B gate/up,
-    2 / 3 / 4 bits: 2.0 / 1.9 / 1.7x at S = 128, 1.2x at S = 512; at S = 2048 the fused kernel reaches 0.37-0.44 of the fp16
-    MFMA peak against ~0.5 for hipBLASLt and loses by 12-30 %)."""
+    measured faster on than the reference's two steps (dequantise + hipBLASLt GEMM; profiles/r03_prefill_gemm.txt, 8B shapes):
+    every matrix up to 160 rows (S = 128, 2-bit: wqkv 25 vs 44 us, wo 21 vs 37, gate/up 50 vs 97, down 36 vs 83 -- K split over
+    fp32 partial sums where the grid is short), up to 640 rows every matrix at 2 / 3 bits and the large ones (gate/up) at 4 bits
+    (S = 512, 2-bit: 48 vs 52, 38 vs 41, 125 vs 158, 84 vs 101); longer prompts keep the two steps (S = 2048: the fused kernel
+    reaches 0.35-0.43 of the fp16 MFMA peak against ~0.5 for hipBLASLt and loses by 12-30 %)."""
     import os
     if not (x.is_cuda and qweight.is_cuda and x.dtype == torch.float16 and 2 <= int(bitwidth) <= 4 and x.shape[-1] % 64 == 0):
         return False
@@ -111,7 +112,9 @@ def anyprec_gemm_supported(x, qweight, bitwidth):
     if mode in ("0", "1"):
         return mode == "1"
     rows = x.numel() // x.shape[-1]
-    return rows <= 640 and qweight.size(1) * x.shape[-1] >= 100_000_000
+    if rows <= 160:
+        return True
+    return rows <= 640 and (int(bitwidth) <= 3 or qweight.size(1) * x.shape[-1] >= 100_000_000)
 
 
 def anyprec_gemm(x, qweight, lut, bitwidth):
@@ -129,8 +132,11 @@ def anyprec_gemm(x, qweight, lut, bitwidth):
     x2 = x.reshape(-1, K).contiguous()
     out = torch.empty((x2.size(0), N), dtype=torch.float16, device=x.device)
     with _dev_guard(qweight):
-        rc = _lib.lib().gq_anyprec_gemm(x2.data_ptr(), out.data_ptr(), qweight.data_ptr(), lut.data_ptr(), x2.size(0), N, K, bitwidth,
-                                        _lib.current_stream_ptr())
+        # short grids split K over fp32 partial sums (gq_anyprec_gemm_ws): the workspace comes from torch's caching allocator
+        wsb = int(_lib.lib().gq_anyprec_gemm_ws_bytes(x2.size(0), N, K, bitwidth))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+        rc = _lib.lib().gq_anyprec_gemm_ws(x2.data_ptr(), out.data_ptr(), qweight.data_ptr(), lut.data_ptr(), x2.size(0), N, K, bitwidth,
+                                           ws.data_ptr() if wsb else None, wsb, _lib.current_stream_ptr())
     _lib.check(rc, "anyprec_gemm")
     return out.reshape(*x.shape[:-1], N)
 

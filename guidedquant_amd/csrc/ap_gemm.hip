@@ -291,9 +291,9 @@ constexpr u32 P_RING = 4u;  // stages in the ring (16 KiB each for 128 tokens, 3
 // hides about 5 other instructions per MFMA (profiles/r03_prefill_gemm_counters.txt), so the shape of choice is 1 x 8 with 8
 // waves (two per SIMD, 128 accumulator registers each): 2.5 decode instructions + 1 ds_read_b128 per MFMA at 2 bits.
 template <int BITS, int RF, int CF, int NW>
-__global__ void __launch_bounds__(64 * NW, (RF * CF == 16 || NW == 8) ? 1 : 2) ap_gemm_pipe_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ out,
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) ap_gemm_pipe_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ out,
                                                                const u32 *__restrict__ qw, const uint16_t *__restrict__ lut, u32 S,
-                                                               u32 N, u32 K, u32 dbg, u32 nbx, u32 ntiles) {
+                                                               u32 N, u32 K, u32 dbg, u32 nbx, u32 ntiles, u32 gper, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // P_RING slots
     const u32 tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, r = lane & 31u, g = lane >> 5;
     constexpr u32 BT = 32u * CF, P_SLOT = BT * 128u, DSPAN = BT / 8u / (u32)NW;  // DSPAN: 1 KiB spans of a stage per wave
@@ -305,11 +305,15 @@ __global__ void __launch_bounds__(64 * NW, (RF * CF == 16 || NW == 8) ? 1 : 2) a
     // 4.3 TB/s of x traffic at S = 2048 on the 8B gate/up matrix, the bound of that version.
     const u32 per_xcd = (ntiles + 7u) >> 3, tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
-    const u32 bx = tile % nbx, by = tile / nbx;
+    // (split K, short grids: tile = (K range ks, token block, row block); range ks covers the groups [ks gper, (ks + 1) gper) and
+    // leaves its fp32 sums in part[ks][S][N] for gq's reduce kernel -- `part` null: the whole K here, fp16 out)
+    const u32 ntxy = nbx * ((S + 32u * CF - 1u) / (32u * CF)), ks = tile / ntxy, txy = tile - ks * ntxy;
+    const u32 bx = txy % nbx, by = txy / nbx;
     const u32 n0 = bx * (32u * RF * NW) + wave * (32u * RF), s0 = by * BT;
     const u32 wpr = K / 32u, nfull = K / 1024u, eff = (K % 1024u) / 32u;
     const u32 hwt = eff >> 1, tail_groups = (hwt + 3u) >> 2;
-    const u32 ngroups = 4u * nfull + tail_groups, nst = 4u * ngroups;  // group = (chunk, q0): 4 stages (byte lanes c)
+    const u32 ngroups_all = 4u * nfull + tail_groups;  // group = (chunk, q0): 4 stages (byte lanes c)
+    const u32 g0 = ks * gper, ngroups = min(ngroups_all, g0 + gper), nst = 4u * ngroups;  // this block: groups [g0, ngroups), stages [4 g0, nst)
     const u32 plane_bytes = N * wpr * 4u;
 
     const u32x4 rx = g_rsrc(x + (size_t)s0 * K, min(BT, S - s0) * K * 2u);
@@ -383,8 +387,8 @@ __global__ void __launch_bounds__(64 * NW, (RF * CF == 16 || NW == 8) ? 1 : 2) a
     };
 
     // prologue: planes of group 0, stages 0..2
-    issue_planes(0u);
-    for (u32 st = 0; st < 3u; st++)
+    issue_planes(g0);
+    for (u32 st = 4u * g0; st < 4u * g0 + 3u; st++)
         if (st < nst) issue_stage(st);
     g_wait_vm<0>();
     __syncthreads();
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(64 * NW, (RF * CF == 16 || NW == 8) ? 1 : 2) a
             stage_end(4u * gi + (u32)c);
         }
     };
-    for (u32 gi = 0; gi < ngroups; gi++) group_full(gi);  // K % 256 == 0 (host): the tail chunk's groups are full as well
+    for (u32 gi = g0; gi < ngroups; gi++) group_full(gi);  // K % 256 == 0 (host): the tail chunk's groups are full as well
 
 #pragma unroll
     for (int f = 0; f < RF; f++)
@@ -479,6 +483,17 @@ __global__ void __launch_bounds__(64 * NW, (RF * CF == 16 || NW == 8) ? 1 : 2) a
             for (int rg = 0; rg < 4; rg++) {
                 const u32 nn = n0 + 32u * (u32)f + 8u * (u32)rg + 4u * g;
                 if (nn >= N) continue;
+                if (part) {  // fp32 partial sums of this K range
+                    float *dst = part + ((size_t)ks * S + s) * N + nn;
+                    if (nn + 3u < N && (N & 3u) == 0u) {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(acc[f][j][4 * rg], acc[f][j][4 * rg + 1], acc[f][j][4 * rg + 2], acc[f][j][4 * rg + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (nn + (u32)e < N) dst[e] = acc[f][j][4 * rg + e];
+                    }
+                    continue;
+                }
                 uint16_t h[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) h[e] = __builtin_bit_cast(uint16_t, (_Float16)acc[f][j][4 * rg + e]);
@@ -494,32 +509,79 @@ __global__ void __launch_bounds__(64 * NW, (RF * CF == 16 || NW == 8) ? 1 : 2) a
         }
 }
 
+// out[i] = fp16(sum over the K ranges of part[ks][i]) in range order: one rounding, as the single-pass kernel
+__global__ void __launch_bounds__(256) gemm_reduce_kernel(const float *__restrict__ part, uint16_t *__restrict__ out, u32 total, u32 nks) {
+    const u32 i = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (i >= total) return;
+    if (i + 3u < total && (total & 3u) == 0u) {
+        float4 a = *reinterpret_cast<const float4 *>(part + i);
+        for (u32 k = 1; k < nks; k++) {
+            const float4 b = *reinterpret_cast<const float4 *>(part + (size_t)k * total + i);
+            a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        const u32 lo = (u32)__builtin_bit_cast(uint16_t, (_Float16)a.x) | ((u32)__builtin_bit_cast(uint16_t, (_Float16)a.y) << 16);
+        const u32 hi = (u32)__builtin_bit_cast(uint16_t, (_Float16)a.z) | ((u32)__builtin_bit_cast(uint16_t, (_Float16)a.w) << 16);
+        *reinterpret_cast<uint2 *>(out + i) = make_uint2(lo, hi);
+    } else {
+        for (u32 e = i; e < total && e < i + 4u; e++) {
+            float a = part[e];
+            for (u32 k = 1; k < nks; k++) a += part[(size_t)k * total + e];
+            out[e] = __builtin_bit_cast(uint16_t, (_Float16)a);
+        }
+    }
+}
+
 template <int BITS, int RF, int CF, int NW>
-int launch_gemm_pipe(const void *x, void *out, const uint32_t *qw, const void *lut, u32 S, u32 N, u32 K, hipStream_t s) {
+int launch_gemm_pipe(const void *x, void *out, const uint32_t *qw, const void *lut, u32 S, u32 N, u32 K, hipStream_t s, u32 nks = 1u,
+                     float *part = nullptr) {
     static GqPerDeviceOnce once;
     auto kern = ap_gemm_pipe_kernel<BITS, RF, CF, NW>;
     constexpr u32 BT = 32u * CF;
     const size_t smem = (size_t)P_RING * BT * 128u;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)smem));
     constexpr u32 BR = 32u * RF * NW;
-    const u32 nbx = (N + BR - 1u) / BR, ntiles = nbx * ((S + BT - 1u) / BT);
+    const u32 ngroups = K / 256u, gper = (ngroups + nks - 1u) / nks, nks_eff = (ngroups + gper - 1u) / gper;
+    const u32 nbx = (N + BR - 1u) / BR, ntiles = nbx * ((S + BT - 1u) / BT) * nks_eff;
     dim3 grid(8u * ((ntiles + 7u) / 8u)), block(64 * NW);
     hipLaunchKernelGGL(kern, grid, block, smem, s, (const uint16_t *)x, (uint16_t *)out, qw, (const uint16_t *)lut, S, N, K, (u32)gq_env_int("GQ_GEMM_DBG", 0),
-                       nbx, ntiles);
+                       nbx, ntiles, gper, nks_eff > 1u ? part : nullptr);
     GQ_HIP_CHECK(hipGetLastError());
+    if (nks_eff > 1u) {
+        const u32 total = S * N;
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((total / 4u + 256u) / 256u), dim3(256), 0, s, part, (uint16_t *)out, total, nks_eff);
+        GQ_HIP_CHECK(hipGetLastError());
+    }
     return GQ_OK;
 }
 
-// Shape of the wave / block tile (GQ_GEMM_SHAPE forces one: 14, 24, 18, 28 = RF, CF of the table; 0 = the first kernel):
+// Shape of the wave / block tile (GQ_GEMM_SHAPE forces one: 14, 24, 18 = RF, CF of the table; 0 = the first kernel):
 //   1 x 4, 4 waves  128 rows x 128 tokens  the most blocks: small grids
 //   2 x 4, 4 waves  256 rows x 128 tokens  2- and 3-bit once there is a block per CU: half the B reads per MFMA
 //   1 x 8, 8 waves  256 rows x 256 tokens  4-bit (its decode is 2.5 x the 2-bit one: twice the MFMAs per decoded fragment)
-//   2 x 8, 4 waves  256 rows x 256 tokens  one wave per SIMD, 256 accumulator registers: measured slower, kept for comparison
+//   (2 x 8 with 4 waves -- one wave per SIMD, 256 accumulator registers -- was built and measured slower: DESIGN.md section 4)
+// the pipelined kernel: K-steps in whole groups of 4 (K % 256 == 0: every model width here), planes and a token slab of x
+// addressed through 32-bit buffer offsets; other shapes keep the first kernel
+bool gemm_pipe_ok(u32 N, u32 K, int bits) {
+    return K % 256u == 0u && (uint64_t)bits * N * (K / 8u) < 0x7FFFFFFFull && 256ull * K * 2u < 0x7FFFFFFFull;
+}
+// K ranges for a short grid (1 x 4 tile, fewer blocks than CUs): about 1.5 blocks per CU, at least 1024 weights per range
+u32 gemm_plan_ksplit(u32 S, u32 N, u32 K, int bits) {
+    if (!gemm_pipe_ok(N, K, bits) || gq_env_int("GQ_GEMM_SHAPE", -1) >= 0) return 1u;
+    const int env = gq_env_int("GQ_GEMM_KSPLIT", -1);
+    const u32 cus = (u32)gq_cu_count(), t14 = ((N + 127u) / 128u) * ((S + 127u) / 128u), ngroups = K / 256u;
+    u32 nks = env >= 0 ? (u32)env : (t14 >= cus ? 1u : (3u * cus + 2u * t14 - 1u) / (2u * t14));
+    if (nks > ngroups / 4u) nks = ngroups / 4u;
+    if (nks > 16u) nks = 16u;
+    if (nks <= 1u) return 1u;
+    const u32 gper = (ngroups + nks - 1u) / nks;
+    return (ngroups + gper - 1u) / gper;
+}
+
 template <int BITS>
-int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u32 S, u32 N, u32 K, hipStream_t s) {
-    // the pipelined kernel: K-steps in whole groups of 4 (K % 256 == 0: every model width here), planes and a token slab of
-    // x addressed through 32-bit buffer offsets; other shapes keep the first kernel
-    const bool pipe = K % 256u == 0u && (uint64_t)BITS * N * (K / 8u) < 0x7FFFFFFFull && 256ull * K * 2u < 0x7FFFFFFFull;
+int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u32 S, u32 N, u32 K, hipStream_t s, float *ws, size_t ws_bytes) {
+    const bool pipe = gemm_pipe_ok(N, K, BITS);
+    const u32 nks = ws ? gemm_plan_ksplit(S, N, K, BITS) : 1u;
+    if (nks > 1u && ws_bytes >= (size_t)nks * S * N * 4u) return launch_gemm_pipe<BITS, 1, 4, 4>(x, out, qw, lut, S, N, K, s, nks, ws);
     int shape = gq_env_int("GQ_GEMM_SHAPE", -1);
     if (shape < 0) {
         const u32 cus = (u32)gq_cu_count();
@@ -537,7 +599,6 @@ int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u
     if (!pipe || shape == 0) return launch_gemm_first<BITS>(x, out, qw, lut, S, N, K, s);
     switch (shape) {
         case 18: return launch_gemm_pipe<BITS, 1, 8, 8>(x, out, qw, lut, S, N, K, s);
-        case 28: return launch_gemm_pipe<BITS, 2, 8, 4>(x, out, qw, lut, S, N, K, s);
         case 24:
             if constexpr (BITS != 4) return launch_gemm_pipe<BITS, 2, 4, 4>(x, out, qw, lut, S, N, K, s);  // (4-bit: does not fit 256 registers)
             [[fallthrough]];
@@ -546,18 +607,31 @@ int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u
 }
 }  // namespace
 
-extern "C" int gq_anyprec_gemm(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t S, uint32_t N,
-                               uint32_t K, int bits, void *stream) {
+extern "C" size_t gq_anyprec_gemm_ws_bytes(uint32_t S, uint32_t N, uint32_t K, int bits) {
+    if (bits < 2 || bits > 4 || K == 0 || S == 0 || N == 0) return 0;
+    const u32 nks = gemm_plan_ksplit(S, N, K, bits);
+    return nks > 1u ? (size_t)nks * S * N * 4u : 0;
+}
+
+extern "C" int gq_anyprec_gemm_ws(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t S, uint32_t N, uint32_t K,
+                                  int bits, void *workspace, size_t ws_bytes, void *stream) {
     if (bits < 2 || bits > 4) return gq_fail(GQ_ENOTSUP, "gq_anyprec_gemm: bits must be 2, 3 or 4 (wider: dequantise + GEMM).");
     if (K == 0 || K % 64u) return gq_fail(GQ_ENOTSUP, "gq_anyprec_gemm: K must be a positive multiple of 64.");
     if (S == 0 || N == 0) return gq_fail(GQ_EINVAL, "gq_anyprec_gemm: empty problem.");
     if (!x || !out || !qweight || !lut) return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (((uintptr_t)x | (uintptr_t)qweight) & 15u || ((uintptr_t)out & 7u) || ((uintptr_t)lut & 3u))
         return gq_fail(GQ_EINVAL, "gq_anyprec_gemm: x / qweight must be 16-byte, out 8-byte aligned.");
+    if (workspace && ((uintptr_t)workspace & 15u)) return gq_fail(GQ_EINVAL, "gq_anyprec_gemm_ws: workspace must be 16-byte aligned.");
     hipStream_t s = (hipStream_t)stream;
+    float *ws = (float *)workspace;
     switch (bits) {
-        case 2: return launch_gemm<2>(x, out, qweight, lut, S, N, K, s);
-        case 3: return launch_gemm<3>(x, out, qweight, lut, S, N, K, s);
-        default: return launch_gemm<4>(x, out, qweight, lut, S, N, K, s);
+        case 2: return launch_gemm<2>(x, out, qweight, lut, S, N, K, s, ws, ws_bytes);
+        case 3: return launch_gemm<3>(x, out, qweight, lut, S, N, K, s, ws, ws_bytes);
+        default: return launch_gemm<4>(x, out, qweight, lut, S, N, K, s, ws, ws_bytes);
     }
+}
+
+extern "C" int gq_anyprec_gemm(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t S, uint32_t N,
+                               uint32_t K, int bits, void *stream) {
+    return gq_anyprec_gemm_ws(x, out, qweight, lut, S, N, K, bits, nullptr, 0, stream);
 }

@@ -18,6 +18,7 @@
 #ifndef GQ_HIP_H
 #define GQ_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -107,6 +108,16 @@ int gq_lnq_cd_block(const float *W, const float *B, const float *Hn, const float
  */
 int gq_anyprec_gemm(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t S, uint32_t N, uint32_t K,
                     int bits, void *stream);
+/*
+ * The same GEMM with a caller-supplied fp32 workspace for SHORT GRIDS (fewer 128 x 128 output tiles than compute units: a
+ * prompt of <= 512 tokens on the 4096-row matrices): K is then split over up to 16 ranges, each block leaves fp32 partial sums
+ * in the workspace and a second launch adds the ranges in order and rounds once to fp16 (results equal to gq_anyprec_gemm's up
+ * to the fp32 summation order).  gq_anyprec_gemm_ws_bytes = the workspace this problem would use (0: no split planned);
+ * a null / too small workspace runs the single pass.  workspace 16-byte aligned.
+ */
+size_t gq_anyprec_gemm_ws_bytes(uint32_t S, uint32_t N, uint32_t K, int bits);
+int gq_anyprec_gemm_ws(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t S, uint32_t N, uint32_t K,
+                       int bits, void *workspace, size_t ws_bytes, void *stream);
 
 /*
  * Host (CPU) twins of the two Any-Precision entry points: same arguments with HOST pointers, no stream; `nthreads` <= 0

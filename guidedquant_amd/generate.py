@@ -44,7 +44,13 @@ def sample(logits, temperature: float = 1.0, top_k: Optional[int] = None):
 
 
 def prefill(model: Transformer, x: torch.Tensor, input_pos: torch.Tensor, **sampling_kwargs) -> torch.Tensor:
-    logits = model(x, input_pos)
+    """input_pos = arange(0, T) (generate()).  Any-Precision models on the GPU take the HIP prompt pass (Transformer.prefill_native:
+    logits of the last token only -- all that is sampled from); GQ_PREFILL_NATIVE=0 keeps the module forward."""
+    import os
+    if os.environ.get("GQ_PREFILL_NATIVE", "1") != "0" and model.cache_initialized and model.prefill_ready(x):
+        logits = model.prefill_native(x, input_pos, start=0, last_only=True)
+    else:
+        logits = model(x, input_pos)
     return sample(logits, **sampling_kwargs)[0]
 
 

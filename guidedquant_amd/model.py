@@ -677,6 +677,56 @@ class Transformer(nn.Module):
                                                 c.dim, self.norm.weight.data_ptr(), c.norm_eps, _lib.current_stream_ptr()), "lm_head")
         return b["logits"]
 
+    # ------------------------------------------------------------------------------------------------ prompt pass
+    def prefill_ready(self, idx: Tensor) -> bool:
+        """the HIP prompt pass serves what the fused decode step serves for Any-Precision models: fp16, batch 1, on the GPU"""
+        return (self._native_kind() == "ap" and idx.is_cuda and idx.numel() > 1 and (idx.dim() == 1 or idx.shape[0] == 1)
+                and self.config.head_dim % 16 == 0 and self.config.dim % 8 == 0 and self.config.dim <= 16384
+                and self.config.intermediate_size % 8 == 0)
+
+    def prefill_native(self, idx: Tensor, input_pos: Tensor, start: int = 0, last_only: bool = True) -> Tensor:
+        """The prompt pass (`Transformer.forward` with seq_len > 1, inference/model.py:206-266 semantics) with the element-wise
+        steps between the linears as ONE HIP launch each (csrc/prefill.hip: RMSNorm rows, RoPE + KV-cache write, silu * up)
+        instead of ~45 eager tensor ops per layer, the linears through `APLinear.forward` (fused prefill GEMM / split K /
+        the reference's two steps by size), attention over the keys [0, start + S) only instead of the whole cache.
+        `input_pos` must be arange(start, start + S) (what generate() passes; `start` is the host copy of its first element).
+        Same fp16 rounding points as the module forward: logits agree up to the summation order of the fp32 sums.
+        last_only: logits of the last prompt token only, [1, 1, V] -- all generate() samples from -- else [1, S, V]."""
+        from . import _lib
+        L = _lib.lib()
+        cfg = self.config
+        S, D, H, Hkv, hd, inter = idx.numel(), cfg.dim, cfg.n_head, cfg.n_local_heads, cfg.head_dim, cfg.intermediate_size
+        T = start + S
+        assert self.prefill_ready(idx) and input_pos.numel() == S and input_pos.dtype == torch.int32 and T <= self.max_seq_length
+        dev = idx.device
+        st = _lib.current_stream_ptr()
+        x = self.tok_embeddings(idx.view(1, S)).view(S, D)
+        xn = torch.empty_like(x)
+        q = torch.empty((H, S, hd), dtype=torch.float16, device=dev)
+        hbuf = torch.empty((S, inter), dtype=torch.float16, device=dev)
+        mask = None if start == 0 else self.causal_mask[None, None, input_pos.long(), :T]
+        rep = H // Hkv
+        with torch.cuda.device(dev):
+            for b in self.layers:
+                att, ff = b.attention, b.feed_forward
+                _lib.check(L.gq_rmsnorm_rows(x.data_ptr(), b.input_layernorm.weight.data_ptr(), xn.data_ptr(), S, D, b.input_layernorm.eps, st), "gq_rmsnorm_rows")
+                qkv = att.wqkv(xn.view(1, S, D)).view(S, -1)
+                kc, vc = att.kv_cache.k_cache, att.kv_cache.v_cache
+                _lib.check(L.gq_rope_cache_rows(qkv.data_ptr(), input_pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), q.data_ptr(),
+                                                kc.data_ptr(), vc.data_ptr(), S, H, Hkv, hd, kc.shape[2], st), "gq_rope_cache_rows")
+                k = kc[0, :, :T].unsqueeze(1).expand(Hkv, rep, T, hd).reshape(1, H, T, hd)
+                v = vc[0, :, :T].unsqueeze(1).expand(Hkv, rep, T, hd).reshape(1, H, T, hd)
+                y = F.scaled_dot_product_attention(q.unsqueeze(0), k, v, attn_mask=mask, dropout_p=0.0, is_causal=mask is None)
+                y = y.transpose(1, 2).reshape(1, S, H * hd)
+                x = x + att.wo(y).view(S, D)
+                _lib.check(L.gq_rmsnorm_rows(x.data_ptr(), b.post_attention_layernorm.weight.data_ptr(), xn.data_ptr(), S, D, b.post_attention_layernorm.eps, st),
+                           "gq_rmsnorm_rows")
+                gu = ff.w1w3(xn.view(1, S, D)).view(S, 2 * inter)
+                _lib.check(L.gq_silu_mul_rows(gu.data_ptr(), hbuf.data_ptr(), S, inter, 1 if getattr(ff.w1w3, "gq_row_pairs", False) else 0, st), "gq_silu_mul_rows")
+                x = x + ff.w2(hbuf.view(1, S, inter)).view(S, D)
+        x = x[-1:] if last_only else x
+        return self.output(self.norm(x)).view(1, -1, cfg.vocab_size)
+
     def decode_native(self, tok: Tensor, pos: Tensor) -> Tensor:
         """One bs=1 decode step.  tok, pos: int32 device tensors with one element.  Returns logits fp16 [1,1,V]
         (a persistent buffer, like the quantized linears' outputs).  Enqueues on the current stream only."""

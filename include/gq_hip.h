@@ -120,6 +120,22 @@ int gq_anyprec_gemm_ws(const void *x, void *out, const uint32_t *qweight, const 
                        int bits, void *workspace, size_t ws_bytes, void *stream);
 
 /*
+ * The element-wise steps of the prompt pass (seq_len > 1) between the prefill GEMMs, one launch each; fp16 rows, the fp16 rounding
+ * points of the tensor expressions they replace (`Transformer.forward`, inference/model.py:206-266):
+ *   gq_rmsnorm_rows     RMSNorm.forward (model.py:84-96) on S rows of D: (x.float() * rsqrt(mean(x^2) + eps)).half() * weight
+ *   gq_rope_cache_rows  apply_rotary_pos_emb (model.py:336-341) on the q and k parts of qkv [S][(n_head + 2 n_kv_head) head_dim],
+ *                       rotated q -> q_out [n_head][S][head_dim], rotated k and v -> the caches [n_kv_head][max_seq][head_dim] at
+ *                       pos[s] (KVCache.update, model.py:69-79; positions >= max_seq are not written)
+ *   gq_silu_mul_rows    F.silu(gate) * up (model.py:266) of y [S][2 inter] -> out [S][inter]; paired != 0: (gate_i, up_i) adjacent
+ *                       (the decode step's row order of the fused gate/up matrix), else gate = y[:, :inter], up = y[:, inter:]
+ * All pointers 16-byte aligned device pointers; D, inter multiples of 8 (D <= 16384), head_dim a multiple of 16.
+ */
+int gq_rmsnorm_rows(const void *x, const void *weight, void *out, uint32_t S, uint32_t D, float eps, void *stream);
+int gq_rope_cache_rows(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *q_out, void *k_cache, void *v_cache,
+                       uint32_t S, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, void *stream);
+int gq_silu_mul_rows(const void *y, void *out, uint32_t S, uint32_t inter, int paired, void *stream);
+
+/*
  * Host (CPU) twins of the two Any-Precision entry points: same arguments with HOST pointers, no stream; `nthreads` <= 0
  * uses the OpenMP default.  They serve BASELINE.json configs[0] ("CPU reference APLinear path via generate.py"): the module
  * semantics of inference/APLinear.py:35-60 with the tensors in host memory (the reference hard-codes 'cuda',

@@ -90,7 +90,7 @@ def lib():
         L.gq_anyprec_gemm.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, vp]
         L.gq_anyprec_gemm_ws.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, vp, ctypes.c_size_t, vp]
         L.gq_anyprec_gemm_ws_bytes.argtypes = [u32, u32, u32, i32]
-        L.gq_rmsnorm_rows.argtypes = [vp, vp, vp, u32, u32, f32, vp]
+        L.gq_rmsnorm_rows.argtypes = [vp, vp, vp, vp, u32, u32, f32, vp]
         L.gq_rope_cache_rows.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, vp]
         L.gq_silu_mul_rows.argtypes = [vp, vp, u32, u32, i32, vp]
         L.gq_anyprec_pack.argtypes = [vp, vp, u32, u32, i32, vp]

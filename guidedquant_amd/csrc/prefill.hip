@@ -3,7 +3,8 @@
 // `Transformer.forward` -> `TransformerBlock.forward` -> `Attention.forward` / `FeedForward.forward`).  At S = 128 the
 // module forward of the 8B model spends 10 of its 14.5 ms in launch overhead of those ops; the GEMMs take 4.2 ms.
 // Every kernel keeps the fp16 rounding points of the tensor expressions it replaces:
-//   gq_rmsnorm_rows     RMSNorm.forward (model.py:84-96):  (x.float() * rsqrt(mean(x^2) + eps)).half() * weight
+//   gq_rmsnorm_rows     RMSNorm.forward (model.py:84-96):  (x.float() * rsqrt(mean(x^2) + eps)).half() * weight, optionally
+//                       behind the residual add in front of it (TransformerBlock.forward, model.py:311-313: h = x + attn(..))
 //   gq_rope_cache_rows  apply_rotary_pos_emb (model.py:336-341) on q and k -- (q * cos) + (rotate_half(q) * sin), three fp16
 //                       operations -- and KVCache.update (model.py:69-79): k, v written at their positions
 //   gq_silu_mul_rows    FeedForward.forward (model.py:266):  F.silu(w1(x)) * w3(x), silu rounded to fp16 before the product
@@ -27,17 +28,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // one block (256 threads) per row; the row stays in registers between the two passes (D <= 256 * 8 * 8 = 16384)
-__global__ void __launch_bounds__(256) rmsnorm_rows_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+// delta != null: the residual add of the block in front (x = x + delta, one fp16 rounding, written back) rides along
+__global__ void __launch_bounds__(256) rmsnorm_rows_kernel(uint16_t *__restrict__ x, const uint16_t *__restrict__ delta, const uint16_t *__restrict__ w,
                                                            uint16_t *__restrict__ out, u32 D, float eps) {
     __shared__ float red[4];
     const u32 tid = threadIdx.x, row = blockIdx.x, nu = D / 8u;  // 16-byte units of the row
-    const uint4 *xr = reinterpret_cast<const uint4 *>(x + (size_t)row * D);
+    uint4 *xr = reinterpret_cast<uint4 *>(x + (size_t)row * D);
+    const uint4 *dr = reinterpret_cast<const uint4 *>(delta + (size_t)row * D);
     uint4 v[8];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const u32 u = tid + 256u * (u32)i;
         v[i] = u < nu ? xr[u] : make_uint4(0u, 0u, 0u, 0u);
+        if (delta && u < nu) {
+            const uint4 dv = dr[u];
+            const u32 xa[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, da[4] = {dv.x, dv.y, dv.z, dv.w};
+            u32 r[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const h16 lo = hbits((uint16_t)(xa[e] & 0xFFFF)) + hbits((uint16_t)(da[e] & 0xFFFF)), hi = hbits((uint16_t)(xa[e] >> 16)) + hbits((uint16_t)(da[e] >> 16));
+                r[e] = (u32)bitsh(lo) | ((u32)bitsh(hi) << 16);
+            }
+            v[i] = make_uint4(r[0], r[1], r[2], r[3]);
+            xr[u] = v[i];
+        }
         const u32 ww[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -161,12 +176,13 @@ __global__ void __launch_bounds__(256) silu_mul_rows_kernel(const uint16_t *__re
 }
 }  // namespace
 
-extern "C" int gq_rmsnorm_rows(const void *x, const void *weight, void *out, uint32_t S, uint32_t D, float eps, void *stream) {
+extern "C" int gq_rmsnorm_rows(void *x, const void *delta, const void *weight, void *out, uint32_t S, uint32_t D, float eps, void *stream) {
     if (!x || !weight || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if ((uintptr_t)delta & 15u) return gq_fail(GQ_EINVAL, "gq_rmsnorm_rows: 16-byte aligned pointers.");
     if (S == 0) return GQ_OK;
     if (D == 0 || D % 8u || D > 16384u) return gq_fail(GQ_ENOTSUP, "gq_rmsnorm_rows: D must be a multiple of 8, <= 16384.");
     if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) & 15u) return gq_fail(GQ_EINVAL, "gq_rmsnorm_rows: 16-byte aligned pointers.");
-    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, (const uint16_t *)weight, (uint16_t *)out, D, eps);
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, (uint16_t *)x, (const uint16_t *)delta, (const uint16_t *)weight, (uint16_t *)out, D, eps);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

@@ -700,16 +700,18 @@ class Transformer(nn.Module):
         assert self.prefill_ready(idx) and input_pos.numel() == S and input_pos.dtype == torch.int32 and T <= self.max_seq_length
         dev = idx.device
         st = _lib.current_stream_ptr()
-        x = self.tok_embeddings(idx.view(1, S)).view(S, D)
+        x = self.tok_embeddings(idx.view(1, S)).view(S, D).contiguous()
         xn = torch.empty_like(x)
         q = torch.empty((H, S, hd), dtype=torch.float16, device=dev)
         hbuf = torch.empty((S, inter), dtype=torch.float16, device=dev)
         mask = None if start == 0 else self.causal_mask[None, None, input_pos.long(), :T]
         rep = H // Hkv
+        pending = None  # the previous block's MLP output: its residual add rides in the next RMSNorm launch
         with torch.cuda.device(dev):
             for b in self.layers:
                 att, ff = b.attention, b.feed_forward
-                _lib.check(L.gq_rmsnorm_rows(x.data_ptr(), b.input_layernorm.weight.data_ptr(), xn.data_ptr(), S, D, b.input_layernorm.eps, st), "gq_rmsnorm_rows")
+                _lib.check(L.gq_rmsnorm_rows(x.data_ptr(), pending.data_ptr() if pending is not None else None, b.input_layernorm.weight.data_ptr(), xn.data_ptr(),
+                                             S, D, b.input_layernorm.eps, st), "gq_rmsnorm_rows")
                 qkv = att.wqkv(xn.view(1, S, D)).view(S, -1)
                 kc, vc = att.kv_cache.k_cache, att.kv_cache.v_cache
                 _lib.check(L.gq_rope_cache_rows(qkv.data_ptr(), input_pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), q.data_ptr(),
@@ -718,12 +720,13 @@ class Transformer(nn.Module):
                 v = vc[0, :, :T].unsqueeze(1).expand(Hkv, rep, T, hd).reshape(1, H, T, hd)
                 y = F.scaled_dot_product_attention(q.unsqueeze(0), k, v, attn_mask=mask, dropout_p=0.0, is_causal=mask is None)
                 y = y.transpose(1, 2).reshape(1, S, H * hd)
-                x = x + att.wo(y).view(S, D)
-                _lib.check(L.gq_rmsnorm_rows(x.data_ptr(), b.post_attention_layernorm.weight.data_ptr(), xn.data_ptr(), S, D, b.post_attention_layernorm.eps, st),
-                           "gq_rmsnorm_rows")
+                o = att.wo(y).view(S, D)
+                _lib.check(L.gq_rmsnorm_rows(x.data_ptr(), o.data_ptr(), b.post_attention_layernorm.weight.data_ptr(), xn.data_ptr(), S, D,
+                                             b.post_attention_layernorm.eps, st), "gq_rmsnorm_rows")
                 gu = ff.w1w3(xn.view(1, S, D)).view(S, 2 * inter)
                 _lib.check(L.gq_silu_mul_rows(gu.data_ptr(), hbuf.data_ptr(), S, inter, 1 if getattr(ff.w1w3, "gq_row_pairs", False) else 0, st), "gq_silu_mul_rows")
-                x = x + ff.w2(hbuf.view(1, S, inter)).view(S, D)
+                pending = ff.w2(hbuf.view(1, S, inter)).view(S, D)
+        x = x + pending
         x = x[-1:] if last_only else x
         return self.output(self.norm(x)).view(1, -1, cfg.vocab_size)
 

@@ -122,7 +122,8 @@ int gq_anyprec_gemm_ws(const void *x, void *out, const uint32_t *qweight, const 
 /*
  * The element-wise steps of the prompt pass (seq_len > 1) between the prefill GEMMs, one launch each; fp16 rows, the fp16 rounding
  * points of the tensor expressions they replace (`Transformer.forward`, inference/model.py:206-266):
- *   gq_rmsnorm_rows     RMSNorm.forward (model.py:84-96) on S rows of D: (x.float() * rsqrt(mean(x^2) + eps)).half() * weight
+ *   gq_rmsnorm_rows     RMSNorm.forward (model.py:84-96) on S rows of D: (x.float() * rsqrt(mean(x^2) + eps)).half() * weight;
+ *                       delta != NULL: the residual add in front of the norm rides along, x = x + delta (fp16, written back to x)
  *   gq_rope_cache_rows  apply_rotary_pos_emb (model.py:336-341) on the q and k parts of qkv [S][(n_head + 2 n_kv_head) head_dim],
  *                       rotated q -> q_out [n_head][S][head_dim], rotated k and v -> the caches [n_kv_head][max_seq][head_dim] at
  *                       pos[s] (KVCache.update, model.py:69-79; positions >= max_seq are not written)
@@ -130,7 +131,7 @@ int gq_anyprec_gemm_ws(const void *x, void *out, const uint32_t *qweight, const 
  *                       (the decode step's row order of the fused gate/up matrix), else gate = y[:, :inter], up = y[:, inter:]
  * All pointers 16-byte aligned device pointers; D, inter multiples of 8 (D <= 16384), head_dim a multiple of 16.
  */
-int gq_rmsnorm_rows(const void *x, const void *weight, void *out, uint32_t S, uint32_t D, float eps, void *stream);
+int gq_rmsnorm_rows(void *x, const void *delta, const void *weight, void *out, uint32_t S, uint32_t D, float eps, void *stream);
 int gq_rope_cache_rows(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *q_out, void *k_cache, void *v_cache,
                        uint32_t S, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, void *stream);
 int gq_silu_mul_rows(const void *y, void *out, uint32_t S, uint32_t inter, int paired, void *stream);

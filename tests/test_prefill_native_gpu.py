@@ -40,11 +40,20 @@ def test_rmsnorm_rows(S, D):
     want = norm(x)
     out = torch.empty_like(x)
     L = _lib()
-    L.check(L.lib().gq_rmsnorm_rows(x.data_ptr(), norm.weight.data_ptr(), out.data_ptr(), S, D, norm.eps, None), "gq_rmsnorm_rows")
+    L.check(L.lib().gq_rmsnorm_rows(x.data_ptr(), None, norm.weight.data_ptr(), out.data_ptr(), S, D, norm.eps, None), "gq_rmsnorm_rows")
     torch.cuda.synchronize()
     # the fp32 sum of squares is added in another order: where the normalised value flips by one fp16 ulp, its product with
     # a weight of up to 1.6 moves by up to two
     _ulp_close(out, want, ulps=2)
+    # with the residual add in front: x + delta (fp16) written back, then the same norm
+    delta = torch.randn(S, D, device=d, generator=g).half()
+    xs = x + delta
+    want2 = norm(xs)
+    x2 = x.clone()
+    L.check(L.lib().gq_rmsnorm_rows(x2.data_ptr(), delta.data_ptr(), norm.weight.data_ptr(), out.data_ptr(), S, D, norm.eps, None), "gq_rmsnorm_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(x2.view(torch.int16), xs.view(torch.int16))
+    _ulp_close(out, want2, ulps=2)
 
 
 @pytest.mark.parametrize("S,H,Hkv,hd,start", [(5, 8, 2, 64, 0), (130, 32, 8, 128, 0), (17, 4, 4, 128, 9)])

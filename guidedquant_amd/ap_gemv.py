@@ -102,7 +102,7 @@ def anyprec_gemm_supported(x, qweight, bitwidth):
     bits, K % 64 == 0.  GQ_PREFILL_FUSED=1 sends every such call to it, =0 none; by default ("auto") only the calls it was
     measured faster on than the reference's two steps (dequantise + hipBLASLt GEMM; profiles/r03_prefill_gemm.txt, 8B shapes):
     every matrix up to 160 rows (S = 128, 2-bit: wqkv 25 vs 44 us, wo 21 vs 37, gate/up 50 vs 97, down 36 vs 83 -- K split over
-    fp32 partial sums where the grid is short), up to 640 rows every matrix at 2 / 3 bits and the large ones (gate/up) at 4 bits
+    fp32 partial sums where the grid is short), up to 640 rows every matrix at 2 / 3 bits and the large ones (gate/up, down) at 4 bits
     (S = 512, 2-bit: 48 vs 52, 38 vs 41, 125 vs 158, 84 vs 101); longer prompts keep the two steps (S = 2048: the fused kernel
     reaches 0.35-0.43 of the fp16 MFMA peak against ~0.5 for hipBLASLt and loses by 12-30 %)."""
     import os
@@ -114,7 +114,7 @@ def anyprec_gemm_supported(x, qweight, bitwidth):
     rows = x.numel() // x.shape[-1]
     if rows <= 160:
         return True
-    return rows <= 640 and (int(bitwidth) <= 3 or qweight.size(1) * x.shape[-1] >= 100_000_000)
+    return rows <= 640 and (int(bitwidth) <= 3 or qweight.size(1) * x.shape[-1] >= 50_000_000)
 
 
 def anyprec_gemm(x, qweight, lut, bitwidth):

@@ -564,24 +564,40 @@ int launch_gemm_pipe(const void *x, void *out, const uint32_t *qw, const void *l
 bool gemm_pipe_ok(u32 N, u32 K, int bits) {
     return K % 256u == 0u && (uint64_t)bits * N * (K / 8u) < 0x7FFFFFFFull && 256ull * K * 2u < 0x7FFFFFFFull;
 }
-// K ranges for a short grid (1 x 4 tile, fewer blocks than CUs): about 1.5 blocks per CU, at least 1024 weights per range
-u32 gemm_plan_ksplit(u32 S, u32 N, u32 K, int bits) {
-    if (!gemm_pipe_ok(N, K, bits) || gq_env_int("GQ_GEMM_SHAPE", -1) >= 0) return 1u;
-    const int env = gq_env_int("GQ_GEMM_KSPLIT", -1);
-    const u32 cus = (u32)gq_cu_count(), t14 = ((N + 127u) / 128u) * ((S + 127u) / 128u), ngroups = K / 256u;
-    u32 nks = env >= 0 ? (u32)env : (t14 >= cus ? 1u : (3u * cus + 2u * t14 - 1u) / (2u * t14));
-    if (nks > ngroups / 4u) nks = ngroups / 4u;
-    if (nks > 16u) nks = 16u;
-    if (nks <= 1u) return 1u;
-    const u32 gper = (ngroups + nks - 1u) / nks;
-    return (ngroups + gper - 1u) / gper;
+// K ranges for a short grid (fewer 128 x 128 tiles than CUs), each at least 1024 weights: the 1 x 4 tile with about 1.5 blocks per
+// CU; with more than 128 tokens, at 4 bits or (3 bits and K >= 8192), the 8-wave 1 x 8 tile (half the decode per MFMA) with about one
+// block per CU when that gives every other CU a block at least (measured: profiles/r03_prefill_gemm.txt, split-K block).  GQ_GEMM_KSPLIT forces the range count, GQ_GEMM_KSHAPE (14 | 18) the tile.
+struct GemmSplit {
+    u32 nks;
+    int shape;
+};
+GemmSplit gemm_plan_ksplit(u32 S, u32 N, u32 K, int bits) {
+    GemmSplit none{1u, 14};
+    if (!gemm_pipe_ok(N, K, bits) || gq_env_int("GQ_GEMM_SHAPE", -1) >= 0) return none;
+    const int env = gq_env_int("GQ_GEMM_KSPLIT", -1), envshape = gq_env_int("GQ_GEMM_KSHAPE", -1);
+    const u32 cus = (u32)gq_cu_count(), t14 = ((N + 127u) / 128u) * ((S + 127u) / 128u), t18 = ((N + 255u) / 256u) * ((S + 255u) / 256u);
+    const u32 ngroups = K / 256u, cap = ngroups / 4u < 16u ? ngroups / 4u : 16u;
+    if (t14 >= cus && env < 0) return none;
+    auto ranges = [&](u32 want) {
+        u32 nks = env >= 0 ? (u32)env : want;
+        if (nks > cap) nks = cap;
+        if (nks <= 1u) return 1u;
+        const u32 gper = (ngroups + nks - 1u) / nks;
+        return (ngroups + gper - 1u) / gper;
+    };
+    const u32 n14 = ranges((3u * cus + 2u * t14 - 1u) / (2u * t14)), n18 = ranges((cus + t18 - 1u) / t18);
+    int shape = envshape == 14 || envshape == 18 ? envshape : ((bits >= 3 && S > 128u && 2u * t18 * n18 >= cus && (bits == 4 || ngroups >= 32u)) ? 18 : 14);
+    const u32 nks = shape == 18 ? n18 : n14;
+    if (nks <= 1u) return none;
+    return GemmSplit{nks, shape};
 }
 
 template <int BITS>
 int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u32 S, u32 N, u32 K, hipStream_t s, float *ws, size_t ws_bytes) {
     const bool pipe = gemm_pipe_ok(N, K, BITS);
-    const u32 nks = ws ? gemm_plan_ksplit(S, N, K, BITS) : 1u;
-    if (nks > 1u && ws_bytes >= (size_t)nks * S * N * 4u) return launch_gemm_pipe<BITS, 1, 4, 4>(x, out, qw, lut, S, N, K, s, nks, ws);
+    const GemmSplit sp = ws ? gemm_plan_ksplit(S, N, K, BITS) : GemmSplit{1u, 14};
+    if (sp.nks > 1u && ws_bytes >= (size_t)sp.nks * S * N * 4u)
+        return sp.shape == 18 ? launch_gemm_pipe<BITS, 1, 8, 8>(x, out, qw, lut, S, N, K, s, sp.nks, ws) : launch_gemm_pipe<BITS, 1, 4, 4>(x, out, qw, lut, S, N, K, s, sp.nks, ws);
     int shape = gq_env_int("GQ_GEMM_SHAPE", -1);
     if (shape < 0) {
         const u32 cus = (u32)gq_cu_count();
@@ -609,7 +625,7 @@ int launch_gemm(const void *x, void *out, const uint32_t *qw, const void *lut, u
 
 extern "C" size_t gq_anyprec_gemm_ws_bytes(uint32_t S, uint32_t N, uint32_t K, int bits) {
     if (bits < 2 || bits > 4 || K == 0 || S == 0 || N == 0) return 0;
-    const u32 nks = gemm_plan_ksplit(S, N, K, bits);
+    const u32 nks = gemm_plan_ksplit(S, N, K, bits).nks;
     return nks > 1u ? (size_t)nks * S * N * 4u : 0;
 }
 

@@ -443,7 +443,61 @@ def other_config_records(dev, steps=200, warmup=40):
         out["prefill_gemm_w1w3_2bit"] = prefill_records(dev)
     except Exception as e:
         out["prefill_gemm_w1w3_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    try:  # the prompt pass of generate() on the headline model: HIP pass vs the module forward with the reference's two GEMM steps
+        out["prompt_pass_8b_2bit"] = prompt_pass_records(dev)
+    except Exception as e:
+        out["prompt_pass_8b_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return out
+
+
+def prompt_pass_records(dev, bits=2, lengths=(128, 512)):
+    """ms per prompt through the whole 8B model (random init): `Transformer.prefill_native` (what generate() takes; logits of the
+    last token) and `Transformer.forward` with GQ_PREFILL_FUSED=0 (anyprec_dequant + matmul per linear, every eager op of
+    inference/model.py); HIP events around one call on an idle stream (host launch overhead included), best of 3"""
+    import gc
+    import torch
+    from guidedquant_amd.generate import load_model
+    torch.manual_seed(1234)
+    model = load_model(MODEL, dev, "ap", bits, random_init=True)
+    model.setup_caches(1, max(lengths) + 8)
+    assert model.native_ready()
+    rows = []
+    prev = os.environ.get("GQ_PREFILL_FUSED")
+    try:
+        for S in lengths:
+            x = torch.randint(0, 128000, (1, S), dtype=torch.int32, device=dev)
+            pos = torch.arange(S, dtype=torch.int32, device=dev)
+            res = {}
+            for mode in ("native", "module_two_steps"):
+                if mode == "native":
+                    os.environ.pop("GQ_PREFILL_FUSED", None)
+                    fn = lambda: model.prefill_native(x, pos, start=0, last_only=True)  # noqa: E731
+                else:
+                    os.environ["GQ_PREFILL_FUSED"] = "0"
+                    fn = lambda: model(x, pos)  # noqa: E731
+                with torch.no_grad():
+                    fn()
+                    torch.cuda.synchronize()
+                    best = 1e9
+                    for _ in range(3):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        fn()
+                        e1.record()
+                        e1.synchronize()
+                        best = min(best, e0.elapsed_time(e1))
+                res[mode] = best
+            rows.append({"prompt_tokens": S, "hip_prompt_pass_ms": round(res["native"], 3), "module_forward_reference_steps_ms": round(res["module_two_steps"], 3),
+                         "prompt_tokens_per_s": round(S / res["native"] * 1e3, 0)})
+    finally:
+        if prev is None:
+            os.environ.pop("GQ_PREFILL_FUSED", None)
+        else:
+            os.environ["GQ_PREFILL_FUSED"] = prev
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"model": MODEL, "bits": bits, "by_prompt_length": rows}
 
 
 def prefill_records(dev, bits=2, N=28672, K=4096):

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) rmsnorm_rows_kernel(uint16_t *__restrict_
     __shared__ float red[4];
     const u32 tid = threadIdx.x, row = blockIdx.x, nu = D / 8u;  // 16-byte units of the row
     uint4 *xr = reinterpret_cast<uint4 *>(x + (size_t)row * D);
-    const uint4 *dr = reinterpret_cast<const uint4 *>(delta + (size_t)row * D);
+    const uint4 *dr = delta ? reinterpret_cast<const uint4 *>(delta + (size_t)row * D) : nullptr;
     uint4 v[8];
     float ss = 0.f;
 #pragma unroll

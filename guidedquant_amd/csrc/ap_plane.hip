@@ -453,6 +453,12 @@ __device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
 #define PL_WPE 4
 #endif
 #ifndef PL_XFIRST
+#ifndef PL_BOOB
+#define PL_BOOB 1
+#endif
+#ifndef PL_LOOB
+#define PL_LOOB 1
+#endif
 #define PL_XFIRST 2  // local-image kernel: activations before tiles in the memory queue (0: round-2 order; 2: the later half of the waves also builds its image first)
 #endif
 #ifndef PL_PRIO
@@ -938,9 +944,20 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         }
         if (++cq_slot == S) cq_slot = 0;
         if (chunk < G.nchunks && !(a.xflags & 1u)) {
+            // MFMA columns without a piece (col >= 4 MB) must read zeros (measured: with real data in them -- the same addresses as
+            // columns 0..3, an LDS broadcast -- w1w3 runs 10.7 instead of 9.8 us: the matrix cores draw more power on non-zero
+            // operands and the chip clocks down).  PL_BOOB: their base address lies outside the workgroup's LDS allocation (192 KiB
+            // and up; this chip has 160 KiB), where ds_read returns zeros (tools/ubench/lds_oob.hip) -- so the (b, h) block and k + 64
+            // distances are immediates of the ds_reads for EVERY lane instead of per-lane address arithmetic (1.1 instructions per
+            // MFMA less in a loop that issues more than the SIMD hides).  PL_BOOB = 0: a 64-byte zero area and per-lane strides 0.
+#if PL_BOOB
+            const unsigned char *bbase = bcol ? bimg + mcol * IMGS + bimg4_off(chunk, 0u, 0u, col & 3u) + ((16u * kb) ^ bimg_swz(col & 3u)) : smem + 0x30000u;
+            mfma_chunk<BITS>(acc, Wd, bbase, 512u, 64u, sb);
+#else
             const unsigned char *bbase = bcol ? bimg + mcol * IMGS + bimg4_off(chunk, 0u, 0u, col & 3u) + ((16u * kb) ^ bimg_swz(col & 3u)) : zero32;
             // next (b, h): 4 pieces * 128 B; second run of the lane at k + 64
             mfma_chunk<BITS>(acc, Wd, bbase, bcol ? 512u : 0u, bcol ? 64u : 0u, sb);
+#endif
             if (!(HOT_ABL & 4) && __builtin_expect(nhot != 0u, 0)) hot_step<BITS>(acc, Wd, hotl, nhot, chunk, sb, col, kb);
         } else if (a.xflags & 1u) {
             acc[0][0] += __builtin_bit_cast(float, Wd[0][0] ^ Wd[BITS - 1][7]);
@@ -1235,7 +1252,13 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     // ---- 2. the steps of this wave
     const u32 r = l & 15u, kb = l >> 4, col = l & 15u;
     const u32 offA0 = atile_unit(r, 2u * kb) * 16u, offA1 = atile_unit(r, 2u * kb + 1u) * 16u;
-    const unsigned char *blane = img + ((col & 3u) << 7) + ((16u * kb) ^ bimg_swz(col & 3u));  // columns 4..15 repeat 0..3 (their sums are never read)
+    // columns 4..15 carry no piece: zeros from outside the LDS allocation (PL_BOOB, see the shared-image kernel; their sums are
+    // never read, but non-zero operands cost power and with it clock) -- PL_LOOB = 0: they repeat columns 0..3
+#if PL_LOOB
+    const unsigned char *blane = col < 4u ? img + ((col & 3u) << 7) + ((16u * kb) ^ bimg_swz(col & 3u)) : smem + 0x30000u;
+#else
+    const unsigned char *blane = img + ((col & 3u) << 7) + ((16u * kb) ^ bimg_swz(col & 3u));
+#endif
     v4f acc[NP1];
 #pragma unroll
     for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B on one box: the current library against guidedquant_amd/abl_$1, local-image launches (wo, w2 plain / residual) + bench.py --quick
+V=$1
+for r in 1 2 3; do for v in base $V; do
+  if [ "$v" = base ]; then unset GQ_LIB_PATH; else export GQ_LIB_PATH=$PWD/guidedquant_amd/abl_$v/libgq_hip.so; fi
+  echo "== $v"
+  python tools/bench_ap.py --bits 2 --shapes wo w2 2>&1 | grep shape | cut -c1-120
+  python tools/bench_ap.py --bits 3 --shapes wo w2 2>&1 | grep shape | cut -c1-120
+done; done
+for v in base $V base $V; do
+  if [ "$v" = base ]; then unset GQ_LIB_PATH; else export GQ_LIB_PATH=$PWD/guidedquant_amd/abl_$v/libgq_hip.so; fi
+  echo "== bench $v"; python bench.py --quick --steps 400 --warmup 100 2>/dev/null | tail -1 | cut -c1-100
+done

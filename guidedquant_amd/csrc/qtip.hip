@@ -19,6 +19,9 @@
 #include "gq_internal.h"
 #include "fwht.h"
 
+#ifndef QT_XOOB
+#define QT_XOOB 1
+#endif
 namespace {
 typedef uint32_t u32;
 using gq_fwht::fwht_lds;
@@ -342,7 +345,14 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
         accA[par] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, o.wa), __builtin_bit_cast(h16x8, o.xb), accA[par], 0, 0, 0);
         accB[par] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, o.wb), __builtin_bit_cast(h16x8, o.xb), accB[par], 0, 0, 0);
     };
-    const uint16_t *xg = xsp + 8u * g;  // this lane group's 8 activations of tile block K2: xg + 32 K2
+    // this lane group's 8 activations of tile block K2: xg + 32 K2.  QT_XOOB: only column 0 of the B operand carries them; the
+    // lanes of columns 1..15 read from 192 KiB above -- outside the LDS allocation, where ds_read returns zeros (tools/ubench/
+    // lds_oob.hip): 15 equal copies of the activations in the matrix cores cost power, and with it clock (ap_plane.hip, PL_BOOB)
+#if QT_XOOB
+    const uint16_t *xg = xsp + 8u * g + ((l & 15u) ? 0x18000u : 0u);
+#else
+    const uint16_t *xg = xsp + 8u * g;
+#endif
     u32 flip = 0;
     for (;;) {
         const u32 jn = j + gridDim.x;
@@ -395,12 +405,23 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
         // D layout: lane (gq = l / 16, n = l % 16) holds logical rows 4 gq + 0..3 of column n (all columns are equal):
         // lanes n < 4 store element n of "rows a", lanes 4 <= n < 8 element n - 4 of "rows a + 8"
         {
-            const u32 n = l & 15u, e = n & 3u, r = 4u * g + e;
             const f32x4 sa = accA[0] + accA[1], sb = accB[0] + accB[1];
+            float *pw = part + flip * (W * 32u) + w * 32u;
+#if QT_XOOB
+            if ((l & 15u) == 0u) {  // column 0 holds the sums: its lane of each group stores the 4 + 4 rows
+#pragma unroll
+                for (u32 e = 0; e < 4u; e++) {
+                    const u32 r = 4u * g + e;
+                    pw[16u * (r >> 3) + (r & 7u)] = sa[e];
+                    pw[16u * (r >> 3) + (r & 7u) + 8u] = sb[e];
+                }
+            }
+#else
+            const u32 n = l & 15u, e = n & 3u, r = 4u * g + e;
             const f32x4 src = (n & 4u) ? sb : sa;
             const float v = e == 0u ? src[0] : (e == 1u ? src[1] : (e == 2u ? src[2] : src[3]));
-            float *pw = part + flip * (W * 32u) + w * 32u;
             if (n < 8u) pw[16u * (r >> 3) + (r & 7u) + 8u * (n >> 2)] = v;
+#endif
         }
         __syncthreads();
         if (tid < 32u) {

@@ -19,6 +19,9 @@
 // x tiles are double-buffered through registers (next stage's global loads in flight during the MFMAs); weights are read
 // once per (row tile, token tile).  fp32 accumulation over all of K, one rounding to fp16 (as a cuBLAS fp16 GEMM).
 // Requires K % 64 == 0 (tail chunks of 64 .. 960 weights are served), 2 <= bits <= 4; other widths keep the dequant path.
+// Two kernels: `ap_gemm_kernel` (round 2: the mapping above, x staged through registers, any K % 64 == 0) and, for K % 256 == 0,
+// `ap_gemm_pipe_kernel` further down (round 3: x through a ring of direct-to-LDS loads, plane words requested a group ahead,
+// hand software pipeline, RF x CF fragments per wave, optional K split) -- `launch_gemm` picks kernel and tile per problem.
 #include <hip/hip_runtime.h>
 
 #include "ap_core.h"

@@ -363,6 +363,8 @@ __device__ __forceinline__ void park_item(v4f (&acc)[NP1], float *pitem, u32 col
     }
 }
 
+__device__ __forceinline__ void store_out16(uint16_t *p, uint16_t v) { gq_store_wt(p, v); }  // hand-off store (gq_internal.h)
+
 // coefficients x plane sums.  lane = (output row, Moebius index c): term c = coef[c] * (c == 0 ? sum(x) : T[c]); the NP
 // terms of a row sit in NP adjacent lanes and are added by a fixed DPP tree (deterministic order)
 template <int BITS>
@@ -413,18 +415,20 @@ __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lu
         if constexpr (NP >= 8) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x141, 0xF, 0xF, false));
         if constexpr (NP >= 16) y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x140, 0xF, 0xF, false));
         _Float16 yh = (_Float16)y;
+        // hand-off stores: write-through, one 2-byte store per output (gq_internal.h; two neighbouring outputs per 4-byte store
+        // measured slower: 831 vs 839 tokens/s, plain stores 825)
         if (a.pairs) {
             // the partner row of the pair sits NP lanes away: F.silu(gate) * up on fp16 values -- inference/model.py:266
             const _Float16 yo = __builtin_bit_cast(_Float16, (uint16_t)__shfl_xor((int)__builtin_bit_cast(uint16_t, yh), NP));
             if (c == 0u && !(rr & 1u) && row + 1u < a.N) {
                 const float gv = (float)yh;
                 const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * yo;
-                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
+                store_out16(a.out + (size_t)m * (a.N >> 1) + (row >> 1), __builtin_bit_cast(uint16_t, o));
             }
         } else if (c == 0u && row < a.N) {
             // (requesting the residual elements at kernel start -- LDS-DMA by wave 0 -- was measured: no gain, the load is an L2 hit)
             if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[(size_t)m * a.N + row]) + yh;
-            a.out[(size_t)m * a.N + row] = __builtin_bit_cast(uint16_t, yh);
+            store_out16(a.out + (size_t)m * a.N + row, __builtin_bit_cast(uint16_t, yh));
         }
     }
 }

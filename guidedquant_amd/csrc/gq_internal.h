@@ -37,6 +37,50 @@ __device__ __forceinline__ float gq_pin_f32(float v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+
+// Hand-off stores: what a launch of the decode step writes is read by the NEXT launch, mostly from other XCDs.  A plain store
+// leaves the line dirty in the writer's XCD L2 until the end-of-kernel write-back; a write-through store (sc1) puts it in
+// memory at once.  Used where it measured faster -- the outputs of the plane GEMV kernels (four of the five launches of a layer,
+// 8 .. 28 KiB each): 8B decode 828 -> 843 tokens/s, same box, alternating, three rounds.  Measured neutral or slower and left
+// plain: the attention output, the 128 K two-byte logits of the lm_head (one fabric write each), the sampler / embedding
+// outputs, the fp32 sums of the QTIP engine.  GQ_WT_STORES=0 at build time brings the plain stores back.
+#ifndef GQ_WT_STORES
+#define GQ_WT_STORES 1
+#endif
+__device__ __forceinline__ void gq_store_wt(uint16_t *p, uint16_t v) {
+#if GQ_WT_STORES
+    asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((uint32_t)v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void gq_store_wt(uint32_t *p, uint32_t v) {
+#if GQ_WT_STORES
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void gq_store_wt(int *p, int v) { gq_store_wt(reinterpret_cast<uint32_t *>(p), (uint32_t)v); }
+__device__ __forceinline__ void gq_store_wt(float *p, float v) { gq_store_wt(reinterpret_cast<uint32_t *>(p), __builtin_bit_cast(uint32_t, v)); }
+__device__ __forceinline__ void gq_store_wt(uint2 *p, uint2 v) {
+#if GQ_WT_STORES
+    typedef uint32_t gq_u32x2 __attribute__((ext_vector_type(2)));
+    const gq_u32x2 t = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void gq_store_wt(uint4 *p, uint4 v) {
+#if GQ_WT_STORES
+    typedef uint32_t gq_u32x4 __attribute__((ext_vector_type(4)));
+    const gq_u32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#else
+    *p = v;
+#endif
+}
 #endif
 
 #define GQ_STR2(x) #x

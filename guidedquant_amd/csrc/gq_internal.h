@@ -43,7 +43,7 @@ __device__ __forceinline__ float gq_pin_f32(float v) {
 // memory at once.  Used where it measured faster -- the outputs of the plane GEMV kernels (four of the five launches of a layer,
 // 8 .. 28 KiB each): 8B decode 828 -> 843 tokens/s, same box, alternating, three rounds.  Measured neutral or slower and left
 // plain: the attention output, the 128 K two-byte logits of the lm_head (one fabric write each), the sampler / embedding
-// outputs, the fp32 sums of the QTIP engine.  GQ_WT_STORES=0 at build time brings the plain stores back.
+// outputs, the fp32 sums of the QTIP engine, the outputs of the exact-mode GEMV kernels (564-566 vs 568-570 tokens/s).  GQ_WT_STORES=0 at build time brings the plain stores back.
 #ifndef GQ_WT_STORES
 #define GQ_WT_STORES 1
 #endif

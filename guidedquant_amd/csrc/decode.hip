@@ -649,8 +649,10 @@ extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32
     if (smem > 160u * 1024u) return gq_fail(GQ_ENOTSUP, "K too large.");
     constexpr int RW = 4;
     const u32 ncu = (u32)cu_count();
-    // ~4 blocks per CU, every block a multiple of 4 waves * RW rows
-    u32 rpb = (N + ncu * 4u - 1u) / (ncu * 4u);
+    // ~3 blocks per CU (measured over 2 .. 16 on the 128256 x 4096 lm_head inside the decode step: 3 is 0.4 % of the token faster than 4,
+    // 6 is 0.7 % slower), every block a multiple of 4 waves * RW rows
+    const u32 bpc = (u32)gq_env_int("GQ_DENSE_BPC", 3);
+    u32 rpb = (N + ncu * bpc - 1u) / (ncu * bpc);
     rpb = ((rpb + 4u * RW - 1u) / (4u * RW)) * (4u * RW);
     const u32 grid = (N + rpb - 1u) / rpb;
     static GqPerDeviceOnce once;

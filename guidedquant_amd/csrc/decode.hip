@@ -50,7 +50,10 @@ __global__ void embed_kernel(const int *tok, const uint16_t *table, uint16_t *ou
 // built by the host from fp32 (LlamaRotaryEmbedding.forward, model.py:379-405).  The rotated k and the v of this
 // token are written to the cache at `pos` (KVCache.update, model.py:69-79) by the first head of each KV group.
 // Scores / softmax / weighted sum run in fp32 from the fp16 operands; the output is rounded to fp16 once.
-constexpr int ATTN_WAVES = 8;  // 8 waves x 4 positions x 4 in flight = 128 positions per pass (HD = 128)
+#ifndef GQ_ATTN_WAVES
+#define GQ_ATTN_WAVES 8
+#endif
+constexpr int ATTN_WAVES = GQ_ATTN_WAVES;  // 8 waves x 4 positions x 4 in flight = 128 positions per pass (HD = 128)
 // QT (QTIP models): q / k / v are not read as fp16 vectors but rebuilt from the trellis matvecs' fp32 sums -- the transform-out of
 // BitshiftLinear.forward (inference/lib/codebook/bitshift.py:470: hadamard(y) * m^-1/2 * (SV * 32) -> fp16), i.e. what
 // gq_qtip_linear_out computes in a launch of its own.  A head needs HD of the M outputs of each vector and the Sylvester matrix

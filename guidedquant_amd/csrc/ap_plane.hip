@@ -1453,6 +1453,9 @@ unsigned long long *g_dbg = nullptr;
 }  // namespace
 
 extern "C" void gq_debug_set_timing_buffer(void *p) { g_dbg = (unsigned long long *)p; }
+unsigned long long *gq_debug_timing_buffer() { return g_dbg; }  // (ap_stream.hip stamps into the same buffer)
+int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K, int bits,
+                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream);  // ap_stream.hip
 
 namespace {
 int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t Kfull,
@@ -1539,6 +1542,15 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
     if (((uintptr_t)qweight | (uintptr_t)x | (uintptr_t)normw) & 15u) return GQ_ENOTSUP;
+    // the stream kernel (ap_stream.hip) first where it measured faster (profiles/r04_stream_kernel.txt): the RMSNorm-prologue
+    // launches of the widths up to 4096 at 2 bits (8B wqkv / w1w3); GQ_ST = 0 never, 2 every shape it serves, 3 every prologue too
+    {
+        const int st = gq_env_int("GQ_ST", 1);
+        if (st >= 3 || (st == 2 && pro == PRO_RMSNORM) || (st == 1 && pro == PRO_RMSNORM && bits == 2 && K <= 4096u)) {
+            const int rc = gq_stream_gemv_try(x, out, qweight, lut, M, N, K, bits, normw, eps, resid, pro, pairs, stream);
+            if (rc != GQ_ENOTSUP) return rc;
+        }
+    }
     if (K <= 16384u) return plane_launch_slice(x, out, qweight, lut, M, N, K, 0u, K, bits, normw, eps, resid, pro, pairs, stream);
     // 16384 < K <= 32768 (the 70B down projection): the B image of the whole row does not fit LDS, so the row is split at a
     // chunk boundary into two launches; the second adds its half to the first one's fp16 result through the residual

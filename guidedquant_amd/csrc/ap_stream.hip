@@ -1,0 +1,880 @@
+// ap_stream.hip -- "stream" form of the plane-MFMA Any-Precision GEMV (fast mode, one batch row) for gfx950.
+//
+// Same arithmetic as ap_plane.hip (plane_core.h: a b-bit LUT is multilinear in the code bits, so y is 2^b - 1 BINARY GEMVs over
+// the stored bit-planes; FP4 single-bit A operands built with one v_and per 8 weights, the activations as 4 exact bf8 pieces in
+// 4 MFMA columns, fp32 accumulation) -- replaces anyprec.cu:372-542 for M = 1.  What is different is where the bytes go
+// (round 4; measured reasons in DESIGN.md section 3.5):
+//   * the plane words travel HBM -> VGPR (buffer_load_dwordx4, 16 rows x 64 B per instruction) and are masked in place: no
+//     LDS ring, no direct-to-LDS loads, no ds_read of A tiles, no hand-counted vmcnt;
+//   * a wave multiplies ONE K range ("unit": half a 1024-weight chunk, 512 activations) of several row groups and keeps the
+//     activation image of that range in 32 VGPRs: no B re-reads in the loop (the round-3 kernel issued 20 ds_read_b128 per
+//     24 MFMAs and its LDS pipe was 50 % busy); the K-split partial sums of a row group are added in the epilogue;
+//   * every unit has its own power-of-two scale (the E8M0 scale operand of its MFMAs undoes it, partial sums of different
+//     units meet in fp32 only): no whole-vector maximum, the only whole-vector statistic left is the RMSNorm sum of squares;
+//   * image hand-over per unit through LDS flags: no block-wide barrier between launch and the first MFMA except the one
+//     that publishes the zeroed flags (placed behind the activation loads).
+// Numerics: products exact, fp32 accumulation, one fp16 rounding -- the fast-mode envelope of tests/ap_helpers.py; not
+// bit-identical to ap_plane.hip (other summation order).  Elements above 64 x the unit's mean magnitude leave the image and are
+// multiplied on their own (see ap_plane.hip "hot" elements; here per unit: fewer than 512 / 64 = 8 of them by Markov).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "gq_internal.h"
+#include "plane_core.h"
+
+using namespace gqp;
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef uint16_t us2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32 lds_u32;
+
+struct StreamArgs {
+    const u32 *qw;
+    const uint16_t *lut;
+    const uint16_t *x;
+    uint16_t *out;
+    const uint16_t *normw;
+    const uint16_t *resid;
+    u32 N, K;
+    u32 wpr_ld;  // plane words per stored row
+    u32 RGB;     // row groups (16 rows) per block
+    u32 lq, lw;  // log2 of the consumer units per row (31: not fewer than waves) and of the waves per block
+    u32 img_off; // LDS offset of the images (behind meta, counters and the coefficient table)
+    u32 dbg_off; // LDS offset of the phase stamps (only with a timing buffer)
+    u32 pairs;   // GQ_EPI_SILU_PAIRS
+    float eps;
+    unsigned long long *dbg;  // per-wave phase timestamps of the middle block (tools/phase_timing.py)
+};
+
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILUMUL = 2 };
+constexpr u32 HOTCAP = 8u;  // Markov: |x| > 64 mean|x| holds for fewer than 512 / 64 elements of a unit
+constexpr u32 OOB = 0x80000000u;
+
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ h2v u2h2(u32 u) { return __builtin_bit_cast(h2v, u); }
+__device__ __forceinline__ u32 h22u(h2v h) { return __builtin_bit_cast(u32, h); }
+
+// wave64 reductions on the DPP path: result valid in lane 63
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+    auto step = [&](auto dpp) {
+        float o = __builtin_bit_cast(float, dpp(__builtin_bit_cast(int, v)));
+        v = MAX ? fmaxf(v, o) : v + o;
+    };
+    step([](int x) { return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); });   // quad_perm [1,0,3,2]
+    step([](int x) { return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); });   // quad_perm [2,3,0,1]
+    step([](int x) { return __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); });  // row_half_mirror
+    step([](int x) { return __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); });  // row_mirror
+    {   // row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 (|x| >= 0 and the sum identity are both 0.0f)
+        float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+        v = MAX ? fmaxf(v, o) : v + o;
+        o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+        v = MAX ? fmaxf(v, o) : v + o;
+    }
+    return v;
+}
+__device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+
+// A = FP4 (4 registers; the upper half of the builtin's vector is ignored for cbsz = 4), B = BF8.  Through the builtin: the
+// compiler must see the instruction to insert the MFMA hazard wait states.
+__device__ __forceinline__ void mfma_f4_bf8(v4f &acc, v4i a, v8i b, int scale_a, int scale_b) {
+    const v8i a8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, -1, -1, -1, -1);
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b, acc, 4, 1, 0, scale_a, 0, scale_b);
+}
+
+// F.silu(gate) * up on two packed fp16 pairs -- inference/model.py:266
+__device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
+    _Float16 hh[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float gv = h2f((uint16_t)(gw >> (16 * k)));
+        hh[k] = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, (uint16_t)(uw >> (16 * k)));
+    }
+    return (u32)__builtin_bit_cast(uint16_t, hh[0]) | ((u32)__builtin_bit_cast(uint16_t, hh[1]) << 16);
+}
+
+struct HotEnt {
+    u32 key, pieces;  // key = b << 7 | k (logical k of the unit's (b) block), pieces: byte p = bf8 piece p of x * 2^ksh
+};
+#define GQ_ST_HOT_T 64.0f
+
+// LDS flags / counters through explicit LDS pointers (a generic pointer becomes a FLAT access whose vmcnt(0) drains the
+// wave's plane loads) and without fences: the LDS serves one wave's operations in order, so a flag written behind the data
+// is seen behind the data; the compiler is held by the asm memory clobbers.
+__device__ __forceinline__ void lds_store(u32 *p, u32 v) {
+    asm volatile("" ::: "memory");
+    *(volatile lds_u32 *)(lds_u32 *)p = v;
+}
+__device__ __forceinline__ u32 lds_load(const u32 *p) {
+    const u32 v = *(volatile lds_u32 *)(lds_u32 *)p;
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait_ge(const u32 *p, u32 target) {
+    while (lds_load(p) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, u32 bytes) {  // raw buffer: stride 0, num_records = bytes
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
+}
+#ifndef ST_AUX
+#define ST_AUX 2  // cache policy of the plane loads: 2 = nt (streamed once)
+#endif
+template <int AUX>
+__device__ __forceinline__ u32x4 bload128(rsrc_t rsrc, u32 voff, u32 soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, AUX));
+}
+
+// The plane words are requested from inline asm and waited for with explicit s_waitcnt vmcnt(n) (vector memory returns in
+// order): the compiler's own counting gives up at the loop's control-flow joins and drains the queue (vmcnt(0)) before every
+// unit, which serialises the memory latency with the MFMAs.  The destination is an in-out operand of the request (an output
+// of its own may be copied by the compiler before the data lands) and is tied again behind the wait.
+__device__ __forceinline__ u32x4 make_rsrc4(const void *p, u32 bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return (u32x4){(u32)a, (u32)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void aload128(u32x4 &dst, u32x4 rsrc, u32 voff, u32 soff) {
+#if ST_AUX == 2
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#else
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most n * LPU plane loads of this wave are outstanding (n wave-uniform)
+template <int LPU>
+__device__ __forceinline__ void wait_vm_units(u32 n) {
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<LPU>(); break;
+        case 2: wait_vm<2 * LPU>(); break;
+        default: wait_vm<3 * LPU>(); break;
+    }
+}
+
+// The MFMAs of one (unit half hh, nibble bit NB) block: FP4 operands of the plane subsets built on the fly (the mask commutes
+// with AND; depth-first over the subset lattice).  Plane p holds code bit BITS-1-p; subset index cm = OR of the code bits.
+template <int BITS, int NB>
+__device__ __forceinline__ void mfma_b(v4f (&acc)[(1 << BITS) - 1], const u32x4 (&A)[BITS], v8i Bv, int sb) {
+    v4i Mp[BITS];
+#pragma unroll
+    for (int p = 0; p < BITS; p++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) Mp[p][v] = (int)extract4(A[p][v], NB);
+    const int sa = scale_byte4(NB);
+#pragma unroll
+    for (int p0 = 0; p0 < BITS; p0++) {
+        const v4i A1 = Mp[p0];
+        const int c1 = 1 << (BITS - 1 - p0);
+        mfma_f4_bf8(acc[c1 - 1], A1, Bv, sa, sb);
+#pragma unroll
+        for (int p1 = p0 + 1; p1 < BITS; p1++) {
+            const v4i A2 = A1 & Mp[p1];
+            const int c2 = c1 | (1 << (BITS - 1 - p1));
+            mfma_f4_bf8(acc[c2 - 1], A2, Bv, sa, sb);
+#pragma unroll
+            for (int p2 = p1 + 1; p2 < BITS; p2++) {
+                const v4i A3 = A2 & Mp[p2];
+                const int c3 = c2 | (1 << (BITS - 1 - p2));
+                mfma_f4_bf8(acc[c3 - 1], A3, Bv, sa, sb);
+#pragma unroll
+                for (int p3 = p2 + 1; p3 < BITS; p3++) {
+                    const v4i A4 = A3 & Mp[p3];
+                    const int c4 = c3 | (1 << (BITS - 1 - p3));
+                    mfma_f4_bf8(acc[c4 - 1], A4, Bv, sa, sb);
+                }
+            }
+        }
+    }
+}
+
+// the extracted elements of one unit half: per nibble bit b with entries one more MFMA set whose B operand is zero except for
+// the listed bytes (exact products, nothing to align against); deterministic whatever the order of the list
+template <int BITS>
+__device__ __forceinline__ void hot_unit(v4f (&acc)[(1 << BITS) - 1], const u32x4 (&A)[BITS], const HotEnt *list, u32 nhot, int sb, u32 col,
+                                         u32 kb) {
+    u32 mask = 0;
+    for (u32 e = 0; e < nhot; e++) mask |= 1u << ((__builtin_amdgcn_readfirstlane(list[e].key) >> 7) & 3u);
+    while (mask) {
+        const u32 b = (u32)__builtin_ctz(mask);
+        mask &= mask - 1u;
+        u32 B[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        for (u32 e = 0; e < nhot; e++) {
+            const u32 key = __builtin_amdgcn_readfirstlane(list[e].key);
+            if (((key >> 7) & 3u) != b) continue;
+            const u32 pieces = __builtin_amdgcn_readfirstlane(list[e].pieces);
+            // lane (col = piece, kb) holds k = 64 (j / 16) + 16 kb + j % 16 as byte j of its 8 registers
+            const u32 k = key & 127u, j = ((k >> 6) << 4) | (k & 15u);
+            const bool mine = col < 4u && ((k >> 4) & 3u) == kb;
+            const u32 val = mine ? ((pieces >> (8u * col)) & 0xFFu) << (8u * (j & 3u)) : 0u;
+#pragma unroll
+            for (u32 r = 0; r < 8; r++) B[r] |= (j >> 2) == r ? val : 0u;
+        }
+        const v8i Bv = {(int)B[0], (int)B[1], (int)B[2], (int)B[3], (int)B[4], (int)B[5], (int)B[6], (int)B[7]};
+        const u32 msk = b == 3u ? 0x44444444u : 0x11111111u << b, sh = b == 3u ? 1u : 0u;
+        v4i Mp[BITS];
+#pragma unroll
+        for (int p = 0; p < BITS; p++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Mp[p][v] = (int)((A[p][v] >> sh) & msk);
+        const int sa = b == 0u ? 128 : (b == 1u ? 127 : 126);
+#pragma unroll
+        for (int cm = 1; cm < (1 << BITS); cm++) {
+            v4i Am = {-1, -1, -1, -1};
+#pragma unroll
+            for (int p = 0; p < BITS; p++)
+                if (cm & (1 << (BITS - 1 - p))) Am &= Mp[p];
+            mfma_f4_bf8(acc[cm - 1], Am, Bv, sa, sb);
+        }
+    }
+}
+
+// 16-lane (DPP row) butterflies: every lane of the row ends up with the row's result -- no row_bcast steps, no readlane
+__device__ __forceinline__ float row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ u32 row_max(u32 v) {
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
+    return v;
+}
+
+// Geometry.  A 1024-weight chunk of a row is 32 plane words t; bit 8 (3 - c) + (7 - j) of word t is the weight of activation
+// 1024 chunk + 256 c + 8 t + j (plane_core.h).  Unit q = (chunk, hh) = q >> 1, q & 1: words t = 16 hh + tt, tt = 0..15 -- 64
+// bytes of every row and plane, 512 activations (4 runs of 128).
+//   A: lane (r = l % 16, g = l / 16) loads the 16 bytes tt = 4 g + v (v = 0..3) of row r; register v masked at nibble bit b is
+//      the FP4 operand element k = 32 g + 8 v + i = 8 tt + i (nibble i): activation c = 3 - i / 2, j = 7 - 4 (i & 1) - b.
+//   image of a unit: [b][piece][k] bytes (4 x 4 x 128 = 2 KiB); pieces 2, 3 keep byte k at k ^ 32 (bank swizzle, plane_core.h).
+//   B: lane (col = piece, kb) holds k = 16 kb .. + 15 and 64 + 16 kb .. + 15 of (b) in 8 registers, for all 4 b: 32 registers
+//      per unit, loaded ONCE per (wave, unit); columns 4..15 hold zeros.
+// Work: consumer unit cq = NH adjacent units (NH = 2: a whole chunk, one accumulation); wave w multiplies cq = w % NCU (+ W ..)
+// for the row groups rgs, rgs + rgstep, ..  Image builders: wave w builds units w, w + W, .. (NPU of them); its lane
+// (g = l / 16, v = l / 4 % 4, c = l % 4) owns the 8 activations (c, tt = 4 g + v, j = 0..7): a DPP row is a scale block.
+// LDS: [meta: 64 units x 16 words {ready, extracted, scale byte, ..}][red: W floats, ctr][coefficients: rows x 2^b
+//      floats][images: NC2 x 2 KiB][hot: NC2 x 8 x 8 B][part]
+//   part (raw, 2-bit): [rgl][cq][subset][col 0..3][16 rows] floats; PSUM: the 4 piece columns added, [rgl][cq][subset][16]
+constexpr u32 META_W = 16u;
+#ifndef ST_XFLAGS
+#define ST_XFLAGS 0  // build-time experiments: 1 no MFMA work, 2 no plane loads
+#endif
+#ifndef ST_W2
+#define ST_W2 16  // waves per block at 2 bits
+#endif
+#ifndef ST_W34
+#define ST_W34 8  // ... at 3 and 4 bits (more accumulators and plane words per wave)
+#endif
+#ifndef ST_NH
+#define ST_NH 1   // unit halves per consumer unit: 1 = a wave multiplies half chunks (32 image registers), 2 = whole chunks (64)
+#endif
+template <int BITS>
+constexpr int st_waves() { return BITS == 2 ? ST_W2 : ST_W34; }
+template <int BITS, int PRO, int NPU, bool PSUM>
+__global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(StreamArgs a) {
+    constexpr int WV = st_waves<BITS>(), NH = ST_NH;
+    constexpr int NP = 1 << BITS, NP1 = NP - 1;
+    constexpr u32 W = WV, T = 64u * W;
+    constexpr u32 RING = 4u;   // plane-word register slots (consumer units) per wave
+    constexpr u32 PF = 2u;     // consumer units requested ahead
+    constexpr u32 LPU = (u32)BITS * NH;  // plane loads per consumer unit
+    constexpr u32 NCOL = PSUM ? 1u : 4u;
+    static_assert(PSUM || BITS == 2, "raw parking: the (column, Moebius index) lanes of a row quad must fit a DPP row");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    // Every wave instruction costs its SIMD a 4-cycle issue slot and four waves share a SIMD: code that all 16 waves run is
+    // paid 4 x per SIMD (the first version spent 2,000 cycles in ~200 instructions per wave before its first plane load).
+    // So: flags at a fixed LDS offset (zeroed by wave 0 without reading a kernel argument), shifts instead of divisions (the
+    // host passes logarithms), the image builders at raised priority, statistics per DPP row.
+    const u32 tid = threadIdx.x;
+    const u32 w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 l = tid & 63u;
+    u32 *meta = reinterpret_cast<u32 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + 4096u);
+    u32 *ctr = reinterpret_cast<u32 *>(smem + 4096u + 64u);
+    float *ctab = reinterpret_cast<float *>(smem + 4096u + 128u);
+    if (w == 0u) {
+#pragma unroll
+        for (u32 i = 0; i < 4u; i++) reinterpret_cast<uint4 *>(meta)[l + 64u * i] = make_uint4(0u, 0u, 0u, 0u);
+        if (l == 0u) ctr[0] = 0u;
+    }
+    // phase stamps (tools/phase_timing.py): kept in LDS and written out at the very end -- a global store per stamp sits in
+    // vmcnt and turns the next wait for a load into a wait for the store's acknowledgement (~1,000 cycles each)
+    unsigned long long *dbgl = reinterpret_cast<unsigned long long *>(smem + a.dbg_off) + w * 24u;
+    const bool dbg_on = a.dbg && blockIdx.x == gridDim.x / 2;
+    auto stamp = [&](int i) {
+        if (dbg_on && l == 0) dbgl[i] = __builtin_readcyclecounter();
+    };
+    auto stamp2 = [&](int i) { stamp(8 + i); };
+    if (dbg_on && l < 24u) dbgl[l] = 0ull;
+    stamp(0);
+    const u32 nchunks = a.K >> 10, NC2 = 2u * nchunks, NCU = NC2 / NH;
+    const u32 npw = NC2 < W ? NC2 : W;  // waves with an image to build
+    const bool is_pro = w < npw;
+    if (is_pro) __builtin_amdgcn_s_setprio(3);
+    unsigned char *img = smem + a.img_off;
+    HotEnt *hotl = reinterpret_cast<HotEnt *>(img + (size_t)NC2 * 2048u);
+    float *xpart = reinterpret_cast<float *>(hotl + (size_t)NC2 * HOTCAP);  // [NC2][4][16]
+    float *part = xpart + (size_t)NC2 * 64u;
+    const u32 rg0 = blockIdx.x * a.RGB;
+
+    // ---------------------------------------------------------------- 0. requests: activations first, then one unit of planes
+    const u32 xg = l >> 4, xc = l & 3u, xtt = 4u * xg + ((l >> 2) & 3u);
+    u32x4 xv[NPU], nv[NPU];
+    if (is_pro) {
+        const rsrc_t rsx = make_rsrc(a.x, (PRO == PRO_SILUMUL ? 4u : 2u) * a.K);
+        const rsrc_t rsn = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * a.K);
+#pragma unroll
+        for (u32 n = 0; n < (u32)NPU; n++) {
+            const u32 q = w + n * W;
+            const u32 voff = q < NC2 ? 2u * (1024u * (q >> 1) + 256u * xc + 8u * (16u * (q & 1u) + xtt)) : OOB;
+            xv[n] = bload128<0>(rsx, voff, 0u);
+            if constexpr (PRO == PRO_RMSNORM) nv[n] = bload128<0>(rsn, voff, 0u);
+            if constexpr (PRO == PRO_SILUMUL) nv[n] = bload128<0>(rsx, voff, 2u * a.K);
+        }
+    }
+    stamp2(0);
+    // the LUT rows of the block: thread T - 1 - i takes row i (the waves that start last and have the least to do); the
+    // Moebius coefficients go to LDS for the epilogue
+    const u32 crow = T - 1u - tid;
+    const bool has_crow = crow < a.RGB * 16u;
+    u32 lutw[NP / 2];
+#pragma unroll
+    for (int k = 0; k < NP / 2; k++) asm volatile("" : "=v"(lutw[k]));
+    if (w >= W - ((a.RGB * 16u + 63u) >> 6)) {  // (wave-uniform)
+        const u32x4 rl = make_rsrc4(a.lut, a.N * (u32)NP * 2u);
+        const u32 voff = has_crow ? (rg0 * 16u + crow) * (u32)NP * 2u : OOB;
+        if constexpr (NP == 4) {
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "+v"(*reinterpret_cast<u32x2 *>(lutw)) : "v"(voff), "s"(rl) : "memory");
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < NP / 8; k4++)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
+                             : "+v"(*reinterpret_cast<u32x4 *>(lutw + 4 * k4))
+                             : "v"(voff), "s"(rl), "n"(16 * k4)
+                             : "memory");
+        }
+    }
+    // consumer units of this wave (a.lq = log2 NCU when NCU < W -- the waves of a K range split its row groups --, else 31)
+    const bool split = a.lq < 31u;
+    const u32 q0 = split ? (w & (NCU - 1u)) : w;
+    const u32 rgs = split ? w >> a.lq : 0u, lrs = split ? a.lw - a.lq : 0u;  // first row group, log2 of the row-group stride
+    const u32 nq = q0 < NCU ? ((NCU - 1u - q0) >> a.lw) + 1u : 0u;
+    const u32 nrg = a.RGB > rgs ? ((a.RGB - rgs - 1u) >> lrs) + 1u : 0u;
+    const u32 n_units = nq * nrg;
+    const u32 plane_bytes = a.N * a.wpr_ld * 4u;
+    const u32x4 rq = make_rsrc4(a.qw, plane_bytes * (u32)BITS);
+    const u32 lane_off = (ST_XFLAGS & 2) ? OOB : ((l & 15u) * a.wpr_ld + 4u * (l >> 4)) * 4u;  // (experiment 2: no plane loads)
+    u32x4 Ar[RING][NH][BITS];
+#pragma unroll
+    for (u32 s = 0; s < RING; s++)
+#pragma unroll
+        for (u32 hh = 0; hh < (u32)NH; hh++)
+#pragma unroll
+            for (u32 p = 0; p < (u32)BITS; p++) asm volatile("" : "=v"(Ar[s][hh][p]));
+    // the units of a wave in order: for each of its K ranges (cq = q0, q0 + W, ..) its row groups (rgs, rgs + rgstep, ..); the
+    // scalar offset of the next request and the LDS offset of the next parking place advance by constants
+    const u32 rg_bytes = (16u * a.wpr_ld * 4u) << lrs, q_bytes = 64u * NH * W - nrg * rg_bytes;
+    u32 i_soff = ((rg0 + rgs) * 16u * a.wpr_ld + 16u * NH * q0) * 4u, i_ri = 0, iu = 0;  // next unit to request
+    auto issue = [&](auto SLOT) {
+        constexpr u32 s = decltype(SLOT)::value;
+#pragma unroll
+        for (u32 hh = 0; hh < (u32)NH; hh++)
+#pragma unroll
+            for (u32 p = 0; p < (u32)BITS; p++)
+                aload128(Ar[s][hh][p], rq, lane_off, i_soff + 64u * hh + p * plane_bytes);
+        i_soff += rg_bytes;
+        if (++i_ri == nrg) i_ri = 0, i_soff += q_bytes;
+        iu++;
+    };
+    if (n_units > 0u) issue(std::integral_constant<u32, 0>{});
+    stamp(6);
+    // flags and counters start at zero: one hardware barrier.  (The CU's memory pipe serves requests in order: a builder's
+    // activation requests are in front of its own plane words; the other waves' first units are requested ~100 instructions
+    // into the kernel, behind the builders' first two loads.)
+    __syncthreads();
+    stamp2(1);
+    auto coefficients = [&]() {  // the block's Moebius coefficients -> LDS (needs the LUT request landed: wait_vm<..> by the caller)
+        if (w >= W - ((a.RGB * 16u + 63u) >> 6)) {
+#pragma unroll
+            for (int k = 0; k < NP / 2; k++) asm volatile("" : "+v"(lutw[k]));
+            float f[NP];
+#pragma unroll
+            for (int cc = 0; cc < NP / 2; cc++) {
+                f[2 * cc] = h2f((uint16_t)(lutw[cc] & 0xFFFF));
+                f[2 * cc + 1] = h2f((uint16_t)(lutw[cc] >> 16));
+            }
+            moebius<BITS>(f);
+            if (has_crow) {  // [c][row]: an epilogue lane reads the coefficients of its 4 rows in one 16-byte read
+#pragma unroll
+                for (int cc = 0; cc < NP; cc++) ctab[(size_t)cc * (a.RGB * 16u) + crow] = f[cc];
+            }
+        }
+    };
+    // epilogue lane = (piece column, Moebius index c, row quad, row group): its residual elements now
+    const u32 e_col = tid & (NCOL - 1u), e_c = (tid / NCOL) & (u32)NP1, e_rq = (tid / (NCOL * NP)) & 3u, e_rgl = tid / (NCOL * NP * 4u);
+    u32x2 rres = {0u, 0u};
+    if (a.resid && !a.pairs && e_rgl < a.RGB && e_c == 0u && e_col == 0u)
+        rres = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.resid, a.N * 2u), (int)(2u * ((rg0 + e_rgl) * 16u + 4u * e_rq)), 0, 0));
+
+    // ---------------------------------------------------------------- 1. images of this wave's units
+    if (is_pro) {
+        float nscale = 1.f;
+        if constexpr (PRO == PRO_RMSNORM) {
+            float ss = 0.f;
+            asm volatile("" : "+v"(xv[0]));
+            stamp2(2);
+#pragma unroll
+            for (u32 n = 0; n < (u32)NPU; n++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)  // (requests outside the vector returned zeros)
+                    ss = __builtin_amdgcn_fdot2(u2h2(xv[n][k]), u2h2(xv[n][k]), ss, false);
+            ss = wave_reduce<false>(ss);
+            if (l == 63) {
+                reinterpret_cast<u32 *>(red)[w] = __builtin_bit_cast(u32, ss);
+                asm volatile("" ::: "memory");
+                __hip_atomic_fetch_add((lds_u32 *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            stamp2(3);
+            lds_wait_ge(ctr, npw);
+            // (all partial sums in one LDS round trip: volatile reads would be served one by one, ~100 cycles each)
+            v4f rp[W / 4];
+#pragma unroll
+            for (u32 i = 0; i < W / 4u; i++) rp[i] = *reinterpret_cast<const v4f *>(red + 4u * i);
+            float tot = 0.f;
+#pragma unroll
+            for (u32 i = 0; i < W; i++) tot += i < npw ? rp[i / 4u][i % 4u] : 0.f;
+            nscale = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+        }
+        stamp(7);
+#pragma unroll
+        for (u32 n = 0; n < (u32)NPU; n++) {
+            const u32 q = w + n * W;
+            if (q >= NC2) continue;
+            // transform: (x.float() * rsqrt(mean(x^2)+eps)).half() * w -- inference/model.py:281-292, both fp16 roundings kept
+            u32 xw[4];
+            const h2v one2 = u2h2(0x3C003C00u);
+            us2 mxp = {0, 0};
+            float s1 = 0.f, xsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 t = xv[n][k];
+                if constexpr (PRO == PRO_RMSNORM) {
+                    const _Float16 h0 = (_Float16)gq_pin_f32(h2f(t & 0xFFFF) * nscale), h1 = (_Float16)gq_pin_f32(h2f(t >> 16) * nscale);
+                    t = h22u((h2v){h0, h1} * u2h2(nv[n][k]));
+                }
+                if constexpr (PRO == PRO_SILUMUL) t = silu_mul2(t, nv[n][k]);
+                xw[k] = t;
+                const u32 ab = t & 0x7FFF7FFFu;  // |fp16| bit patterns order like unsigned integers
+                mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, ab));
+                s1 = __builtin_amdgcn_fdot2(u2h2(ab), one2, s1, false);
+                xsum = __builtin_amdgcn_fdot2(u2h2(t), one2, xsum, false);
+            }
+            // statistics of the unit: maximum -> power of two (ONE scale per MFMA column: tools/ubench/scale_probe.hip -- the scale
+            // operand is taken from lanes 0..15 for all of K, there are no per-32-element scales inside one instruction), mean
+            // magnitude -> extraction threshold; per DPP row the sum for the coef[0] term
+            const u32 mxl = max((u32)mxp[0], (u32)mxp[1]);
+            const float xmax = lane63(wave_reduce<true>(h2f((uint16_t)mxl)));
+            const float tot1 = lane63(wave_reduce<false>(s1));
+            xsum = row_sum(xsum);
+            stamp2(4);
+            // x * 2^k with max|x| * 2^k in [2^14, 2^15) (plane_core.h piece_shift): k + 15 = 44 - (biased fp16 exponent of the maximum)
+            const u32 ke = (u32)(piece_shift(xmax) + 15);
+            const u32 k16 = ke << 10;  // fp16 bits of 2^k
+            // threshold of the extraction as an fp16 bit pattern (rounded up): 64 x the unit's mean magnitude, + 1 % for the roundings
+            u32 tau = 0x7C00u;
+            {
+                const float tf = GQ_ST_HOT_T * 1.01f * tot1 * (1.0f / 512.0f);
+                if (tf < 65000.f) tau = (u32)__builtin_bit_cast(uint16_t, (_Float16)tf) + 1u;
+            }
+            HotEnt *hl = hotl + (size_t)q * HOTCAP;
+            u32 nh = 0;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mxl > tau) != 0ull, 0)) {
+                // rare: the lane's elements above the threshold leave the image (ascending lane order: deterministic list)
+#pragma unroll
+                for (u32 k = 0; k < 4; k++)
+#pragma unroll
+                    for (u32 hf = 0; hf < 2; hf++) {
+                        const u32 xh = (xw[k] >> (16u * hf)) & 0xFFFFu;
+                        const bool hot = (xh & 0x7FFFu) > tau;
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hot);
+                        if (bal == 0ull) continue;
+                        const u32 idx = nh + (u32)__builtin_popcountll(bal & ((1ull << l) - 1ull));
+                        if (hot && idx < HOTCAP) {
+                            const u32 j = 2u * k + hf, sbit = 7u - j;  // plane bit s = 7 - j: b = s & 3, nibble i = 2 (3 - c) + (s >> 2)
+                            _Float16 rem = __builtin_bit_cast(_Float16, (uint16_t)xh) * __builtin_bit_cast(_Float16, (uint16_t)k16);
+                            u32 pieces = 0;
+#pragma unroll
+                            for (u32 p = 0; p < 4; p++) {
+                                const uint16_t pb = __builtin_bit_cast(uint16_t, rem) & 0xFF00u;
+                                pieces |= (u32)(pb >> 8) << (8u * p);
+                                rem = rem - __builtin_bit_cast(_Float16, pb);
+                            }
+                            hl[idx].key = ((sbit & 3u) << 7) | (8u * xtt + 2u * (3u - xc) + (sbit >> 2));
+                            hl[idx].pieces = pieces;
+                        }
+                        if (hot) xw[k] &= ~(0xFFFFu << (16u * hf));
+                        nh += (u32)__builtin_popcountll(bal);
+                    }
+                nh = nh < HOTCAP ? nh : HOTCAP;
+            }
+            // split into 4 exact bf8 pieces and scatter: the lane's 8 activations are, per nibble bit b, the two bytes
+            // k0 (j = 7 - b) and k0 + 1 (j = 3 - b), k0 = 8 tt + 2 (3 - c)
+            const h2v kk = u2h2(k16 * 0x10001u);
+            u32 P[4][4];  // [piece][word]: bf8 of element 2 word in byte 1, of 2 word + 1 in byte 3
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                h2v rem = u2h2(xw[k]) * kk;
+#pragma unroll
+                for (u32 p = 0; p < 4; p++) {
+                    P[p][k] = h22u(rem) & 0xFF00FF00u;
+                    if (p < 3) rem = rem - u2h2(P[p][k]);
+                }
+            }
+            stamp2(5);
+            unsigned char *dst = img + (size_t)q * 2048u;
+            const u32 k0 = 8u * xtt + 2u * (3u - xc);
+#pragma unroll
+            for (u32 p = 0; p < 4; p++) {
+                // b = 0: j = 7, 3 (byte 3 of words 3, 1); b = 1: j = 6, 2 (byte 1 of words 3, 1)
+                const u32 v01 = __builtin_amdgcn_perm(P[p][1], P[p][3], 0x05010703u);
+                // b = 2: j = 5, 1 (byte 3 of words 2, 0); b = 3: j = 4, 0 (byte 1 of words 2, 0)
+                const u32 v23 = __builtin_amdgcn_perm(P[p][0], P[p][2], 0x05010703u);
+                unsigned char *d = dst + p * 128u + (k0 ^ bimg_swz(p));
+                *reinterpret_cast<uint16_t *>(d) = (uint16_t)v01;
+                *reinterpret_cast<uint16_t *>(d + 512u) = (uint16_t)(v01 >> 16);
+                *reinterpret_cast<uint16_t *>(d + 1024u) = (uint16_t)v23;
+                *reinterpret_cast<uint16_t *>(d + 1536u) = (uint16_t)(v23 >> 16);
+            }
+            // sum(x) as a pseudo partial sum [unit][piece column = g][16 rows]: the epilogue lanes of the coef[0] term run the
+            // same loads and additions as the others (no divergent branch on the tail of the kernel)
+            xpart[q * 64u + l] = xsum;
+            if (l == 0u) {
+                meta[META_W * q + 1u] = nh;
+                meta[META_W * q + 2u] = 142u - ke;  // E8M0 byte of 2^-k: 127 - k
+            }
+            lds_store(meta + META_W * q, 1u);  // (every lane stores the same flag behind its own image bytes)
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    stamp(1);
+    // (ONE request site per register slot: a second site in another branch gets registers of its own and a copy at the
+    // join -- made before the data lands)
+    if (is_pro) {
+        wait_vm<0>();  // (the LUT rows and the first unit, long landed; nothing else of this wave is in flight)
+        coefficients();
+    }
+    stamp2(6);
+    if (1u < n_units) issue(std::integral_constant<u32, 1>{});
+    stamp2(7);
+    if (!is_pro) {
+        wait_vm_units<LPU>(iu > 1u ? 1u : 0u);  // everything in front of the second unit
+        coefficients();
+    }
+
+    // ---------------------------------------------------------------- 2. the units of this wave
+    const u32 col = l & 15u, kb = l >> 4;
+    v8i Bv[NH][4];
+    int sb[NH];
+    u32 nhot[NH];
+    constexpr u32 PUNIT = (u32)NP1 * NCOL * 16u;  // floats parked per unit
+    const u32 part_rg = (NCU * PUNIT) << lrs, part_q = W * PUNIT - nrg * part_rg;
+    float *c_pp = part + (size_t)(rgs * NCU + q0) * PUNIT + (PSUM ? 4u * kb : col * 16u + 4u * kb);
+    u32 c_q = q0, c_ri = 0;
+    bool stamped = false;
+    auto consume = [&](auto SLOT, u32 u) {
+        constexpr u32 s = decltype(SLOT)::value;
+        if (c_ri == 0u) {
+            // a new K range: wait for its image, then hold it in registers for all row groups
+#pragma unroll
+            for (u32 hh = 0; hh < (u32)NH; hh++) {
+                const u32 q = c_q * NH + hh;
+                u32x2 fl;
+                do {  // {ready, extracted} in one read
+                    fl = *(volatile __attribute__((address_space(3))) u32x2 *)(lds_u32 *)(meta + META_W * q);
+                    asm volatile("" ::: "memory");
+                    if (fl[0] == 0u) __builtin_amdgcn_s_sleep(1);
+                } while (fl[0] == 0u);
+                nhot[hh] = __builtin_amdgcn_readfirstlane(fl[1]);
+                sb[hh] = (int)meta[META_W * q + 2u];
+                const unsigned char *src = img + (size_t)q * 2048u + (col & 3u) * 128u + ((16u * kb) ^ bimg_swz(col & 3u));
+#pragma unroll
+                for (u32 b = 0; b < 4; b++) {
+                    uint4 b0 = make_uint4(0, 0, 0, 0), b1 = make_uint4(0, 0, 0, 0);
+                    if (col < 4u) {
+                        b0 = *reinterpret_cast<const uint4 *>(src + b * 512u);
+                        b1 = *reinterpret_cast<const uint4 *>(src + b * 512u + 64u);
+                    }
+                    Bv[hh][b] = (v8i){(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+                }
+            }
+            if (!stamped) stamp(2), stamped = true;
+        }
+        // the requests behind this unit's: one more unit, or none at the tail
+        if (iu - 1u - u) wait_vm<LPU>();
+        else wait_vm<0>();
+#pragma unroll
+        for (u32 hh = 0; hh < (u32)NH; hh++)
+#pragma unroll
+            for (u32 p = 0; p < (u32)BITS; p++) asm volatile("" : "+v"(Ar[s][hh][p]));
+        v4f acc[NP1];
+#pragma unroll
+        for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+#if !(ST_XFLAGS & 1)
+        {
+#pragma unroll
+            for (u32 hh = 0; hh < (u32)NH; hh++) {
+                mfma_b<BITS, 0>(acc, Ar[s][hh], Bv[hh][0], sb[hh]);
+                mfma_b<BITS, 1>(acc, Ar[s][hh], Bv[hh][1], sb[hh]);
+                mfma_b<BITS, 2>(acc, Ar[s][hh], Bv[hh][2], sb[hh]);
+                mfma_b<BITS, 3>(acc, Ar[s][hh], Bv[hh][3], sb[hh]);
+                if (__builtin_expect(nhot[hh] != 0u, 0))
+                    hot_unit<BITS>(acc, Ar[s][hh], hotl + (size_t)(c_q * NH + hh) * HOTCAP, nhot[hh], sb[hh], col, kb);
+            }
+        }
+#else  // experiment: no MFMA work
+#pragma unroll
+        for (u32 hh = 0; hh < (u32)NH; hh++) acc[0][0] += __builtin_bit_cast(float, Ar[s][hh][0][0] ^ Ar[s][hh][BITS - 1][3]);
+#endif
+        // park: lane (col, kb) owns rows 4 kb .. 4 kb + 3 of column col
+        if constexpr (PSUM) {
+#pragma unroll
+            for (int cm = 0; cm < NP1; cm++) {
+                v4f v = acc[cm];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    float f = v[q4];
+                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
+                    f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
+                    v[q4] = f;
+                }
+                if (col == 0u) *reinterpret_cast<v4f *>(c_pp + (size_t)cm * 16u) = v;
+            }
+        } else if (col < 4u) {
+#pragma unroll
+            for (int cm = 0; cm < NP1; cm++) *reinterpret_cast<v4f *>(c_pp + (size_t)cm * 64u) = acc[cm];
+        }
+        c_pp += part_rg;
+        if (++c_ri == nrg) c_ri = 0, c_q += W, c_pp += part_q;
+        if (iu < n_units) issue(std::integral_constant<u32, (s + PF) % RING>{});  // (iu == u + PF here)
+    };
+    for (u32 u0 = 0; u0 < n_units; u0 += RING) {
+        if (u0 + 0u < n_units) consume(std::integral_constant<u32, 0>{}, u0);
+        if (u0 + 1u < n_units) consume(std::integral_constant<u32, 1>{}, u0 + 1u);
+        if (u0 + 2u < n_units) consume(std::integral_constant<u32, 2>{}, u0 + 2u);
+        if (u0 + 3u < n_units) consume(std::integral_constant<u32, 3>{}, u0 + 3u);
+    }
+    stamp(3);
+    __syncthreads();
+    stamp(4);
+
+    // ---------------------------------------------------------------- 3. epilogue: coefficients x plane sums
+    // lane = (piece column, Moebius index c, row quad, row group): the K-split partial sums of its 4 rows are added in unit
+    // order (16-byte LDS reads), then the piece columns and the NP terms c of a row -- term c = coef[c] * (c == 0 ? sum(x) :
+    // T[c]) -- by fixed DPP trees (adjacent lanes): deterministic
+    if (e_rgl < a.RGB) {  // (whole waves except the last one)
+        // (c == 0: the pseudo partial sums of sum(x), stride 64 floats per unit, "column" = scale block)
+        const float *pp = e_c != 0u ? part + (((size_t)(e_rgl * NCU) * NP1 + (e_c - 1u)) * NCOL + e_col) * 16u + 4u * e_rq
+                                    : xpart + (size_t)e_col * 16u + 4u * e_rq;
+        const u32 pstride = e_c != 0u ? (u32)NP1 * NCOL * 16u : 64u, pcount = e_c != 0u ? NCU : NC2;
+        v4f term = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (PSUM) {
+            // (one column of real partial sums; sum(x) keeps its 4 block columns: lane c == 0 adds them itself)
+            if (e_c == 0u) {
+                for (u32 q = 0; q < NC2; q++) {
+                    v4f t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (u32 g = 0; g < 4; g++) t += *reinterpret_cast<const v4f *>(xpart + (size_t)q * 64u + g * 16u + 4u * e_rq);
+                    term += t;
+                }
+            } else {
+                for (u32 cq = 0; cq < NCU; cq++) term += *reinterpret_cast<const v4f *>(pp + (size_t)cq * pstride);
+            }
+        } else {
+            for (u32 cq = 0; cq < pcount; cq += 4u) {  // (multiples of 4: K >= 2048)
+                v4f v[4];
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) v[k] = *reinterpret_cast<const v4f *>(pp + (size_t)(cq + k) * pstride);
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) term += v[k];
+            }
+        }
+        asm volatile("" : "+v"(term));
+        stamp2(8);
+        const v4f cf = *reinterpret_cast<const v4f *>(ctab + (size_t)e_c * (a.RGB * 16u) + e_rgl * 16u + 4u * e_rq);
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float f = term[r];
+            if constexpr (!PSUM) {
+                f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
+                f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x4E, 0xF, 0xF, false));
+            }
+            f *= cf[r];
+            constexpr int D0 = PSUM ? 0xB1 : 0x141, D1 = PSUM ? 0x4E : 0x140;
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), D0, 0xF, 0xF, false));
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), D1, 0xF, 0xF, false));
+            if constexpr (NP >= 8) f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x141, 0xF, 0xF, false));
+            if constexpr (NP >= 16) f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x140, 0xF, 0xF, false));
+            y[r] = f;
+        }
+        asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+        stamp2(9);
+        // every lane of the row quad holds the 4 sums
+        const u32 row = (rg0 + e_rgl) * 16u + 4u * e_rq;
+        if (a.pairs) {
+            // rows (2 i, 2 i + 1) = (gate, up): F.silu(gate) * up on fp16 values -- inference/model.py:266.  Lane (c = 0, col = k)
+            // takes pair k of the quad (one silu per lane instead of two on the tail)
+            const u32 k = PSUM ? e_c : e_col;  // (PSUM: lanes c = 0, 1 of the quad)
+            const _Float16 yg = (_Float16)(k ? y[2] : y[0]), yu = (_Float16)(k ? y[3] : y[1]);
+            const float gv = (float)yg;
+            const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * yu;
+            if ((PSUM ? true : e_c == 0u) && k < 2u && row + 2u * k + 1u < a.N) gq_store_wt(a.out + (row >> 1) + k, __builtin_bit_cast(uint16_t, o));
+        } else if (e_c == 0u && e_col == 0u) {
+            uint16_t o[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                _Float16 yh = (_Float16)y[r];
+                if (a.resid) yh = __builtin_bit_cast(_Float16, (uint16_t)(rres[r >> 1] >> (16 * (r & 1)))) + yh;
+                o[r] = __builtin_bit_cast(uint16_t, yh);
+            }
+            if (row + 3u < a.N) {
+                gq_store_wt(reinterpret_cast<uint2 *>(a.out + row), make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (row + (u32)r < a.N) gq_store_wt(a.out + row + r, o[r]);
+            }
+        }
+    }
+    stamp(5);
+    if (dbg_on && l < 24u) {
+        const unsigned long long v = dbgl[l];
+        if (l < 8u) a.dbg[w * 8u + l] = v;
+        else a.dbg[128u + w * 16u + (l - 8u)] = v;
+    }
+}
+
+struct StreamCfg {
+    u32 grid, RGB, NPU, W, img_off;
+    bool psum;
+    size_t smem;
+};
+
+bool pick_stream_cfg(u32 N, u32 K, int bits, StreamCfg &c) {
+    if (K % 2048u || K > 32768u) return false;  // (the epilogue adds the K-split partial sums four units at a time)
+    const u32 nchunks = K / 1024u, NC2 = 2u * nchunks;
+    if (NC2 > 64u) return false;  // (meta: 64 entries at a fixed offset)
+    const u32 RGt = (N + 15u) / 16u, ncu = (u32)gq_cu_count();
+    c.W = bits == 2 ? (u32)ST_W2 : (u32)ST_W34;
+    const u32 NCU = NC2 / (u32)ST_NH;
+    if (NCU < c.W && (NCU & (NCU - 1u))) return false;  // the waves of a K range split its row groups evenly (shifts in the kernel)
+    c.NPU = (NC2 + c.W - 1u) / c.W;
+    if (c.NPU > 2u) return false;
+    u32 rgb = (RGt + ncu - 1u) / ncu;
+    if (rgb < 1u) rgb = 1u;
+    c.RGB = rgb;
+    c.grid = (RGt + rgb - 1u) / rgb;
+    const u32 np = 1u << bits, np1 = np - 1u;
+    c.img_off = (4096u + 128u + rgb * 16u * np * 4u + 1023u) / 1024u * 1024u;
+    const size_t fixed = c.img_off + (size_t)NC2 * 2048u + (size_t)NC2 * HOTCAP * 8u + (size_t)NC2 * 256u;
+    const size_t raw = (size_t)rgb * NCU * np1 * 4u * 16u * 4u, lds = 160u * 1024u;
+    c.psum = bits > 2 || fixed + raw > lds || gq_env_int("GQ_ST_PSUM", 0);
+    if ((size_t)rgb * 4u * np * (c.psum ? 1u : 4u) > 64u * c.W) return false;  // epilogue lanes
+    if (rgb * 16u > 64u * c.W) return false;                                    // coefficient lanes
+    c.smem = fixed + (c.psum ? raw / 4u : raw);
+    return c.smem <= lds;
+}
+
+template <int BITS, int PRO, int NPU, bool PSUM>
+int launch_inst(const StreamArgs &a, const StreamCfg &c, hipStream_t s) {
+    static GqPerDeviceOnce once;
+    auto kern = ap_stream_kernel<BITS, PRO, NPU, PSUM>;
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
+    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(64u * c.W), c.smem, s, a);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+template <int BITS, int PRO>
+int launch_npu(const StreamArgs &a, const StreamCfg &c, hipStream_t s) {
+    if constexpr (BITS == 2) {
+        if (!c.psum) return c.NPU == 1u ? launch_inst<BITS, PRO, 1, false>(a, c, s) : launch_inst<BITS, PRO, 2, false>(a, c, s);
+    }
+    return c.NPU == 1u ? launch_inst<BITS, PRO, 1, true>(a, c, s) : launch_inst<BITS, PRO, 2, true>(a, c, s);
+}
+template <int BITS>
+int launch_pro(const StreamArgs &a, const StreamCfg &c, int pro, hipStream_t s) {
+    switch (pro) {
+        case PRO_RMSNORM: return launch_npu<BITS, PRO_RMSNORM>(a, c, s);
+        case PRO_SILUMUL: return launch_npu<BITS, PRO_SILUMUL>(a, c, s);
+        default: return launch_npu<BITS, PRO_NONE>(a, c, s);
+    }
+}
+}  // namespace
+
+unsigned long long *gq_debug_timing_buffer();  // ap_plane.hip (gq_debug_set_timing_buffer)
+
+// returns GQ_ENOTSUP when the shape is not served by this kernel (the caller goes on to ap_plane.hip / the exact kernels)
+int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K, int bits,
+                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
+    if (M != 1u || bits < 2 || bits > gq_env_int("GQ_ST_MAXBITS", 4)) return GQ_ENOTSUP;
+    const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
+    if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
+    if (((uintptr_t)qweight | (uintptr_t)x | (uintptr_t)normw | (uintptr_t)lut) & 15u) return GQ_ENOTSUP;
+    StreamCfg c;
+    if (!pick_stream_cfg(N, K, bits, c)) return GQ_ENOTSUP;
+    StreamArgs a{};
+    a.qw = qweight;
+    a.lut = (const uint16_t *)lut;
+    a.x = (const uint16_t *)x;
+    a.out = (uint16_t *)out;
+    a.normw = (const uint16_t *)normw;
+    a.resid = (const uint16_t *)resid;
+    a.N = N;
+    a.K = K;
+    a.wpr_ld = K / 32u;
+    a.RGB = c.RGB;
+    a.img_off = c.img_off;
+    {
+        const u32 NCU = 2u * (K / 1024u) / (u32)ST_NH;
+        a.lw = c.W == 16u ? 4u : 3u;
+        a.lq = 31u;
+        if (NCU < c.W)
+            for (u32 i = 0; i < 5u; i++)
+                if ((1u << i) == NCU) a.lq = i;
+    }
+    a.pairs = pairs ? 1u : 0u;
+    a.eps = eps;
+    a.dbg = gq_debug_timing_buffer();
+    a.dbg_off = (u32)((c.smem + 15u) & ~(size_t)15u);
+    if (a.dbg) {
+        c.smem = a.dbg_off + 16u * 24u * 8u;
+        if (c.smem > 160u * 1024u) a.dbg = nullptr;
+    }
+#ifndef ST_MAXBITS
+#define ST_MAXBITS 2  // bit widths compiled in
+#endif
+    if (bits == 2) return launch_pro<2>(a, c, pro, stream);
+#if ST_MAXBITS >= 3
+    if (bits == 3) return launch_pro<3>(a, c, pro, stream);
+#endif
+#if ST_MAXBITS >= 4
+    if (bits == 4) return launch_pro<4>(a, c, pro, stream);
+#endif
+    return GQ_ENOTSUP;
+}

@@ -85,7 +85,10 @@ def test_rmsnorm_prologue_default_dispatch_equals_unfused_chain(oracle, bits, N,
     diff = fused.view(np.uint16) != plain.view(np.uint16)
     assert diff.mean() <= 0.02, diff.mean()
     ulp = np.abs(np.spacing(plain)).astype(np.float64)
-    assert (np.abs(fused.astype(np.float64) - plain.astype(np.float64)) <= 2 * ulp).all()
+    # (round 4: the RMSNorm launches of the 2-bit 8B shapes run the stream kernel, the plain launch the round-3 kernels: two fp32
+    # summation orders, so an output that nearly cancels may move by more than its own ulps -- by fp32 noise of sum|w||x|)
+    slack = 2e-6 * (np.abs(lut.astype(np.float64)).max(axis=1) * np.abs(xn.astype(np.float64)).sum())
+    assert (np.abs(fused.astype(np.float64) - plain.astype(np.float64)) <= 2 * ulp + slack).all()
     rows = _rows(rng, N, 32)
     if N * K >= (20 if bits == 2 else 32) * 1000000:  # the default dispatch sends this shape to the plane-MFMA kernel
         _check_fast(fused, rmsnorm_ref(x, nw, EPS), q, lut, bits, oracle, rows=rows)

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../guidedquant_amd/csrc"
 make -s >/dev/null
 out=../abl_$name; mkdir -p $out
 base=$(basename $src .hip)
-extra=""; case $base in qtip|ap_plane) extra="-fno-slp-vectorize";; esac
+extra=""; case $base in qtip|ap_plane|ap_stream) extra="-fno-slp-vectorize";; esac
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $extra "$@" -c $base.hip -o $out/$base.o
 objs=$(ls *.o | grep -v "^$base.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $out/$base.o -fopenmp -L/opt/rocm/lib/llvm/lib -Wl,-rpath,/opt/rocm/lib/llvm/lib -o $out/libgq_hip.so

@@ -111,6 +111,11 @@ def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
     res = torch.randn(N, device=d, generator=g).half()
     out = torch.empty(1, 1, N, dtype=torch.float16, device=d)
     L = _lib.lib()
+    rope = None
+    if fused == "qkv_rope":
+        rope = dict(pos=torch.tensor([17], dtype=torch.int32, device=d), cos=torch.randn(256, 128, device=d).half(),
+                    sin=torch.randn(256, 128, device=d).half(), kc=torch.zeros(N // 128 // 6, 256, 128, dtype=torch.float16, device=d),
+                    vc=torch.zeros(N // 128 // 6, 256, 128, dtype=torch.float16, device=d))
 
     def run(i):
         sp = _lib.current_stream_ptr()
@@ -119,6 +124,12 @@ def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
         elif fused in ("norm", "norm_pairs"):
             rc = L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, nw.data_ptr(),
                                          1e-5, None, 4 if fused == "norm_pairs" else 0, sp)
+        elif fused == "qkv_rope":  # RMSNorm prologue + RoPE / KV-cache epilogue (the decode graph's wqkv launch, 8B head geometry)
+            hd = 128
+            hkv = N // hd // 6
+            rc = L.gq_anyprec_gemv_qkv_rope(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, nw.data_ptr(), 1e-5,
+                                            rope["pos"].data_ptr(), rope["cos"].data_ptr(), rope["sin"].data_ptr(), rope["kc"].data_ptr(),
+                                            rope["vc"].data_ptr(), 4 * hkv, hkv, hd, 256, sp)
         else:
             rc = L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, None, 0.0,
                                          res.data_ptr(), 1, sp)

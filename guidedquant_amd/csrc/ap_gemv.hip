@@ -505,6 +505,9 @@ bool exact_mode() {
     if (g_ap_mode >= 0) return g_ap_mode == 1;
     return gq_env_int("GQ_AP_EXACT", 0) != 0;
 }
+}  // namespace
+bool gq_ap_exact_mode() { return exact_mode(); }  // (ap_stream.hip: the fused q / k / v + RoPE launch is a fast-mode kernel)
+namespace {
 
 int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     if (bits < 2 || bits > 8) return gq_fail(GQ_EINVAL, "Bitwidth must be between 2 and 8.");

@@ -52,6 +52,11 @@ struct StreamArgs {
     u32 pairs;   // GQ_EPI_SILU_PAIRS
     float eps;
     unsigned long long *dbg;  // per-wave phase timestamps of the middle block (tools/phase_timing.py)
+    // RoPE epilogue of the fused q / k / v projection (gq_anyprec_gemv_qkv_rope): see the epilogue
+    const int *pos;
+    const uint16_t *cos_t, *sin_t;
+    uint16_t *kc, *vc;
+    u32 rope, H, Hkv, lhd, max_seq;  // lhd = log2(head_dim)
 };
 
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILUMUL = 2 };
@@ -327,11 +332,22 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     const u32 npw = NC2 < W ? NC2 : W;  // waves with an image to build
     const bool is_pro = w < npw;
     if (is_pro) __builtin_amdgcn_s_setprio(3);
+    // RoPE epilogue: the position is requested first thing (a vector load: it returns in order ahead of everything else of this
+    // wave and is looked at only behind the image build -- reading it where the cos / sin addresses are formed would park the wave
+    // for a memory round trip in front of its prologue: measured, 1 us per launch)
+    u32 posv = 0;
+    if (a.rope) posv = (u32)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.pos, 4u), 0, 0, 0);
     unsigned char *img = smem + a.img_off;
     HotEnt *hotl = reinterpret_cast<HotEnt *>(img + (size_t)NC2 * 2048u);
     float *xpart = reinterpret_cast<float *>(hotl + (size_t)NC2 * HOTCAP);  // [NC2][4][16]
     float *part = xpart + (size_t)NC2 * 64u;
     const u32 rg0 = blockIdx.x * a.RGB;
+    // Which 16 rows a row group is: any 16 rows do (every lane addresses its own row).  Plain: 16 consecutive rows.  RoPE epilogue:
+    // MFMA row i of group rg is row  head * hd + 8 (rg % (hd / 16)) + i / 2 + (hd / 2) (i % 2),  head = rg / (hd / 16): rows (2 m,
+    // 2 m + 1) of a group are the rotation partners (d, d + hd / 2) of one head (rotate_half, inference/model.py:330-341), so the
+    // epilogue lane that owns 4 consecutive MFMA rows owns two whole pairs -- the stored tensor keeps the reference's row order.
+    auto grp_base = [&](u32 rg) -> u32 { return a.rope ? ((rg >> (a.lhd - 4u)) << a.lhd) + 8u * (rg & ((1u << (a.lhd - 4u)) - 1u)) : rg * 16u; };
+    auto grp_row = [&](u32 i) -> u32 { return a.rope ? (i >> 1) + ((i & 1u) << (a.lhd - 1u)) : i; };
 
     // ---------------------------------------------------------------- 0. requests: activations first, then one unit of planes
     const u32 xg = l >> 4, xc = l & 3u, xtt = 4u * xg + ((l >> 2) & 3u);
@@ -358,7 +374,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     for (int k = 0; k < NP / 2; k++) asm volatile("" : "=v"(lutw[k]));
     if (w >= W - ((a.RGB * 16u + 63u) >> 6)) {  // (wave-uniform)
         const u32x4 rl = make_rsrc4(a.lut, a.N * (u32)NP * 2u);
-        const u32 voff = has_crow ? (rg0 * 16u + crow) * (u32)NP * 2u : OOB;
+        const u32 voff = has_crow ? (grp_base(rg0 + (crow >> 4)) + grp_row(crow & 15u)) * (u32)NP * 2u : OOB;
         if constexpr (NP == 4) {
             asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "+v"(*reinterpret_cast<u32x2 *>(lutw)) : "v"(voff), "s"(rl) : "memory");
         } else {
@@ -379,7 +395,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     const u32 n_units = nq * nrg;
     const u32 plane_bytes = a.N * a.wpr_ld * 4u;
     const u32x4 rq = make_rsrc4(a.qw, plane_bytes * (u32)BITS);
-    const u32 lane_off = (ST_XFLAGS & 2) ? OOB : ((l & 15u) * a.wpr_ld + 4u * (l >> 4)) * 4u;  // (experiment 2: no plane loads)
+    const u32 lane_off = (ST_XFLAGS & 2) ? OOB : (grp_row(l & 15u) * a.wpr_ld + 4u * (l >> 4)) * 4u;  // (experiment 2: no plane loads)
     u32x4 Ar[RING][NH][BITS];
 #pragma unroll
     for (u32 s = 0; s < RING; s++)
@@ -387,19 +403,17 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
         for (u32 hh = 0; hh < (u32)NH; hh++)
 #pragma unroll
             for (u32 p = 0; p < (u32)BITS; p++) asm volatile("" : "=v"(Ar[s][hh][p]));
-    // the units of a wave in order: for each of its K ranges (cq = q0, q0 + W, ..) its row groups (rgs, rgs + rgstep, ..); the
-    // scalar offset of the next request and the LDS offset of the next parking place advance by constants
-    const u32 rg_bytes = (16u * a.wpr_ld * 4u) << lrs, q_bytes = 64u * NH * W - nrg * rg_bytes;
-    u32 i_soff = ((rg0 + rgs) * 16u * a.wpr_ld + 16u * NH * q0) * 4u, i_ri = 0, iu = 0;  // next unit to request
+    // the units of a wave in order: for each of its K ranges (cq = q0, q0 + W, ..) its row groups (rgs, rgs + rgstep, ..)
+    u32 i_q = q0, i_rg = rgs, i_ri = 0, iu = 0;  // next unit to request
     auto issue = [&](auto SLOT) {
         constexpr u32 s = decltype(SLOT)::value;
+        const u32 soff = (grp_base(rg0 + i_rg) * a.wpr_ld + 16u * NH * i_q) * 4u;
 #pragma unroll
         for (u32 hh = 0; hh < (u32)NH; hh++)
 #pragma unroll
-            for (u32 p = 0; p < (u32)BITS; p++)
-                aload128(Ar[s][hh][p], rq, lane_off, i_soff + 64u * hh + p * plane_bytes);
-        i_soff += rg_bytes;
-        if (++i_ri == nrg) i_ri = 0, i_soff += q_bytes;
+            for (u32 p = 0; p < (u32)BITS; p++) aload128(Ar[s][hh][p], rq, lane_off, soff + 64u * hh + p * plane_bytes);
+        i_rg += 1u << lrs;
+        if (++i_ri == nrg) i_ri = 0, i_rg = rgs, i_q += W;
         iu++;
     };
     if (n_units > 0u) issue(std::integral_constant<u32, 0>{});
@@ -573,6 +587,23 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
         __builtin_amdgcn_s_setprio(0);
     }
     stamp(1);
+    // RoPE epilogue: lane (c = 0, col = k < 2) of a row quad rotates the pair (rows 2 k, 2 k + 1 of the quad): its cos / sin now
+    u32 rp_row = 0, rp_cs[4] = {0u, 0u, 0u, 0u};
+    u32 rp_pos = 0;
+    if (a.rope) {
+        rp_pos = __builtin_amdgcn_readfirstlane(posv);
+        rp_row = grp_base(rg0 + e_rgl) + 2u * e_rq + e_col;  // the pair's first row (d < hd / 2), partner at + hd / 2
+        if (e_rgl < a.RGB) {  // (the epilogue's waves)
+            const u32 hd = 1u << a.lhd, d = rp_row & (hd - 1u);
+            const bool mine = e_c == 0u && e_col < 2u && (rp_row >> a.lhd) < a.H + a.Hkv && rp_pos < a.max_seq;
+            const rsrc_t rc = make_rsrc(a.cos_t, a.max_seq * hd * 2u), rs_ = make_rsrc(a.sin_t, a.max_seq * hd * 2u);
+            const u32 o = mine ? (rp_pos * hd + d) * 2u : OOB;
+            rp_cs[0] = (u32)__builtin_amdgcn_raw_buffer_load_b16(rc, (int)o, 0, 0);
+            rp_cs[1] = (u32)__builtin_amdgcn_raw_buffer_load_b16(rc, (int)o, (int)hd, 0);  // (+ hd / 2 elements)
+            rp_cs[2] = (u32)__builtin_amdgcn_raw_buffer_load_b16(rs_, (int)o, 0, 0);
+            rp_cs[3] = (u32)__builtin_amdgcn_raw_buffer_load_b16(rs_, (int)o, (int)hd, 0);
+        }
+    }
     // (ONE request site per register slot: a second site in another branch gets registers of its own and a copy at the
     // join -- made before the data lands)
     if (is_pro) {
@@ -737,7 +768,34 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
         stamp2(9);
         // every lane of the row quad holds the 4 sums
         const u32 row = (rg0 + e_rgl) * 16u + 4u * e_rq;
-        if (a.pairs) {
+        if (a.rope) {
+            // apply_rotary_pos_emb on fp16 values (inference/model.py:336-341): q_embed = (q * cos) + (rotate_half(q) * sin), three
+            // fp16-rounded operations on the GEMV's fp16 outputs; rotated q -> out (reference row order), rotated k and plain v ->
+            // the caches at *pos (KVCache.update, model.py:69-79).  A position past the cache writes nothing to the caches.
+            if constexpr (!PSUM) {
+                const u32 hd = 1u << a.lhd, head = rp_row >> a.lhd, d = rp_row & (hd - 1u);
+                const _Float16 lo = (_Float16)(e_col ? y[2] : y[0]), hi = (_Float16)(e_col ? y[3] : y[1]);
+                if (e_c == 0u && e_col < 2u && rp_row + (hd >> 1) < a.N) {
+                    if (head < a.H + a.Hkv) {
+                        const _Float16 c0 = __builtin_bit_cast(_Float16, (uint16_t)rp_cs[0]), c1 = __builtin_bit_cast(_Float16, (uint16_t)rp_cs[1]);
+                        const _Float16 s0 = __builtin_bit_cast(_Float16, (uint16_t)rp_cs[2]), s1 = __builtin_bit_cast(_Float16, (uint16_t)rp_cs[3]);
+                        const _Float16 olo = (_Float16)(lo * c0) + (_Float16)((-hi) * s0), ohi = (_Float16)(hi * c1) + (_Float16)(lo * s1);
+                        if (head < a.H) {
+                            gq_store_wt(a.out + rp_row, __builtin_bit_cast(uint16_t, olo));
+                            gq_store_wt(a.out + rp_row + (hd >> 1), __builtin_bit_cast(uint16_t, ohi));
+                        } else if (rp_pos < a.max_seq) {
+                            uint16_t *kp = a.kc + ((size_t)(head - a.H) * a.max_seq + rp_pos) * hd + d;
+                            gq_store_wt(kp, __builtin_bit_cast(uint16_t, olo));
+                            gq_store_wt(kp + (hd >> 1), __builtin_bit_cast(uint16_t, ohi));
+                        }
+                    } else if (rp_pos < a.max_seq) {
+                        uint16_t *vp = a.vc + ((size_t)(head - a.H - a.Hkv) * a.max_seq + rp_pos) * hd + d;
+                        gq_store_wt(vp, __builtin_bit_cast(uint16_t, lo));
+                        gq_store_wt(vp + (hd >> 1), __builtin_bit_cast(uint16_t, hi));
+                    }
+                }
+            }
+        } else if (a.pairs) {
             // rows (2 i, 2 i + 1) = (gate, up): F.silu(gate) * up on fp16 values -- inference/model.py:266.  Lane (c = 0, col = k)
             // takes pair k of the quad (one silu per lane instead of two on the tail)
             const u32 k = PSUM ? e_c : e_col;  // (PSUM: lanes c = 0, 1 of the quad)
@@ -829,16 +887,18 @@ int launch_pro(const StreamArgs &a, const StreamCfg &c, int pro, hipStream_t s) 
 
 unsigned long long *gq_debug_timing_buffer();  // ap_plane.hip (gq_debug_set_timing_buffer)
 
-// returns GQ_ENOTSUP when the shape is not served by this kernel (the caller goes on to ap_plane.hip / the exact kernels)
-int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K, int bits,
-                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
-    if (M != 1u || bits < 2 || bits > gq_env_int("GQ_ST_MAXBITS", 4)) return GQ_ENOTSUP;
+namespace {
+int stream_launch(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits, const void *normw,
+                  float eps, const void *resid, int pro, int pairs, const StreamArgs *rope, hipStream_t stream) {
+    if (bits < 2 || bits > gq_env_int("GQ_ST_MAXBITS", 4)) return GQ_ENOTSUP;
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
     if (((uintptr_t)qweight | (uintptr_t)x | (uintptr_t)normw | (uintptr_t)lut) & 15u) return GQ_ENOTSUP;
     StreamCfg c;
     if (!pick_stream_cfg(N, K, bits, c)) return GQ_ENOTSUP;
+    if (rope && c.psum) return GQ_ENOTSUP;
     StreamArgs a{};
+    if (rope) a = *rope;
     a.qw = qweight;
     a.lut = (const uint16_t *)lut;
     a.x = (const uint16_t *)x;
@@ -877,4 +937,43 @@ int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const 
     if (bits == 4) return launch_pro<4>(a, c, pro, stream);
 #endif
     return GQ_ENOTSUP;
+}
+}  // namespace
+
+// returns GQ_ENOTSUP when the shape is not served by this kernel (the caller goes on to ap_plane.hip / the exact kernels)
+int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K, int bits,
+                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
+    if (M != 1u) return GQ_ENOTSUP;
+    return stream_launch(x, out, qweight, lut, N, K, bits, normw, eps, resid, pro, pairs, nullptr, stream);
+}
+
+// The fused q / k / v projection of a decode step with RoPE and the KV-cache write in its epilogue (include/gq_hip.h).
+bool gq_ap_exact_mode();  // ap_gemv.hip
+extern "C" int gq_anyprec_qkv_rope_supported(uint32_t N, uint32_t K, int bits, uint32_t head_dim) {
+    StreamCfg c;
+    return bits == 2 && (head_dim == 64u || head_dim == 128u) && N % head_dim == 0u && gq_env_int("GQ_QKV_ROPE", 1) &&
+                   !gq_ap_exact_mode() && pick_stream_cfg(N, K, bits, c) && !c.psum
+               ? 1 : 0;
+}
+extern "C" int gq_anyprec_gemv_qkv_rope(const void *x, void *q_out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                                        const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
+                                        void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                                        void *stream) {
+    if (!x || !q_out || !qweight || !lut || !norm_weight || !pos || !cos_table || !sin_table || !k_cache || !v_cache)
+        return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (N != (n_head + 2u * n_kv_head) * head_dim) return gq_fail(GQ_EINVAL, "N must be (n_head + 2 n_kv_head) * head_dim.");
+    if (!gq_anyprec_qkv_rope_supported(N, K, bits, head_dim)) return gq_fail(GQ_ENOTSUP, "gq_anyprec_gemv_qkv_rope: shape / bit width not served.");
+    StreamArgs r{};
+    r.pos = pos;
+    r.cos_t = (const uint16_t *)cos_table;
+    r.sin_t = (const uint16_t *)sin_table;
+    r.kc = (uint16_t *)k_cache;
+    r.vc = (uint16_t *)v_cache;
+    r.rope = 1u;
+    r.H = n_head;
+    r.Hkv = n_kv_head;
+    r.lhd = head_dim == 128u ? 7u : 6u;
+    r.max_seq = max_seq;
+    const int rc = stream_launch(x, q_out, qweight, lut, N, K, bits, norm_weight, eps, nullptr, PRO_RMSNORM, 0, &r, (hipStream_t)stream);
+    return rc == GQ_ENOTSUP ? gq_fail(GQ_ENOTSUP, "gq_anyprec_gemv_qkv_rope: shape / bit width not served.") : rc;
 }

@@ -303,6 +303,144 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
     }
 }
 
+// ------------------------------------------------------------------------------------------------ attention, q / k rotated upstream
+// Round 4: the wqkv GEMV of the decode step applies RoPE in its epilogue and writes k / v of the current token straight into the
+// caches (ap_stream.hip, gq_anyprec_gemv_qkv_rope), so this launch starts at q k^T: no cos / sin round trip behind the position, no
+// rotation, no LDS staging of the current token, no barrier in front of the position streams.  And the first batch of cached rows
+// does not wait for the position either: the rows [0, PASS) are requested together with q and the position (one memory round trip
+// instead of two); which of them are valid (t <= pos) is decided when they have landed.  Rows past the position hold whatever
+// an earlier sequence left (finite or not): their scores are replaced and their V rows zeroed before use.
+// Same arithmetic as attn_decode_kernel otherwise (fp32 scores / softmax / weighted sum from fp16 operands, one fp16 rounding).
+#ifndef GQ_ATTN_SPEC
+#define GQ_ATTN_SPEC 32  // cached rows requested before the position is known (a multiple of 16)
+#endif
+template <int HD>
+__global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint16_t *q, const int *pos_ptr, const uint16_t *kc, const uint16_t *vc,
+                                                                     uint16_t *out, u32 H, u32 Hkv, u32 max_seq, float scale, u32 nsplit, float *ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr u32 NW = ATTN_WAVES;
+    constexpr int LPP = HD / 8, PPW = 64 / LPP, U = 4;
+    constexpr u32 NS = NW * PPW, PASS = NW * PPW * U;
+    float *sc = reinterpret_cast<float *>(smem);  // [2 * NS] running max / sum of the position streams
+    float *red2 = sc + 2u * NS;                   // [NS][HD] partial outputs
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    const u32 h = blockIdx.x, g = h / (H / Hkv), sp = blockIdx.y;
+    const u32 sub = l / LPP, ld = l % LPP;
+    const uint16_t *kcg = kc + (size_t)g * max_seq * HD, *vcg = vc + (size_t)g * max_seq * HD;
+    // requests that do not depend on the position: q, and (first split) the first batch of cached rows
+    const uint4 q4 = *reinterpret_cast<const uint4 *>(q + (size_t)h * HD + ld * 8);
+    uint4 kv[U], vv[U];
+    u32 t0 = w * PPW * U;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const u32 t = t0 + (u32)u * PPW + sub;
+        // (only the first GQ_ATTN_SPEC rows: every row requested ahead of the position is HBM traffic whether it is needed or not --
+        // 128 rows x 32 heads = 2 MiB per layer, which costs what the saved round trip gains)
+        const bool in = sp == 0u && t < max_seq && t < (u32)GQ_ATTN_SPEC;
+        kv[u] = in ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+        vv[u] = in ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+    }
+    const u32 pos = (u32)pos_ptr[0];
+    if (pos >= max_seq) {  // decoding past the cache: the head's output is poisoned (NaN logits), like attn_decode_kernel
+        if (sp == 0u && tid < HD) out[(size_t)h * HD + tid] = 0x7e00u;
+        return;
+    }
+    const bool solo = nsplit > 1u && pos + 1u <= 2u * PASS;  // a short context is not worth splitting (see attn_decode_kernel)
+    if (solo) {
+        if (sp > 0u) return;
+        nsplit = 1u;
+    }
+    const u32 per = nsplit > 1u ? (((pos + nsplit) / nsplit + PASS - 1u) / PASS) * PASS : pos + 1u;
+    const u32 p0 = sp * per, p1 = min(pos + 1u, p0 + per);
+    float qreg[8];
+    {
+        const u32 qw[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) qreg[2 * e] = h2f((uint16_t)(qw[e] & 0xFFFF)), qreg[2 * e + 1] = h2f((uint16_t)(qw[e] >> 16));
+    }
+    float m_run = -3.0e38f, s_run = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    bool have = sp == 0u && t0 + PPW * U <= (u32)GQ_ATTN_SPEC;  // the batch at t0 is already in registers
+    for (t0 = p0 + w * PPW * U; t0 < p1; t0 += NW * PPW * U) {
+        if (!have) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u32 t = t0 + (u32)u * PPW + sub;
+                const bool in = t < p1;
+                kv[u] = in ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+                vv[u] = in ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        have = false;
+        float pu[U], vfu[U][8];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 t = t0 + (u32)u * PPW + sub;
+            const bool valid = t < p1;
+            const u32 kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w}, vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                p += qreg[2 * e] * h2f((uint16_t)(kw[e] & 0xFFFF));
+                p += qreg[2 * e + 1] * h2f((uint16_t)(kw[e] >> 16));
+                vfu[u][2 * e] = valid ? h2f((uint16_t)(vw[e] & 0xFFFF)) : 0.f;
+                vfu[u][2 * e + 1] = valid ? h2f((uint16_t)(vw[e] >> 16)) : 0.f;
+            }
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
+            if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
+            pu[u] = valid ? p * scale : -3.0e38f;  // (a stale row past the position may have produced anything, NaN included)
+        }
+        float m_new = m_run;
+#pragma unroll
+        for (int u = 0; u < U; u++) m_new = fmaxf(m_new, pu[u]);
+        const float resc = __expf(m_run - m_new);
+        s_run *= resc;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] *= resc;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float wgt = pu[u] > -2.0e38f ? __expf(pu[u] - m_new) : 0.f;
+            s_run += wgt;
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += wgt * vfu[u][e];
+        }
+        m_run = m_new;
+    }
+    const u32 stream = w * PPW + sub;
+#pragma unroll
+    for (int e = 0; e < 8; e++) red2[stream * HD + ld * 8 + e] = acc[e];
+    if (ld == 0) {
+        sc[stream] = m_run;
+        sc[NS + stream] = s_run;
+    }
+    __syncthreads();
+    if (tid < HD) {
+        float M = -3.0e38f;
+#pragma unroll
+        for (u32 i = 0; i < NS; i++) M = fmaxf(M, sc[i]);
+        float o = 0.f, sum = 0.f;
+#pragma unroll
+        for (u32 i = 0; i < NS; i++) {
+            const float f = __expf(sc[i] - M);
+            sum += sc[NS + i] * f;
+            o += red2[i * HD + tid] * f;
+        }
+        if (nsplit > 1u) {
+            float *wp = ws + ((size_t)h * nsplit + sp) * (HD + 2u);
+            wp[tid] = o;
+            if (tid == 0) {
+                wp[HD] = M;
+                wp[HD + 1] = sum;
+            }
+        } else {
+            out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
+        }
+    }
+}
+
 // split-KV combine: out[h] = sum_s o_s e^(M_s - M) / sum_s l_s e^(M_s - M)
 template <int HD>
 __global__ void __launch_bounds__(HD) attn_combine_kernel(const float *ws, uint16_t *out, u32 nsplit, const int *pos_ptr, u32 max_seq) {
@@ -634,6 +772,38 @@ extern "C" int gq_attn_decode_qtip(const GqQtipOut *qkv_lin, const int *pos, con
     }
     return attn_launch<true>(nullptr, qt, pos, cos_table, sin_table, k_cache, v_cache, out, n_head, n_kv_head, head_dim, max_seq, scale, n_split,
                              workspace, stream);
+}
+
+
+// Attention of the decode step when the wqkv launch has already rotated q / k and written k / v of the current token into the
+// caches (gq_anyprec_gemv_qkv_rope): q fp16 [n_head * head_dim] rotated; the caches hold every position <= *pos.
+extern "C" int gq_attn_decode_roped(const void *q, const int *pos, const void *k_cache, const void *v_cache, void *out, uint32_t n_head,
+                                    uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, float scale, uint32_t n_split, float *workspace,
+                                    void *stream) {
+    if (!q || !pos || !k_cache || !v_cache || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (n_kv_head == 0 || n_head % n_kv_head) return gq_fail(GQ_EINVAL, "n_head must be a multiple of n_kv_head.");
+    if (head_dim != 64 && head_dim != 128) return gq_fail(GQ_ENOTSUP, "head_dim must be 64 or 128.");
+    if (n_split < 1u || n_split > 64u || (n_split > 1u && !workspace)) return gq_fail(GQ_EINVAL, "n_split in 1..64, with a workspace when > 1.");
+    if (((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
+    const u32 nstreams = (u32)ATTN_WAVES * 64u / (head_dim / 8u);
+    const size_t smem = ((size_t)2u * nstreams + (size_t)nstreams * head_dim) * 4u;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(n_head, n_split);
+    if (head_dim == 128) {
+        static GqPerDeviceOnce once;
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_roped_kernel<128>), 160 * 1024));
+        hipLaunchKernelGGL((attn_roped_kernel<128>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)q, pos, (const uint16_t *)k_cache,
+                           (const uint16_t *)v_cache, (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
+        if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(n_head), dim3(128), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
+    } else {
+        static GqPerDeviceOnce once;
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_roped_kernel<64>), 160 * 1024));
+        hipLaunchKernelGGL((attn_roped_kernel<64>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)q, pos, (const uint16_t *)k_cache,
+                           (const uint16_t *)v_cache, (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
+        if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(n_head), dim3(64), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
+    }
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
 }
 
 extern "C" int gq_attn_decode(const void *qkv, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,

@@ -666,13 +666,24 @@ class Transformer(nn.Module):
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2  # bytes per batch slot
         for li, blk in enumerate(self.layers[l0:l1]):
             at, ff = blk.attention, blk.feed_forward
-            ck(L.gq_anyprec_gemv_fused(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
-                                       at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
-                                       c.norm_eps, None, 0, st), "wqkv")
-            ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
-                                      at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride,
-                                      y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
-                                      b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, st), "attn")
+            kc, vc = at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride
+            ws = b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None
+            # RoPE + KV-cache write in the epilogue of the wqkv GEMV, attention without them, where the library serves the layer's
+            # wqkv that way (fast mode, 2-bit, K <= 4096: csrc/ap_stream.hip); else the two launches of rounds 1-3
+            if L.gq_anyprec_qkv_rope_supported(at.wqkv.out_features, c.dim, at.wqkv.bitwidth, c.head_dim):
+                ck(L.gq_anyprec_gemv_qkv_rope(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
+                                              at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
+                                              c.norm_eps, pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), kc, vc,
+                                              c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, st), "wqkv+rope")
+                ck(L.gq_attn_decode_roped(qkv.data_ptr(), pos.data_ptr(), kc, vc, y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim,
+                                          self.max_seq_length, scale, b["attn_split"], ws, st), "attn")
+            else:
+                ck(L.gq_anyprec_gemv_fused(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
+                                           at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
+                                           c.norm_eps, None, 0, st), "wqkv")
+                ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), kc, vc,
+                                          y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
+                                          ws, st), "attn")
             ck(L.gq_anyprec_gemv_fused(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
                                        at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, st), "wo")
             if pairs:

@@ -316,6 +316,28 @@ int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table,
                          void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
                          float scale, uint32_t n_split, float *workspace, void *stream);
 
+/*
+ * Round 4: RoPE and the KV-cache write in the EPILOGUE of the fused q / k / v projection, attention without them.
+ *
+ * gq_anyprec_gemv_qkv_rope = RMSNorm -> Any-Precision GEMV of the fused wqkv tensor (reference row order q | k | v, model.py:211;
+ * nothing is permuted in memory: the kernel picks its 16-row groups so that a lane owns both rotation partners d, d + head_dim / 2)
+ * -> apply_rotary_pos_emb on the fp16 outputs (model.py:330-341: three fp16-rounded operations, fp16 cos / sin tables) ->
+ *   q_out fp16 [n_head * head_dim] rotated queries;  k_cache[g][*pos][:] rotated keys;  v_cache[g][*pos][:] values
+ * (KVCache.update, model.py:69-79).  *pos >= max_seq writes nothing to the caches.  Replaces gq_anyprec_gemv_fused(wqkv) + the
+ * rotation / cache write inside gq_attn_decode_split; results are bit-identical to that chain (same GEMV arithmetic, same fp16
+ * rounding points).  gq_anyprec_qkv_rope_supported: 1 when this build serves (N, K, bits, head_dim) -- the caller keeps the
+ * two-launch form otherwise (GQ_ENOTSUP).
+ * gq_attn_decode_roped: single-query attention over positions 0..*pos of the caches for queries that are already rotated; the first
+ * batch of cached rows is requested together with q and the position (one memory round trip); arguments as gq_attn_decode_split. */
+int gq_anyprec_qkv_rope_supported(uint32_t N, uint32_t K, int bits, uint32_t head_dim);
+int gq_anyprec_gemv_qkv_rope(const void *x, void *q_out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                             const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
+                             void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                             void *stream);
+int gq_attn_decode_roped(const void *q, const int *pos, const void *k_cache, const void *v_cache, void *out, uint32_t n_head,
+                         uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, float scale, uint32_t n_split, float *workspace,
+                         void *stream);
+
 /* out[n] = sum_k rmsnorm?(x)[k] * W[n][k]      dense fp16 GEMV (lm_head `output`, model.py:94,128-129); fp32
  * accumulation, fp16 output; norm_weight == NULL skips the RMSNorm prologue.  K % 512 == 0. */
 int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint32_t K, const void *norm_weight, float eps,

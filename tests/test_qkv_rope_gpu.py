@@ -1,0 +1,140 @@
+"""GPU: RoPE + KV-cache write in the epilogue of the fused q / k / v GEMV (gq_anyprec_gemv_qkv_rope) and the attention launch that
+starts at q k^T (gq_attn_decode_roped) against the two launches they replace (gq_anyprec_gemv_fused + gq_attn_decode_split:
+inference/model.py:206-241 semantics, tested against torch in test_decode_gpu.py).  Same GEMV arithmetic (the stream kernel,
+csrc/ap_stream.hip), same fp16 rounding points of apply_rotary_pos_emb, same score / softmax order: caches and outputs bit for bit."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _setup(H, Hkv, hd, K, bits, max_seq, seed):
+    from guidedquant_amd.model import rope_tables
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d)
+    g.manual_seed(seed)
+    N = (H + 2 * Hkv) * hd
+    q = torch.randint(-2**31, 2**31 - 1, (bits, N, K // 32), dtype=torch.int32, device=d, generator=g)
+    lut = (torch.randn(N, 1 << bits, device=d, generator=g) * 0.03).half()
+    nw = (1 + 0.1 * torch.randn(K, device=d, generator=g)).half()
+    cos, sin = rope_tables(hd, max_seq, 500000.0, d)
+    return d, g, N, q, lut, nw, cos, sin
+
+
+@pytest.mark.parametrize("H,Hkv,hd,K,max_seq,nsplit", [(32, 8, 128, 4096, 64, 1), (32, 8, 128, 4096, 1024, 4), (32, 8, 64, 2048, 48, 1),
+                                                       (8, 2, 128, 4096, 40, 1)])
+def test_qkv_rope_chain_is_bit_identical_to_the_two_launches(H, Hkv, hd, K, max_seq, nsplit):
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    L.gq_set_ap_mode(0)
+    os.environ["GQ_PL_MIN_MWEIGHTS"] = "0"
+    os.environ["GQ_ST"] = "2"  # the unfused reference launch on the stream kernel too (same fp32 summation order)
+    L.gq_reset_env_cache()
+    try:
+        bits = 2
+        d, g, N, q, lut, nw, cos, sin = _setup(H, Hkv, hd, K, bits, max_seq, H + hd + K)
+        if not L.gq_anyprec_qkv_rope_supported(N, K, bits, hd):
+            pytest.skip("shape not served by the fused launch in this build")
+        st = _lib.current_stream_ptr()
+        kc = [torch.zeros(1, Hkv, max_seq, hd, dtype=torch.float16, device=d) for _ in range(2)]
+        vc = [torch.zeros_like(kc[0]) for _ in range(2)]
+        # stale rows past the position must not matter (the fused attention requests them before it knows the position)
+        positions = list(range(12)) + ([200, 201, 300, 555] if max_seq >= 1024 else [max_seq - 9])
+        junk = torch.randn(kc[0].shape, device=d, generator=g).half() * 50   # rows in the gaps: read by both chains, finite
+        junk[:, :, positions[-1] + 1:, ::7] = float("nan")                    # rows no step may use: anything, NaN included
+        for t in kc + vc:
+            t.copy_(junk)
+        ws = [torch.zeros(H * nsplit * (hd + 2), dtype=torch.float32, device=d) for _ in range(2)]
+        qkv = [torch.zeros(N, dtype=torch.float16, device=d) for _ in range(2)]
+        out = [torch.zeros(H * hd, dtype=torch.float16, device=d) for _ in range(2)]
+        scale = 1.0 / math.sqrt(hd)
+        # (positions are visited in order: both chains fill their caches the same way; gaps keep the junk rows of both identical)
+        for p in positions:
+            x = torch.randn(K, device=d, generator=g).half()
+            if p % 5 == 0:
+                x[torch.randint(0, K, (3,), device=d, generator=g)] *= 40.0  # massive channels through the extraction path
+            pos = torch.tensor([p], dtype=torch.int32, device=d)
+            _lib.check(L.gq_anyprec_gemv_fused(x.data_ptr(), qkv[0].data_ptr(), q.data_ptr(), lut.data_ptr(), N, K, bits, nw.data_ptr(), 1e-5,
+                                               None, 0, st), "wqkv")
+            _lib.check(L.gq_attn_decode_split(qkv[0].data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc[0].data_ptr(),
+                                              vc[0].data_ptr(), out[0].data_ptr(), H, Hkv, hd, max_seq, scale, nsplit,
+                                              ws[0].data_ptr() if nsplit > 1 else None, st), "attn")
+            _lib.check(L.gq_anyprec_gemv_qkv_rope(x.data_ptr(), qkv[1].data_ptr(), q.data_ptr(), lut.data_ptr(), N, K, bits, nw.data_ptr(), 1e-5,
+                                                  pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc[1].data_ptr(), vc[1].data_ptr(), H, Hkv, hd,
+                                                  max_seq, st), "wqkv+rope")
+            _lib.check(L.gq_attn_decode_roped(qkv[1].data_ptr(), pos.data_ptr(), kc[1].data_ptr(), vc[1].data_ptr(), out[1].data_ptr(), H, Hkv,
+                                              hd, max_seq, scale, nsplit, ws[1].data_ptr() if nsplit > 1 else None, st), "attn roped")
+            torch.cuda.synchronize()
+            assert torch.equal(kc[0][:, :, p].view(torch.int16), kc[1][:, :, p].view(torch.int16)), ("rotated keys", p)
+            assert torch.equal(vc[0][:, :, p].view(torch.int16), vc[1][:, :, p].view(torch.int16)), ("values", p)
+            assert torch.isfinite(out[1].float()).all(), (p, torch.isnan(out[1].float()).view(H, hd).sum(1).tolist())
+            assert torch.equal(out[0].view(torch.int16), out[1].view(torch.int16)), ("attention output", p, (out[0].float() - out[1].float()).abs().max().item())
+        # rotated queries against apply_rotary_pos_emb on the unfused projection's output
+        from guidedquant_amd.model import apply_rotary_pos_emb
+        qq = qkv[0][:H * hd].view(1, 1, H, hd).transpose(1, 2)
+        kk = qkv[0][H * hd:(H + Hkv) * hd].view(1, 1, Hkv, hd).transpose(1, 2)
+        p = positions[-1]
+        qr, _ = apply_rotary_pos_emb(qq, kk, cos[p:p + 1].unsqueeze(0), sin[p:p + 1].unsqueeze(0))
+        assert torch.equal(qr.transpose(1, 2).reshape(-1).view(torch.int16), qkv[1][:H * hd].view(torch.int16))
+        # past the cache: nothing written, output poisoned
+        before = (kc[1].clone(), vc[1].clone())
+        pos = torch.tensor([max_seq], dtype=torch.int32, device=d)
+        _lib.check(L.gq_anyprec_gemv_qkv_rope(x.data_ptr(), qkv[1].data_ptr(), q.data_ptr(), lut.data_ptr(), N, K, bits, nw.data_ptr(), 1e-5,
+                                              pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc[1].data_ptr(), vc[1].data_ptr(), H, Hkv, hd, max_seq,
+                                              st), "wqkv+rope")
+        _lib.check(L.gq_attn_decode_roped(qkv[1].data_ptr(), pos.data_ptr(), kc[1].data_ptr(), vc[1].data_ptr(), out[1].data_ptr(), H, Hkv, hd,
+                                          max_seq, scale, nsplit, ws[1].data_ptr() if nsplit > 1 else None, st), "attn roped")
+        torch.cuda.synchronize()
+        assert torch.equal(before[0].view(torch.int16), kc[1].view(torch.int16)) and torch.equal(before[1].view(torch.int16), vc[1].view(torch.int16))
+        assert torch.isnan(out[1].float()).all()
+    finally:
+        os.environ.pop("GQ_ST", None)
+        L.gq_reset_env_cache()
+        L.gq_set_ap_mode(-1)
+
+
+def test_decode_step_with_the_fused_launch_matches_the_two_launch_step():
+    """the whole native decode step at the 8B attention geometry: GQ_QKV_ROPE=0/1 give the same logits bit for bit"""
+    from guidedquant_amd import _lib
+    from guidedquant_amd.APLinear import APLinear
+    from guidedquant_amd.generate import random_init_
+    from guidedquant_amd.model import ModelArgs, Transformer
+    L = _lib.lib()
+    L.gq_set_ap_mode(0)
+    os.environ["GQ_PL_MIN_MWEIGHTS"] = "0"
+    d = torch.device("cuda:0")
+    cfg = ModelArgs(block_size=128, vocab_size=2048, n_layer=2, n_head=32, dim=4096, intermediate_size=2048, n_local_heads=8,
+                    rope_base=500000, model_name="llama-test")
+    m = Transformer(torch.float16, cfg, linear_class=APLinear, linear_kwargs=dict(bitwidth=2, device=d)).to(device=d, dtype=torch.float16)
+    random_init_(m, seed=3, lut_std=0.02)
+    m.eval()
+    m.setup_caches(1, 64)
+    toks = [5, 17, 900, 3, 3, 512, 44, 1023, 7, 7]
+    res = {}
+    try:
+        for flag in ("0", "1"):
+            os.environ["GQ_QKV_ROPE"] = flag
+            L.gq_reset_env_cache()
+            for b in m.layers:
+                b.attention.kv_cache.k_cache.zero_()
+                b.attention.kv_cache.v_cache.zero_()
+            outs = []
+            with torch.no_grad():
+                for p, t in enumerate(toks):
+                    lg = m.decode_native(torch.tensor([t], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d))
+                    torch.cuda.synchronize()
+                    outs.append(lg.clone())
+            res[flag] = (outs, [b.attention.kv_cache.k_cache.clone() for b in m.layers])
+        assert L.gq_anyprec_qkv_rope_supported(cfg.dim + 2 * 8 * 128, cfg.dim, 2, 128)
+        for a, b in zip(res["0"][0], res["1"][0]):
+            assert torch.isfinite(b.float()).all() and torch.equal(a.view(torch.int16), b.view(torch.int16))
+        for a, b in zip(res["0"][1], res["1"][1]):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    finally:
+        os.environ.pop("GQ_QKV_ROPE", None)
+        L.gq_reset_env_cache()
+        L.gq_set_ap_mode(-1)

@@ -18,6 +18,10 @@ for p in sorted({0, 10, 50, 99, S // 4, S // 2, S - 2} & set(range(S))):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         def run():
+            if os.environ.get("ROPED"):
+                _lib.check(L.gq_attn_decode_roped(qkv.data_ptr(), pos.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), H, Hkv, HD, S,
+                                                  0.088, NS, ws.data_ptr(), _lib.current_stream_ptr()), "attn")
+                return
             _lib.check(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(),
                                               out.data_ptr(), H, Hkv, HD, S, 0.088, NS, ws.data_ptr(), _lib.current_stream_ptr()), "attn")
         run(); s.synchronize()

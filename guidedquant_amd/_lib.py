@@ -19,7 +19,7 @@ EXPORTS = [
     "gq_dense_gemv_f16", "gq_sample_topk", "gq_qtip_linear_in", "gq_qtip_linear_out", "gq_qtip_transform", "gq_lutgemm_gemv_ws", "gq_attn_decode_split",
     "gq_attn_decode_qtip", "gq_qtip_linear_out_seg",
     "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
-    "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped",
+    "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck",
 ]
 _VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer")
 
@@ -108,6 +108,13 @@ def lib():
         L.gq_anyprec_gemm_ws_bytes.restype = ctypes.c_size_t
         L.gq_last_error.restype = ctypes.c_char_p
         _lib = L
+        # one-time hardware self-check (LDS out-of-range reads return zero: csrc/capi.hip) -- fail loudly, never corrupt sums
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing() and os.environ.get("GQ_SELFCHECK", "1") != "0":
+            rc = L.gq_selfcheck()
+            if rc != 0:
+                msg = L.gq_last_error()
+                _lib = None
+                raise RuntimeError(f"gq_selfcheck: {msg.decode() if msg else rc}")
     return _lib
 
 

@@ -61,3 +61,31 @@ extern "C" void gq_reset_env_cache(void) {
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env_cache.clear();
 }
+
+// Self-check of a hardware behaviour three kernels rest on (ap_plane.hip PL_BOOB / PL_LOOB, qtip.hip QT_XOOB): a ds_read from an
+// LDS address beyond the workgroup's allocation (192 KiB and up; the chip has 160 KiB) returns zeros -- the idle MFMA columns of
+// those kernels take their zeros from there.  Verified on gfx950 (tools/ubench/lds_oob.hip); another architecture, a sanitizer or
+// a compiler that lowers the access to flat addressing would corrupt sums silently, so the binding runs this once per process
+// and refuses to go on if it fails (rebuild with -DPL_BOOB=0 -DPL_LOOB=0 -DQT_XOOB=0 then).
+namespace {
+__global__ void lds_oob_probe(unsigned *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    sm[threadIdx.x] = 0xAB;
+    __syncthreads();
+    const uint4 v = *reinterpret_cast<const uint4 *>(sm + 0x30000u + 16u * threadIdx.x);
+    const uint4 w = *reinterpret_cast<const uint4 *>(sm + 0x38000u + 16u * threadIdx.x);
+    out[threadIdx.x] = v.x | v.y | v.z | v.w | w.x | w.y | w.z | w.w | (sm[threadIdx.x] == 0xAB ? 0u : 1u);
+}
+}  // namespace
+extern "C" int gq_selfcheck(void) {
+    unsigned *d = nullptr, h[64];
+    GQ_HIP_CHECK(hipMalloc(&d, sizeof(h)));
+    hipLaunchKernelGGL(lds_oob_probe, dim3(1), dim3(64), 1024, 0, d);
+    hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return gq_fail_hip(e, "gq_selfcheck");
+    for (unsigned v : h)
+        if (v) return gq_fail(GQ_ENOTSUP, "LDS reads beyond the workgroup's allocation do not return zero on this device: rebuild with "
+                                           "-DPL_BOOB=0 -DPL_LOOB=0 -DQT_XOOB=0 (csrc/ap_plane.hip, csrc/qtip.hip).");
+    return GQ_OK;
+}

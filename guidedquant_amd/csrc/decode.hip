@@ -753,7 +753,8 @@ extern "C" int gq_attn_decode_split(const void *qkv, const int *pos, const void 
 }
 
 // QTIP models: the same attention with the transform-out of the q, k and v linears folded in (qkv_lin[0..2]: the GqQtipOut
-// descriptors gq_qtip_linear_out would take; resid / out unused).  Bit-identical to gq_qtip_linear_out + gq_attn_decode_split.
+// descriptors gq_qtip_linear_out would take; resid / out unused).  Equal to gq_qtip_linear_out + gq_attn_decode_split up to fp32
+// rounding (the segments are combined first: the additions of the full transform in another order), not bit for bit.
 extern "C" int gq_attn_decode_qtip(const GqQtipOut *qkv_lin, const int *pos, const void *cos_table, const void *sin_table, void *k_cache,
                                    void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
                                    float scale, uint32_t n_split, float *workspace, void *stream) {
@@ -824,7 +825,8 @@ extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32
     const u32 ncu = (u32)cu_count();
     // ~3 blocks per CU (measured over 2 .. 16 on the 128256 x 4096 lm_head inside the decode step: 3 is 0.4 % of the token faster than 4,
     // 6 is 0.7 % slower), every block a multiple of 4 waves * RW rows
-    const u32 bpc = (u32)gq_env_int("GQ_DENSE_BPC", 3);
+    const int bpc_env = gq_env_int("GQ_DENSE_BPC", 3);
+    const u32 bpc = bpc_env >= 1 ? (u32)bpc_env : 1u;
     u32 rpb = (N + ncu * bpc - 1u) / (ncu * bpc);
     rpb = ((rpb + 4u * RW - 1u) / (4u * RW)) * (4u * RW);
     const u32 grid = (N + rpb - 1u) / rpb;

@@ -105,6 +105,9 @@ class DecodeGraph:
         m = self.model
         sig = [m.max_seq_length, m.max_batch_size, m.rope_cos.data_ptr(), m.rope_sin.data_ptr()]
         sig += [b.attention.kv_cache.k_cache.data_ptr() for b in m.layers]
+        # the weight tensors the captured launches read (model.to() / .half() or an in-place re-pair after a sub-module
+        # load_state_dict assign new ones; `_alloc_gen` is bumped on those events, this is what the re-validation compares)
+        sig += [t.data_ptr() for b in m.layers for t in list(b.buffers(recurse=True)) + list(b.parameters(recurse=True))]
         if m._native is not None:
             sig += [m._native["x"].data_ptr(), m._native["logits"].data_ptr()]
         return tuple(sig)

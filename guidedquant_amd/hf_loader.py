@@ -61,11 +61,20 @@ def load_anyprec_hf(path: str, bitwidth: int = None, device="cuda", dtype=torch.
         bitwidth = bits[0]
     if bitwidth not in bits:
         raise ValueError(f"bitwidth {bitwidth} not in the checkpoint's precisions {bits}")
+    return anyprec_state_dict_to_transformer(read_hf_state_dict(path), cfg, bitwidth, device, dtype)
+
+
+def anyprec_state_dict_to_transformer(sd: dict, cfg: dict, bitwidth: int, device="cuda", dtype=torch.float16) -> Transformer:
+    """HF-keyed Any-Precision tensors (host or device) + the config dict -> the fused decode model at `bitwidth`"""
     args = model_args_from_hf_config(cfg)
-    sd = read_hf_state_dict(path)
+    sd = {k: v for k, v in sd.items() if "rotary_emb" not in k}
     if "lm_head.weight" not in sd and cfg.get("tie_word_embeddings", False):
         sd["lm_head.weight"] = sd["model.embed_tokens.weight"]  # tied embeddings (Llama-3.2-1B)
     fused = convert_anyprec_fuse(sd, bitwidth, n_layer=args.n_layer)
-    model = Transformer(dtype, args, linear_class=APLinear, linear_kwargs=dict(bitwidth=bitwidth, device="cpu"), fuse_linears=True)
+    on_dev = all(v.device.type != "cpu" for v in fused.values())
+    model = Transformer(dtype, args, linear_class=APLinear, linear_kwargs=dict(bitwidth=bitwidth, device=device if on_dev else "cpu"),
+                        fuse_linears=True)
+    if on_dev:
+        model = model.to(device=device, dtype=dtype)
     model.load_state_dict(fused, strict=True)
     return model.to(device=device, dtype=dtype).eval()

@@ -277,6 +277,7 @@ def pair_gate_up_rows_(m) -> None:
     m.qweight.data = m.qweight.data[:, perm, :].contiguous()
     m.lut.data = m.lut.data[perm].contiguous()
     m.gq_row_pairs = True
+    m.gq_realloc_gen = getattr(m, "gq_realloc_gen", 0) + 1  # (new tensors: captured graphs must re-validate, Transformer._alloc_gen)
 
 
 def _unpair_on_export(module, state_dict, prefix, local_metadata):
@@ -338,6 +339,12 @@ class Transformer(nn.Module):
         self._native = None
         self._native_kind_cache = None
         self._alloc_gen = getattr(self, "_alloc_gen", 0) + 1  # captured graphs re-validate their pointers (generate.DecodeGraph.step)
+
+    def _apply(self, fn, *a, **k):
+        # .to() / .half() / .cuda() move or re-allocate every tensor a captured decode graph points at
+        r = super()._apply(fn, *a, **k)
+        self._reset_native()
+        return r
 
     @classmethod
     def from_name(cls, dtype, name: str, linear_class=nn.Linear, linear_kwargs=None, halve_layers=False,
@@ -566,7 +573,10 @@ class Transformer(nn.Module):
         # GQ_QTIP_ATTN_FOLD (default ON): the transform-out of q / k / v runs inside the attention launch -- every head block needs
         # head_dim of the outputs: the segments combined with the signs of its row, then one head_dim-point transform (equal to
         # gq_qtip_linear_out up to fp32 rounding) --: one launch (4.8 us) per layer less.  Needs power-of-two q / k / v widths.
-        attn_fold = os.environ.get("GQ_QTIP_ATTN_FOLD", "1") != "0" and not one_launch and c.head_dim in (64, 128)
+        # (gq_attn_decode_qtip serves n_head * head_dim <= 8192, a power of two; wider models keep gq_qtip_linear_out + attention)
+        qw = c.n_head * c.head_dim
+        attn_fold = (os.environ.get("GQ_QTIP_ATTN_FOLD", "1") != "0" and not one_launch and c.head_dim in (64, 128)
+                     and qw <= 8192 and (qw & (qw - 1)) == 0)
         layers = []
         prev_down = None
         for b in self.layers:
@@ -660,7 +670,9 @@ class Transformer(nn.Module):
         h, y, qkv, gu, pairs = b["h"], b["y"], b["qkv"], b["gu"], b["pairs"]
         if pairs:  # a load_state_dict into a sub-module bypasses _reset_native: the rows must still be paired at launch
             for blk in self.layers[l0:l1]:
-                pair_gate_up_rows_(blk.feed_forward.w1w3)
+                if not getattr(blk.feed_forward.w1w3, "gq_row_pairs", False):
+                    pair_gate_up_rows_(blk.feed_forward.w1w3)
+                    self._alloc_gen = getattr(self, "_alloc_gen", 0) + 1  # (the re-pair assigned new tensors)
         ck = _lib.check
         scale = 1.0 / math.sqrt(c.head_dim)
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2  # bytes per batch slot
@@ -728,7 +740,6 @@ class Transformer(nn.Module):
         T = start + S
         assert self.prefill_ready(idx) and input_pos.numel() == S and input_pos.dtype == torch.int32 and T <= self.max_seq_length
         dev = idx.device
-        st = _lib.current_stream_ptr()
         x = self.tok_embeddings(idx.view(1, S)).view(S, D).contiguous()
         xn = torch.empty_like(x)
         q = torch.empty((H, S, hd), dtype=torch.float16, device=dev)
@@ -737,6 +748,7 @@ class Transformer(nn.Module):
         rep = H // Hkv
         pending = None  # the previous block's MLP output: its residual add rides in the next RMSNorm launch
         with torch.cuda.device(dev):
+            st = _lib.current_stream_ptr()  # (the model's device's current stream: inside the guard)
             for b in self.layers:
                 att, ff = b.attention, b.feed_forward
                 _lib.check(L.gq_rmsnorm_rows(x.data_ptr(), pending.data_ptr() if pending is not None else None, b.input_layernorm.weight.data_ptr(), xn.data_ptr(),
@@ -761,7 +773,8 @@ class Transformer(nn.Module):
         """One bs=1 decode step.  tok, pos: int32 device tensors with one element.  Returns logits fp16 [1,1,V]
         (a persistent buffer, like the quantized linears' outputs).  Enqueues on the current stream only."""
         assert tok.dtype == torch.int32 and pos.dtype == torch.int32 and tok.is_cuda and pos.is_cuda
-        x = self._native_state()["x"]
-        self.native_embed(tok, x)
-        self.native_layers(x, pos, 0, len(self.layers))
-        return self.native_head(x)
+        with torch.cuda.device(self.output.weight.device):  # (launches go to the model's device's current stream)
+            x = self._native_state()["x"]
+            self.native_embed(tok, x)
+            self.native_layers(x, pos, 0, len(self.layers))
+            return self.native_head(x)

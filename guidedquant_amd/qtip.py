@@ -116,7 +116,7 @@ if "hadamard::hadamard" not in _registered:
 
     @torch.library.register_fake("hadamard::hadamard")
     def _hadamard_abstract(x, scale):
-        return x
+        return torch.empty_like(x)  # (a new tensor, like the implementation: returning x itself claims an alias -- opcheck)
 
     @torch.library.impl("hadamard::hadamard", "cuda")
     def _hadamard_cuda(x, scale):

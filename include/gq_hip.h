@@ -316,6 +316,11 @@ int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table,
                          void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
                          float scale, uint32_t n_split, float *workspace, void *stream);
 
+/* One-time device self-check of a hardware behaviour the plane / QTIP kernels rest on (an LDS read beyond the workgroup's
+ * allocation returns zeros: the idle MFMA columns take their zeros from there).  GQ_OK, or GQ_ENOTSUP with the rebuild flags in
+ * gq_last_error().  The Python binding calls it once per process on a GPU box. */
+int gq_selfcheck(void);
+
 /*
  * Round 4: RoPE and the KV-cache write in the EPILOGUE of the fused q / k / v projection, attention without them.
  *

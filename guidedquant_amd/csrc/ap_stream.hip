@@ -843,7 +843,8 @@ bool pick_stream_cfg(u32 N, u32 K, int bits, StreamCfg &c) {
     const u32 NCU = NC2 / (u32)ST_NH;
     if (NCU < c.W && (NCU & (NCU - 1u))) return false;  // the waves of a K range split its row groups evenly (shifts in the kernel)
     c.NPU = (NC2 + c.W - 1u) / c.W;
-    if (c.NPU > 2u) return false;
+    if (c.NPU == 3u) c.NPU = 4u;
+    if (c.NPU > (bits == 2 ? 4u : 2u)) return false;  // (images per builder wave compiled in)
     u32 rgb = (RGt + ncu - 1u) / ncu;
     if (rgb < 1u) rgb = 1u;
     c.RGB = rgb;
@@ -871,8 +872,13 @@ int launch_inst(const StreamArgs &a, const StreamCfg &c, hipStream_t s) {
 template <int BITS, int PRO>
 int launch_npu(const StreamArgs &a, const StreamCfg &c, hipStream_t s) {
     if constexpr (BITS == 2) {
+        if (c.NPU == 4u) {  // K > 16384 (the 70B down projection in one launch): summed parking only, no RMSNorm in front of it
+            if constexpr (PRO != PRO_RMSNORM) return c.psum ? launch_inst<BITS, PRO, 4, true>(a, c, s) : GQ_ENOTSUP;
+            return GQ_ENOTSUP;
+        }
         if (!c.psum) return c.NPU == 1u ? launch_inst<BITS, PRO, 1, false>(a, c, s) : launch_inst<BITS, PRO, 2, false>(a, c, s);
     }
+    if (c.NPU > 2u) return GQ_ENOTSUP;
     return c.NPU == 1u ? launch_inst<BITS, PRO, 1, true>(a, c, s) : launch_inst<BITS, PRO, 2, true>(a, c, s);
 }
 template <int BITS>
@@ -927,7 +933,7 @@ int stream_launch(const void *x, void *out, const uint32_t *qweight, const void 
         if (c.smem > 160u * 1024u) a.dbg = nullptr;
     }
 #ifndef ST_MAXBITS
-#define ST_MAXBITS 2  // bit widths compiled in
+#define ST_MAXBITS 4  // bit widths compiled in
 #endif
     if (bits == 2) return launch_pro<2>(a, c, pro, stream);
 #if ST_MAXBITS >= 3

@@ -4,7 +4,7 @@ from guidedquant_amd import _lib
 os.environ['GQ_PL_MIN_MWEIGHTS']='0'
 L=_lib.lib(); L.gq_set_ap_mode(0)
 d=torch.device("cuda:0")
-for (N,K) in [(8192,28672),(57344,8192)]:
+for (N,K) in [(4096,4096),(8192,8192)]:
     torch.manual_seed(N+K)
     q=torch.randint(-2**31,2**31-1,(2,N,K//32),dtype=torch.int32,device=d); lut=(torch.randn(N,4,device=d)*0.02).half()
     x=torch.randn(K,device=d).half(); res=torch.randn(N,device=d).half()

@@ -19,7 +19,7 @@ EXPORTS = [
     "gq_dense_gemv_f16", "gq_sample_topk", "gq_qtip_linear_in", "gq_qtip_linear_out", "gq_qtip_transform", "gq_lutgemm_gemv_ws", "gq_attn_decode_split",
     "gq_attn_decode_qtip", "gq_qtip_linear_out_seg",
     "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
-    "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck",
+    "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck", "gq_hop_send", "gq_hop_wait",
 ]
 _VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer")
 
@@ -97,6 +97,8 @@ def lib():
         L.gq_anyprec_pack.argtypes = [vp, vp, u32, u32, i32, vp]
         L.gq_lnq_cd_block.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, vp]
         L.gq_debug_set_timing_buffer.argtypes = [vp]
+        L.gq_hop_send.argtypes = [vp, vp, u32, vp, vp, u32, vp]
+        L.gq_hop_wait.argtypes = [vp, vp, u32, vp, u32, vp]
         L.gq_anyprec_qkv_rope_supported.argtypes = [u32, u32, i32, u32]
         L.gq_anyprec_gemv_qkv_rope.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, vp, vp, vp, vp, u32, u32, u32, u32, vp]
         L.gq_attn_decode_roped.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp]

@@ -23,9 +23,15 @@ What one stage tick is on the GPU (native path):
   * transport: device tensors go straight into isend / irecv (RCCL).  With a backend that only moves host memory (gloo; used
     to run the multi-rank native path on ONE GPU in the tests) each hop is staged through a pinned host buffer -- same
     schedule, same graphs.
+  * hop="ipc" (GQ_PP_HOP=ipc; round 4): no send / receive calls at all.  Every stage maps the NEXT stage's hidden-state slots
+    and sequence words (torch's CUDA IPC: the peer may be another process on the same GPU -- how the tests run it -- or a peer
+    GPU over xGMI), its tick graph ENDS with gq_hop_send (system-scope stores of the 8-16 KiB vector, then the slot's sequence
+    word = its tick number) and BEGINS with gq_hop_wait (one wave polls its own sequence word, bounded); the sampled token returns
+    to stage 0 the same way.  The host replays graphs and never synchronises inside a run.
 `stage_ranges(.., head_cost_layers=measure_head_cost(model))` balances the stages with the measured cost of the head.
 `PipelinedDecoder.run(n_tokens)` decodes n_tokens for each of the S sequences and returns them (on every rank).
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -83,15 +89,19 @@ class PipelinedDecoder:
 
     def __init__(self, model, rank: int, world: int, layers: range, n_seq: Optional[int] = None, max_new_tokens: int = 100,
                  temperature: float = 0.0, top_k: Optional[int] = 32, bos_id: int = 1, native: Optional[bool] = None, group=None,
-                 feedback_group=None, use_graphs: Optional[bool] = None, seed: int = 1234):
+                 feedback_group=None, use_graphs: Optional[bool] = None, seed: int = 1234, hop: Optional[str] = None):
         self.model, self.rank, self.world, self.layers = model, rank, world, layers
         self.n_seq = S = n_seq or world
         self.group = group
         # a second communicator for the token feedback (see module docstring); the caller may pass one, else it is created
         # collectively here (every rank constructs the decoder)
         self.fb_group = feedback_group
-        if self.fb_group is None and world > 1:
+        if self.fb_group is None and world > 1 and (hop or os.environ.get("GQ_PP_HOP", "p2p")) != "ipc":
             self.fb_group = dist.new_group(ranks=list(range(world)))
+        self.hop = (hop or os.environ.get("GQ_PP_HOP", "p2p")) if world > 1 else "p2p"
+        assert self.hop in ("p2p", "ipc")
+        if self.fb_group is None and world > 1 and self.hop == "ipc":
+            self.fb_group = group  # (no feedback communicator needed: the token returns through mapped memory)
         self.first, self.last = rank == 0, rank == world - 1
         self.temperature, self.top_k, self.bos_id, self.seed = temperature, top_k, bos_id, seed
         dev = model.output.weight.device
@@ -101,14 +111,17 @@ class PipelinedDecoder:
         c = model.config
         dt = model.output.weight.dtype
         self.h = torch.zeros(S, c.dim, dtype=dt, device=dev)          # per-slot hidden state (received into / computed in place / sent)
-        self.tok = torch.zeros(S, dtype=torch.int32, device=dev)      # per-slot input token (stage 0)
-        self.tok_out = torch.zeros(S, dtype=torch.int32, device=dev)  # per-slot sampled token (last stage)
+        # (token rows of 16 bytes: the device-to-device hop moves 16-byte units)
+        self._tok4 = torch.zeros(S, 4, dtype=torch.int32, device=dev)
+        self._tok_out4 = torch.zeros(S, 4, dtype=torch.int32, device=dev)
+        self.tok = self._tok4[:, 0]          # per-slot input token (stage 0)
+        self.tok_out = self._tok_out4[:, 0]  # per-slot sampled token (last stage)
         self.pos_dev = torch.zeros(S, dtype=torch.int32, device=dev)  # per-slot position, advanced on the device
         self.pos = [0] * S                                            # host mirror (eager path only)
         self.use_graphs = (self.native and dev.type == "cuda") if use_graphs is None else use_graphs
         self.graphs = None
         # host staging: the process group cannot move device memory (gloo) but the model lives on a GPU
-        self.staged = world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo"
+        self.staged = world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo" and self.hop != "ipc"
         if self.staged:
             self.h_host = torch.zeros(S, c.dim, dtype=dt).pin_memory()
             self.tok_host = torch.zeros(S, dtype=torch.int32).pin_memory()
@@ -119,8 +132,70 @@ class PipelinedDecoder:
         if self.native:
             # the QTIP launch plans are bound to the model's own hidden-state buffer: compute there, copy in / out
             self._x = model._native_state()["x"] if model._native_kind() == "qtip" else None
+        if self.hop == "ipc":
+            assert self.native and self.use_graphs and dev.type == "cuda", "hop='ipc' is the native graph path on GPUs"
+            self._setup_ipc(max_new_tokens)
         if self.use_graphs:
             self._capture()
+
+    # -- device-to-device hops (hop="ipc") ------------------------------------------------------------------------
+    def _setup_ipc(self, max_new_tokens):
+        """sequence words, tick counters, and the peers' buffers mapped into this process"""
+        from torch.multiprocessing.reductions import reduce_tensor
+        S, dev = self.n_seq, self.dev
+        self.seq_h = torch.zeros(S, dtype=torch.int32, device=dev)     # incoming hidden state of slot s carries tick number seq_h[s]
+        self.seq_tok = torch.ones(S, dtype=torch.int32, device=dev)    # (stage 0) incoming token ...; 1 = the BOS token of tick 1
+        self.tick = torch.zeros(S, dtype=torch.int32, device=dev)      # ticks of slot s completed on this stage
+        self.tick64 = torch.zeros(S, dtype=torch.int64, device=dev)
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.out_buf = torch.zeros(S, max_new_tokens + 1, dtype=torch.int32, device=dev)
+        self.spins = int(os.environ.get("GQ_HOP_SPINS", str(1 << 21)))
+        torch.cuda.synchronize()
+        mine = {k: reduce_tensor(t) for k, t in (("h", self.h), ("seq_h", self.seq_h), ("tok", self._tok4), ("seq_tok", self.seq_tok))}
+        allh = [None] * self.world
+        dist.all_gather_object(allh, mine, group=self.group)
+
+        def open_(rank_, key):
+            fn, args = allh[rank_][key]
+            return fn(*args)
+
+        self._peer = {}
+        if not self.last:
+            self._peer["h"], self._peer["seq_h"] = open_(self.rank + 1, "h"), open_(self.rank + 1, "seq_h")
+        else:
+            self._peer["tok"], self._peer["seq_tok"] = open_(0, "tok"), open_(0, "seq_tok")
+        dist.barrier(group=self.group)  # every mapping is open before anybody may free or reuse
+
+    def _tick_ipc(self, slot: int):
+        from . import _lib
+        L, st = _lib.lib(), _lib.current_stream_ptr()
+        tick = self.tick[slot:slot + 1]
+        seq = self.seq_tok if self.first else self.seq_h
+        _lib.check(L.gq_hop_wait(seq[slot:slot + 1].data_ptr(), tick.data_ptr(), 1, self.err.data_ptr(), self.spins, st), "gq_hop_wait")
+        self._tick_native(slot)
+        c = self.model.config
+        if not self.last:
+            _lib.check(L.gq_hop_send(self.h[slot].data_ptr(), self._peer["h"][slot].data_ptr(), c.dim * 2, self._peer["seq_h"][slot:slot + 1].data_ptr(),
+                                     tick.data_ptr(), 1, st), "gq_hop_send")
+        else:
+            self.out_buf[slot].index_copy_(0, self.tick64[slot:slot + 1], self.tok_out[slot:slot + 1])
+            _lib.check(L.gq_hop_send(self._tok_out4[slot].data_ptr(), self._peer["tok"][slot].data_ptr(), 16, self._peer["seq_tok"][slot:slot + 1].data_ptr(),
+                                     tick.data_ptr(), 2, st), "gq_hop_send")
+        tick.add_(1)
+        self.tick64[slot:slot + 1].add_(1)
+
+    def _run_ipc(self, n_tokens: int) -> torch.Tensor:
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)  # every stage has reset its sequence words
+        for _ in range(n_tokens):
+            for slot in range(self.n_seq):
+                self.graphs[slot].replay()
+        torch.cuda.synchronize()
+        if int(self.err.item()):
+            raise RuntimeError("device-to-device hop: a stage waited for its input beyond the spin limit (GQ_HOP_SPINS)")
+        out = self.out_buf[:, :n_tokens].contiguous()
+        dist.broadcast(out, src=self.world - 1, group=self.group)
+        return out
 
     # -- stage compute -------------------------------------------------------------------------------------------
     def _tick_native(self, slot: int):
@@ -183,7 +258,7 @@ class PipelinedDecoder:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():
-            for slot in range(self.n_seq):  # warm-up: lazy kernel attributes, allocator
+            for slot in range(self.n_seq):  # warm-up: lazy kernel attributes, allocator (without the hops: no peer is ticking yet)
                 self._tick_native(slot)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -191,7 +266,10 @@ class PipelinedDecoder:
         for slot in range(self.n_seq):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
-                self._tick_native(slot)
+                if self.hop == "ipc":
+                    self._tick_ipc(slot)
+                else:
+                    self._tick_native(slot)
             self.graphs.append(g)
         torch.cuda.synchronize()
         self.reset()
@@ -202,6 +280,13 @@ class PipelinedDecoder:
         self.pos = [0] * self.n_seq
         if self.native and self.last:
             self.rng_counter.zero_()
+        if self.hop == "ipc":
+            self.tick.zero_()
+            self.tick64.zero_()
+            self.seq_h.zero_()
+            self.seq_tok.fill_(1)
+            self._tok4.zero_()
+            self._tok4[:, 0] = self.bos_id
 
     def _tick(self, slot: int):
         if self.graphs is not None:
@@ -215,6 +300,8 @@ class PipelinedDecoder:
     # -- schedule ------------------------------------------------------------------------------------------------
     def run(self, n_tokens: int) -> torch.Tensor:
         """returns int32 [n_seq, n_tokens] (valid on every rank: broadcast from the last stage at the end)"""
+        if self.hop == "ipc":
+            return self._run_ipc(n_tokens)
         w, r, S = self.world, self.rank, self.n_seq
         out = torch.zeros(S, n_tokens, dtype=torch.int32, device=self.dev)
         recv_req = [None] * S  # the posted receive of each slot's next input

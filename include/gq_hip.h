@@ -316,6 +316,17 @@ int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table,
                          void *v_cache, void *out, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
                          float scale, uint32_t n_split, float *workspace, void *stream);
 
+/*
+ * Device-to-device hand-over of the layer pipeline (round 4; reference precedent: the host-side `.to(device)` hops of
+ * qtip/lib/utils/shard_model.py:44-68).  gq_hop_send: copy `nbytes` (multiple of 16) from src into dst_remote -- memory of the
+ * next stage, mapped into this process (hipIpc / torch's CUDA IPC; same GPU or a peer over xGMI) -- with system-scope stores, then
+ * store *seq_remote = *tick + add behind them.  gq_hop_wait: spin (one wave, bounded: max_spins polls of ~1 us, 0 = 2^21) until
+ * *seq_local >= *tick + add; on expiry *err = 1 and the launch returns (the GPU never hangs on a missing peer).  `tick` is a word
+ * in device memory the caller's graph increments per tick.
+ */
+int gq_hop_send(const void *src, void *dst_remote, uint32_t nbytes, uint32_t *seq_remote, const uint32_t *tick, uint32_t add, void *stream);
+int gq_hop_wait(const uint32_t *seq_local, const uint32_t *tick, uint32_t add, uint32_t *err, uint32_t max_spins, void *stream);
+
 /* One-time device self-check of a hardware behaviour the plane / QTIP kernels rest on (an LDS read beyond the workgroup's
  * allocation returns zeros: the idle MFMA columns take their zeros from there).  GQ_OK, or GQ_ENOTSUP with the rebuild flags in
  * gq_last_error().  The Python binding calls it once per process on a GPU box. */

@@ -32,7 +32,7 @@ def _model(dev):
     return m.eval()
 
 
-def _worker(rank, world, port, ntok, q, backend="nccl", one_gpu=False):
+def _worker(rank, world, port, ntok, q, backend="nccl", one_gpu=False, hop="p2p", n_seq=None):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -46,8 +46,8 @@ def _worker(rank, world, port, ntok, q, backend="nccl", one_gpu=False):
         from guidedquant_amd.pipeline import PipelinedDecoder, stage_ranges
         model = _model(dev)
         rng = stage_ranges(model.config.n_layer, world, head_cost_layers=1.0)[rank]
-        dec = PipelinedDecoder(model, rank, world, rng, n_seq=world, max_new_tokens=ntok, temperature=0.0, top_k=32, bos_id=1)
-        assert dec.native and dec.graphs is not None and dec.staged == (backend == "gloo")
+        dec = PipelinedDecoder(model, rank, world, rng, n_seq=n_seq or world, max_new_tokens=ntok, temperature=0.0, top_k=32, bos_id=1, hop=hop)
+        assert dec.native and dec.graphs is not None and dec.staged == (backend == "gloo" and hop == "p2p")
         with torch.no_grad():
             out = dec.run(ntok)
             dec.reset()
@@ -113,3 +113,33 @@ def test_pipelined_native_decode_ranks_sharing_one_gpu(world):
             if p.is_alive():
                 p.kill()
     assert all(row == ref for row in got) and got2 == got
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,n_seq", [(2, 2), (3, 3), (2, 1)])
+def test_pipelined_decode_device_to_device_hops_ranks_sharing_one_gpu(world, n_seq):
+    """hop="ipc": the stages hand the hidden state and the sampled token over through IPC-mapped device memory (gq_hop_send /
+    gq_hop_wait at the ends of every tick graph; no send / receive call, no host synchronisation inside a run) -- `world`
+    processes on cuda:0, tokens of every sequence equal the single-process decode, also on a second run, also with ONE sequence
+    in flight (the reference's use case)"""
+    import torch.multiprocessing as mp
+    from guidedquant_amd.generate import generate
+    ntok = 12
+    d0 = torch.device("cuda", 0)
+    ref = generate(_model(d0), torch.tensor([1], dtype=torch.int32, device=d0), ntok, use_graph=False, temperature=0.0, top_k=32)[0, 1:].tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ntok, q, "gloo", True, "ipc", n_seq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got, got2 = q.get(timeout=600)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert len(got) == n_seq and all(row == ref for row in got) and got2 == got

@@ -683,7 +683,7 @@ def guarded_pipeline_record(line, rank, world, dev, limit_s=240.0):
                "ms_per_stage_tick": round(dt / (world * n_tok) * 1e3, 4), "head_cost_layers_measured": dec.head_cost_layers,
                "layers_per_stage": [len(r) for r in __import__("guidedquant_amd.pipeline", fromlist=["stage_ranges"]).stage_ranges(
                    model.config.n_layer, world, head_cost_layers=dec.head_cost_layers)],
-               "graphs": bool(dec.graphs), "note": "single-stream 1-GPU figure of the same model: python bench.py --model " + PP_MODEL}
+               "graphs": bool(dec.graphs), "hop": dec.hop, "note": "single-stream 1-GPU figure of the same model: python bench.py --model " + PP_MODEL}
     except Exception as e:  # the replicas measurement stands on its own
         rec = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     timer.cancel()

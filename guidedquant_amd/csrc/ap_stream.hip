@@ -502,9 +502,10 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
                 s1 = __builtin_amdgcn_fdot2(u2h2(ab), one2, s1, false);
                 xsum = __builtin_amdgcn_fdot2(u2h2(t), one2, xsum, false);
             }
-            // statistics of the unit: maximum -> power of two (ONE scale per MFMA column: tools/ubench/scale_probe.hip -- the scale
-            // operand is taken from lanes 0..15 for all of K, there are no per-32-element scales inside one instruction), mean
-            // magnitude -> extraction threshold; per DPP row the sum for the coef[0] term
+            // statistics of the unit: maximum -> power of two (ONE scale per unit, the same in every lane: a version with one scale
+            // per 128-activation block, supplied by the block's lane group, failed test_hot_channels_* by 5.7e-4 of sum|w||x| as
+            // soon as the blocks of a unit differed -- the scale operand does not act per 32-element block the way that assumed),
+            // mean magnitude -> extraction threshold; per DPP row the sum for the coef[0] term
             const u32 mxl = max((u32)mxp[0], (u32)mxp[1]);
             const float xmax = lane63(wave_reduce<true>(h2f((uint16_t)mxl)));
             const float tot1 = lane63(wave_reduce<false>(s1));

@@ -44,6 +44,14 @@ __global__ void k(float *out, const int *src, int iters) {
                 int4 x0 = p[0], x1 = p[1];
                 b = (v8i){x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             }
+            if (MODE == 10 || MODE == 11) {  // the stream kernel's pattern: 4 masks of the FP4 operand per MFMA (+ 4 unrelated VALU operations)
+#pragma unroll
+                for (int i = 0; i < 4; i++) a0[i] = w[i] & (0x11111111 << (j & 3));
+            }
+            if (MODE == 11) {
+#pragma unroll
+                for (int i = 4; i < 8; i++) w[i] = (w[i] >> 1) ^ 0x5555;
+            }
             if (MODE == 6) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) a0[i] = w[i] & (0x11111111 << (j & 3));
@@ -51,7 +59,7 @@ __global__ void k(float *out, const int *src, int iters) {
             v8i &aa = (MODE == 2 && (j & 1)) ? a1 : a0;
             if (MODE == 5 || MODE == 6)  // fp4 x fp4
                 acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 4, 4, 0, 141, 0, 127);
-            else if (MODE == 7)  // fp4 A x bf8 B
+            else if (MODE == 7 || MODE == 10 || MODE == 11)  // fp4 A x bf8 B
                 acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 4, 1, 0, 141, 0, 127);
             else if (MODE == 8)  // fp6 x fp6
                 acc[j % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc[j % NACC], 2, 2, 0, 141, 0, 127);
@@ -99,5 +107,7 @@ int main() {
     run<7, 3>("fp4 A x bf8 B MFMA only", out, src);
     run<8, 3>("fp6 x fp6 MFMA only", out, src);
     run<9, 3>("fp4 A x fp6 B MFMA only", out, src);
+    run<10, 3>("fp4 A x bf8 B, 4 v_and -> A + MFMA", out, src);
+    run<11, 3>("fp4 A x bf8 B, 4 v_and + 8 other VALU + MFMA", out, src);
     return 0;
 }

@@ -29,10 +29,25 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) u64 gu64;
 
 constexpr int NPH = 5;
-__host__ __device__ constexpr u32 kb_of(int ph) { return ph == 0 ? 24u : ph == 2 ? 16u : ph == 3 ? 112u : ph == 4 ? 56u : 0u; }    // weight KiB per CU
+// -DCFG=0: Llama-3-8B 2-bit (54 MB per layer)   1: Llama-3-8B 4-bit (109 MB)   2: Llama-3.3-70B 2-bit (214 MB)
+#ifndef CFG
+#define CFG 0
+#endif
+#if CFG == 2
+__host__ __device__ constexpr u32 kb_of(int ph) { return ph == 0 ? 80u : ph == 2 ? 64u : ph == 3 ? 448u : ph == 4 ? 224u : 0u; }
+__host__ __device__ constexpr u32 nout_of(int ph) { return ph == 0 ? 40u : ph == 1 ? 128u : ph == 3 ? 112u : 32u; }
+__host__ __device__ constexpr u32 nin_of(int ph) { return ph == 1 ? 384u : ph == 4 ? 28672u : 8192u; }
+constexpr u32 NSLOT = 6, NATT = 64;  // (the gathered w2 input is 56 KiB of LDS: 6 ring slots fit beside it)
+#else
+__host__ __device__ constexpr u32 kb_of(int ph) { return (CFG + 1u) * (ph == 0 ? 24u : ph == 2 ? 16u : ph == 3 ? 112u : ph == 4 ? 56u : 0u); }    // weight KiB per CU
 __host__ __device__ constexpr u32 nout_of(int ph) { return ph == 0 ? 24u : ph == 1 ? 128u : ph == 3 ? 56u : 16u; }                // output halves per producing CU
 __host__ __device__ constexpr u32 nin_of(int ph) { return ph == 1 ? 384u : ph == 4 ? 14336u : 4096u; }
-constexpr u32 SLOT = 16384, NSLOT = 8, LAYER_KB = 24 + 16 + 112 + 56;
+constexpr u32 NSLOT = 8, NATT = 32;
+#endif
+constexpr u32 SLOT = 16384, LAYER_KB = kb_of(0) + kb_of(2) + kb_of(3) + kb_of(4);
+constexpr u32 XL_WORDS = nin_of(4) / 2u, NGRAN = 16384;
+__host__ __device__ constexpr u32 fills_of(int ph) { return (kb_of(ph) + 15u) / 16u; }
+__host__ __device__ constexpr u32 kb_before(int ph) { return ph == 0 ? 0u : ph <= 2 ? kb_of(0) : ph == 3 ? kb_of(0) + kb_of(2) : kb_of(0) + kb_of(2) + kb_of(3); }
 constexpr u32 SPIN_MAX = 1u << 21;
 
 __device__ __forceinline__ u32 sgpr(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -53,26 +68,51 @@ template <int PH>
 __global__ void __launch_bounds__(256) phase_kernel(const unsigned char *weights, u64 wbytes, u32 layer, const uint16_t *vin, uint16_t *vout, u32 *sink) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const u32 tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63u;
-    if (PH == 1 && blockIdx.x >= 32u) return;
+    if (PH == 1 && blockIdx.x >= NATT) return;
     u32 acc = 0;
+    constexpr bool RINGED = kb_of(PH) > 128u;  // share larger than the LDS: every wave streams its quarter through two private 16 KiB slots
     // weight share of this CU: KB KiB at a rotating offset; wave w issues every 4th KiB
-    if (kb_of(PH)) {
-        const u64 base = (((u64)layer * LAYER_KB + (PH == 0 ? 0 : PH == 2 ? 24 : PH == 3 ? 40 : 152)) * 256u + (u64)blockIdx.x * kb_of(PH)) * 1024u % (wbytes - (1u << 20));
-        const u32x4 rs = make_rsrc(weights + (base & ~1023ull), 1u << 20);
+    const u64 base = (((u64)layer * LAYER_KB + kb_before(PH)) * 256u + (u64)blockIdx.x * kb_of(PH)) * 1024u % (wbytes - (1u << 20));
+    const u32x4 rs = make_rsrc(weights + (base & ~1023ull), 1u << 20);
+    if (kb_of(PH) && !RINGED) {
         for (u32 i = w; i < kb_of(PH); i += 4u) dma16(rs, (u32)(uintptr_t)smem + i * 1024u, l * 16u, i * 1024u);
+    }
+    if (RINGED) {
+#pragma unroll
+        for (u32 i = 0; i < 16u; i++) dma16(rs, (u32)(uintptr_t)smem + (w * 32u + i) * 1024u, l * 16u, (w * (kb_of(PH) / 4u) + i) * 1024u);
     }
     // input vector: plain 16-byte loads spread over the block (every CU reads all of it, as the real kernels do)
     const u32 npieces = PH == 1 ? 48u : nin_of(PH) / 8u;
-    const uint16_t *src = PH == 1 ? vin + (blockIdx.x % 32u) * 128u : vin;
+    const uint16_t *src = PH == 1 ? vin + (blockIdx.x % NATT) * 128u : vin;
     for (u32 p = tid; p < npieces; p += 256u) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + 8u * p);
         acc ^= v.x ^ v.y ^ v.z ^ v.w;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (u32 p = tid; p < kb_of(PH) * 64u; p += 256u) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(smem + 16u * p);
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    if (RINGED) {
+        constexpr u32 NF = kb_of(PH) / 64u;  // 16 KiB fills per wave
+        for (u32 f = 0; f < NF; f++) {
+            if (f + 1u < NF) {
+#pragma unroll
+                for (u32 i = 0; i < 16u; i++)
+                    dma16(rs, (u32)(uintptr_t)smem + (w * 32u + ((f + 1u) & 1u) * 16u + i) * 1024u, l * 16u, (w * (kb_of(PH) / 4u) + (f + 1u) * 16u + i) * 1024u);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const unsigned char *slot = smem + (w * 32u + (f & 1u) * 16u) * 1024u;
+            for (u32 p = l; p < 1024u; p += 64u) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(slot + 16u * p);
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // the slot is read before it is refilled
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (u32 p = tid; p < kb_of(PH) * 64u; p += 256u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(smem + 16u * p);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
     }
     if (tid < nout_of(PH)) vout[blockIdx.x * nout_of(PH) + tid] = (uint16_t)(acc | 1u);
     if (acc == 0x12345u) sink[0] = acc;
@@ -84,11 +124,11 @@ struct Ctl {
 };
 
 template <bool GATHER, u32 GP, u32 INFLIGHT>
-__global__ void __launch_bounds__(256) engine_kernel(const unsigned char *weights, u64 wbytes, u32 layers, gu64 *gran /* [4][8192] */, u32 *err,
+__global__ void __launch_bounds__(256) engine_kernel(const unsigned char *weights, u64 wbytes, u32 layers, gu64 *gran /* [4][NGRAN] */, u32 *err,
                                                      u32 *sink) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char *ring = smem;                                      // NSLOT x SLOT
-    u32 *xl = reinterpret_cast<u32 *>(smem + NSLOT * SLOT);          // gathered payloads (<= 7168 words)
+    u32 *xl = reinterpret_cast<u32 *>(smem + NSLOT * SLOT);          // gathered payloads (<= XL_WORDS words)
     __shared__ Ctl ctl_s;
     volatile Ctl *ctl = &ctl_s;
     const u32 tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63u;
@@ -99,7 +139,7 @@ __global__ void __launch_bounds__(256) engine_kernel(const unsigned char *weight
         ctl->fail = 0;
     }
     __syncthreads();
-    const u32 fills_per_phase[NPH] = {2, 0, 1, 7, 4};  // 24 KiB rounded up to 2 slots (32), 16, 112, 56 rounded up to 4 (64)
+    const u32 fills_per_phase[NPH] = {fills_of(0), 0, fills_of(2), fills_of(3), fills_of(4)};  // shares rounded up to whole 16 KiB slots
     if (w == 0) {
         // ------------------------------------------------ loader: runs ahead of the consumers by up to NSLOT fills
         u32 fill = 0;
@@ -136,12 +176,12 @@ __global__ void __launch_bounds__(256) engine_kernel(const unsigned char *weight
     for (u32 layer = 0; layer < layers; layer++)
         for (int ph = 0; ph < NPH; ph++) {
             ++epoch;
-            const bool active = !(ph == 1 && blockIdx.x >= 32u);
+            const bool active = !(ph == 1 && blockIdx.x >= NATT);
             // -------- gather the input vector = the previous phase's output (tag = epoch - 1)
             if (GATHER && epoch > 1u && active) {
                 if (w == 1) {
                     const u32 ng = ph == 1 ? 192u : nin_of(ph) / 2u;
-                    gu64 *g = gran + (size_t)((epoch - 1u) & 3u) * 8192u + (ph == 1 ? (blockIdx.x % 32u) * 64u : 0u);
+                    gu64 *g = gran + (size_t)((epoch - 1u) & 3u) * NGRAN + (ph == 1 ? (blockIdx.x % NATT) * 64u : 0u);
                     u32 spins = 0;
                     for (u32 k0 = 0; k0 < ng; k0 += 64u * GP) {  // GP granules per lane in flight per pass
                         for (;;) {
@@ -209,7 +249,7 @@ __global__ void __launch_bounds__(256) engine_kernel(const unsigned char *weight
             if (w == 1 && active) {
                 const u32 ngo = nout_of(ph) / 2u;
                 if (l < ngo)
-                    __hip_atomic_store(gran + (size_t)(epoch & 3u) * 8192u + blockIdx.x * ngo + l, ((u64)epoch << 32) | (acc | 1u), __ATOMIC_RELAXED,
+                    __hip_atomic_store(gran + (size_t)(epoch & 3u) * NGRAN + blockIdx.x * ngo + l, ((u64)epoch << 32) | (acc | 1u), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -223,15 +263,15 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&weights, wbytes));
     CHECK(hipMemset(weights, 1, wbytes));
     uint16_t *va, *vb;
-    CHECK(hipMalloc(&va, 32768));
-    CHECK(hipMalloc(&vb, 32768));
-    CHECK(hipMemset(va, 0, 32768));
-    CHECK(hipMemset(vb, 0, 32768));
+    CHECK(hipMalloc(&va, 65536));
+    CHECK(hipMalloc(&vb, 65536));
+    CHECK(hipMemset(va, 0, 65536));
+    CHECK(hipMemset(vb, 0, 65536));
     u32 *sink, *err;
     CHECK(hipMalloc(&sink, 64));
     CHECK(hipMalloc(&err, 64));
     gu64 *gran;
-    { void *p; CHECK(hipMalloc(&p, 4 * 8192 * 8)); gran = (gu64 *)p; }
+    { void *p; CHECK(hipMalloc(&p, 4 * NGRAN * 8)); gran = (gu64 *)p; }
     hipStream_t s;
     CHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -239,17 +279,21 @@ int main(int argc, char **argv) {
     CHECK(hipEventCreate(&e1));
 
     // ---- launches: one graph of layers x 5 kernels
+    CHECK(hipFuncSetAttribute((const void *)phase_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)phase_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CHECK(hipFuncSetAttribute((const void *)phase_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CHECK(hipFuncSetAttribute((const void *)phase_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    auto lds_of = [](int ph) { return (size_t)(kb_of(ph) > 128u ? 128u : kb_of(ph)) * 1024u; };
+    printf("CFG %d: %u KiB of weights per CU and layer = %.1f MB per layer\n", CFG, LAYER_KB, LAYER_KB * 1024.0 * 256 / 1e6);
     hipGraph_t g;
     hipGraphExec_t ge;
     CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     for (u32 layer = 0; layer < layers; layer++) {
-        hipLaunchKernelGGL(phase_kernel<0>, dim3(256), dim3(256), 24 * 1024, s, weights, wbytes, layer, va, vb, sink);
+        hipLaunchKernelGGL(phase_kernel<0>, dim3(256), dim3(256), lds_of(0), s, weights, wbytes, layer, va, vb, sink);
         hipLaunchKernelGGL(phase_kernel<1>, dim3(256), dim3(256), 1024, s, weights, wbytes, layer, vb, va, sink);
-        hipLaunchKernelGGL(phase_kernel<2>, dim3(256), dim3(256), 16 * 1024, s, weights, wbytes, layer, va, vb, sink);
-        hipLaunchKernelGGL(phase_kernel<3>, dim3(256), dim3(256), 112 * 1024, s, weights, wbytes, layer, vb, va, sink);
-        hipLaunchKernelGGL(phase_kernel<4>, dim3(256), dim3(256), 56 * 1024, s, weights, wbytes, layer, va, vb, sink);
+        hipLaunchKernelGGL(phase_kernel<2>, dim3(256), dim3(256), lds_of(2), s, weights, wbytes, layer, va, vb, sink);
+        hipLaunchKernelGGL(phase_kernel<3>, dim3(256), dim3(256), lds_of(3), s, weights, wbytes, layer, vb, va, sink);
+        hipLaunchKernelGGL(phase_kernel<4>, dim3(256), dim3(256), lds_of(4), s, weights, wbytes, layer, va, vb, sink);
     }
     CHECK(hipStreamEndCapture(s, &g));
     CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -269,7 +313,7 @@ int main(int argc, char **argv) {
            LAYER_KB * 1024.0 * 256 / (best * 1e3 / layers) / 1e3);
 
     // ---- engine
-    const size_t smem = NSLOT * SLOT + 7168 * 4;
+    const size_t smem = NSLOT * SLOT + XL_WORDS * 4;
     for (int variant = 0; variant < 5; variant++) {
         const int gather = variant != 4;
         // (24 or 32 granules per lane and pass trip a code-generation error of this hipcc: 16 is the widest sweep built)
@@ -281,7 +325,7 @@ int main(int argc, char **argv) {
         best = 1e9f;
         u32 herr = 0;
         for (u32 r = 0; r < iters + 1; r++) {
-            CHECK(hipMemsetAsync((void *)gran, 0, 4 * 8192 * 8, s));  // tags re-initialised every call
+            CHECK(hipMemsetAsync((void *)gran, 0, 4 * NGRAN * 8, s));  // tags re-initialised every call
             CHECK(hipMemsetAsync(err, 0, 4, s));
             CHECK(hipEventRecord(e0, s));
             hipLaunchKernelGGL(kern, dim3(256), dim3(256), smem, s, weights, wbytes, layers, gran, err, sink);
@@ -295,7 +339,7 @@ int main(int argc, char **argv) {
         }
         (void)gather;
         printf("engine skeleton (1 launch, loader + 3 consumers per CU; %s): %7.2f us per layer  (%.0f GB/s of weights)%s\n",
-               vn[variant], best * 1e3f / layers, (2 + 1 + 7 + 4) * 16.0 * 1024 * 256 / (best * 1e3 / layers) / 1e3,
+               vn[variant], best * 1e3f / layers, (fills_of(0) + fills_of(2) + fills_of(3) + fills_of(4)) * 16.0 * 1024 * 256 / (best * 1e3 / layers) / 1e3,
                herr ? "   ** spin limit hit: result invalid **" : "");
         if (herr) printf("   err mask %u\n", herr);
     }

@@ -20,6 +20,7 @@ EXPORTS = [
     "gq_attn_decode_qtip", "gq_qtip_linear_out_seg",
     "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
     "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck", "gq_hop_send", "gq_hop_wait",
+    "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows",
 ]
 _VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer")
 
@@ -32,6 +33,12 @@ class GqQtipIn(ctypes.Structure):  # include/gq_hip.h
 class GqQtipXf(ctypes.Structure):
     _fields_ = [("y32", ctypes.c_void_p), ("vec", ctypes.c_void_p), ("hadK", ctypes.c_void_p), ("resid", ctypes.c_void_p),
                 ("out", ctypes.c_void_p)]
+
+
+class GqQtipMid(ctypes.Structure):
+    _fields_ = [("y32_gate", ctypes.c_void_p), ("y32_up", ctypes.c_void_p), ("SV32_gate", ctypes.c_void_p), ("SV32_up", ctypes.c_void_p),
+                ("hadT_right16", ctypes.c_void_p), ("SU_down", ctypes.c_void_p), ("had_left_down16", ctypes.c_void_p), ("z32", ctypes.c_void_p),
+                ("gate_out", ctypes.c_void_p), ("up_out", ctypes.c_void_p)]
 
 
 class GqQtipOut(ctypes.Structure):
@@ -78,6 +85,8 @@ def lib():
         L.gq_qtip_plan_ksplit.argtypes = [i32, ctypes.POINTER(u32), u32, i32]
         L.gq_qtip_linear.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), ctypes.POINTER(GqQtipOut), i32, vp, vp]
         L.gq_qtip_transform.argtypes = [i32, vp, vp, vp, f32, i32, i32, ctypes.POINTER(GqQtipXf), u32, u32, i32, vp]
+        L.gq_qtip_mlp_mid.argtypes = [ctypes.POINTER(GqQtipMid), u32, u32, u32, vp]
+        L.gq_qtip_linear_in_rows.argtypes = [vp, u32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, vp]
         L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]
         L.gq_set_ap_mode.argtypes = [i32]
         L.gq_embed_lookup.argtypes = [vp, vp, vp, u32, u32, vp]
@@ -97,6 +106,7 @@ def lib():
         L.gq_anyprec_pack.argtypes = [vp, vp, u32, u32, i32, vp]
         L.gq_lnq_cd_block.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, vp]
         L.gq_debug_set_timing_buffer.argtypes = [vp]
+        L.gq_debug_set_qtip_timing_buffer.argtypes = [vp]
         L.gq_hop_send.argtypes = [vp, vp, u32, vp, vp, u32, vp]
         L.gq_hop_wait.argtypes = [vp, vp, u32, vp, u32, vp]
         L.gq_anyprec_qkv_rope_supported.argtypes = [u32, u32, i32, u32]

@@ -52,6 +52,7 @@ typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 unsigned long long *g_qdbg = nullptr;  // optional per-wave phase stamps of the middle block (tools/qtip_phase_timing.py)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------ the band engine
 // Round 2 redesign (round 1: one v_dot2 per state, one 2 KiB codebook with ~3.5-way bank conflicts, 8 VALU per state).
@@ -511,6 +512,7 @@ struct QtipInArgs {
     const uint16_t *x, *x2, *normw;
     float eps, kscale;  // kscale = (float)K^-1/2, rounded from double like the scale argument of hadamard()
     u32 K, n;
+    u32 P;       // QPRO_ROWS: length of the row transforms (K = Kf * P)
     u32 ksplit;  // 1..4 K ranges per band; range ks of a band writes its sums to y32 + ks * M
     QtipIn lin[3];
     u32 nprev;          // 1 / 2: x (and x2) are the outputs of the linears prev[] whose transform-out is done here (M == K)
@@ -521,7 +523,7 @@ struct QtipInArgs {
     u32 *fin_ctr;  // [n] zero before the first launch; the finishing block resets its counter
     unsigned long long *dbg;
 };
-enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2, QPRO_PRE = 3 };
+enum { QPRO_NONE = 0, QPRO_RMSNORM = 1, QPRO_SILUMUL = 2, QPRO_PRE = 3, QPRO_ROWS = 4 };
 
 // y32 of a producing linear: its split-K parts added in ascending order (what gq_qtip_linear_out reads)
 __device__ __forceinline__ float qtip_sum_parts(const float *y32, u32 M, u32 parts, u32 i) {
@@ -635,9 +637,22 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     QtipTabRegs tr;
     qtip_table_request(tr, L.tlut);
     constexpr u32 NU = 2;  // 8-element units per thread held in registers (K <= 16 T)
-    const bool inreg = !a.nprev && K <= 8u * NU * T && PRO != QPRO_PRE && !(((uintptr_t)xg | (uintptr_t)x2g | (uintptr_t)a.normw | (uintptr_t)L.SU) & 15u);
+    const bool inreg = !a.nprev && K <= 8u * NU * T && PRO != QPRO_PRE && PRO != QPRO_ROWS &&
+                       !(((uintptr_t)xg | (uintptr_t)x2g | (uintptr_t)a.normw | (uintptr_t)L.SU) & 15u);
     uint4 xq[NU], x2q[NU], nwq[NU];
     float4 su0[NU], su1[NU];
+    // QPRO_ROWS: x is the fp32 vector gq_qtip_mlp_mid left -- the Kf x Kf factor product of the transform-in is done (column by
+    // column, so it commutes with the row transforms); what is left is cheap enough to repeat in every block: the P-point
+    // Sylvester transform of every row, * K^-1/2 / 32, fp16.  Requested with the other inputs (<= 4 x 16 bytes per thread).
+    constexpr u32 NZ = 4;
+    float4 zq[NZ];
+    if constexpr (PRO == QPRO_ROWS) {
+#pragma unroll
+        for (u32 k = 0; k < NZ; k++) {
+            const u32 u = tid + k * T;
+            zq[k] = u < K / 4u ? reinterpret_cast<const float4 *>(xg)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     if (inreg) {
 #pragma unroll
         for (u32 k = 0; k < NU; k++) {
@@ -707,7 +722,14 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
             }
             return (float)xh * su;
         };
-        if (inreg) {
+        if constexpr (PRO == QPRO_ROWS) {
+#pragma unroll
+            for (u32 k = 0; k < NZ; k++) {
+                const u32 u = tid + k * T;
+                if (u < K / 4u) reinterpret_cast<float4 *>(v)[u] = zq[k];
+            }
+            for (u32 u = tid + NZ * T; u < K / 4u; u += T) reinterpret_cast<float4 *>(v)[u] = reinterpret_cast<const float4 *>(xg)[u];
+        } else if (inreg) {
 #pragma unroll
             for (u32 k = 0; k < NU; k++) {
                 const u32 u = tid + k * T;
@@ -734,7 +756,7 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         __syncthreads();
         pstamp();
 #if !(QT_ABL & 32)
-        fwht_lds(v, K);
+        fwht_lds(v, K, PRO == QPRO_ROWS ? a.P : K);
 #endif
         pstamp();
         // fp32 -> fp16, IN PLACE (xs is the front half of v): every thread takes its (<= NU) units of 8 values into
@@ -982,6 +1004,218 @@ __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ middle of a gated MLP with a factor width
+// gate / up leave their sums y32 [n]; down wants half(H(silu(g) * u * SU) * n^-1/2 / 32) with g, u = half(H(y32) * n^-1/2 * SV32),
+// n = Kf * P (Llama-2: 11008 = 172 * 64).  As two gq_qtip_transform launches (out, then in) that is 2 x 6.9 us of a 78 us layer.
+// H = hadK (x) H_P acts on the [Kf][P] view as  hadK @ X @ H_P: the two sides commute.  So
+//     out:  rows first, then the factor product      (the order of gq_qtip_transform: g and u come out bit-identical to it)
+//     in :  the factor product first, then the rows  (the other order: equal up to fp32 rounding)
+// and everything between the two row passes -- out product, scales, fp16 roundings, silu * up, SU, in product -- is local to a
+// COLUMN of the view.  Block j owns column j: it computes that column of the row transforms itself (a 64-term sum in butterfly
+// order per row), both factor products and the element-wise middle, and stores column j of the fp32 vector whose row transforms the
+// matvec launch of down runs in its prologue (QPRO_ROWS: one in-register pass per block).  One launch of P blocks instead of two
+// launches of Kf / 4 blocks that each stage the whole vector.
+// Every block needs both Kf x Kf tables: they come as fp16 (+-1 is exact; 2 x 59 KB per block instead of 2 x 118 KB -- the first
+// version with fp32 tables and one row per thread spent 16 us, most of it in 96 four-byte loads per thread) in [k][r] order, wave w
+// owns the k group w (the 16 groups of qtip_transform_kernel) and lane L the rows 4 L .. 4 L + 3: 8-byte loads, coalesced, requested
+// before anything else -- they do not depend on the previous launch and arrive while its sums are still on their way --, kept in
+// registers and multiplied by v_fma_mix_f32 (fp16 x fp32 + fp32: with +-1 entries the product is exact, so the fused form
+// rounds like the multiply-add of qtip_transform_kernel).
+struct QtipMidArgs {
+    const float *y32g, *y32u, *sv32g, *sv32u, *su_down;
+    const uint16_t *hadT_out, *had_in;  // fp16 [Kf][Kf]
+    float *z32;
+    uint16_t *gout, *uout;  // optional fp16 copies of gate / up (null: not stored)
+    u32 parts, n, Kf, kper;
+    float nscale;
+    unsigned long long *dbg;  // phase stamps of block 32 (tools/qtip_mid_timing.py)
+};
+constexpr u32 MID_R = 256u, MID_T = 1024u, MID_KP = 12u;  // Kf <= 192 (3 rounds of 64 rows in stage 1), kper = ceil(Kf / 16) <= 12
+__global__ void __launch_bounds__(MID_T) qtip_mlp_mid_kernel(QtipMidArgs a) {
+    // dynamic LDS: both tables (fp16 [Kf][Kf], flat copies), then xr [256][gate, up] (column j of the row transforms), ps [16][gate,
+    // up][256] (partial sums of the out product; the in product's [16][256] re-use it), vin [256]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tbytes = a.Kf * a.Kf * 2u;  // (a multiple of 16: Kf % 4 == 0)
+    const unsigned char *tabO = smem, *tabI = smem + tbytes;
+    float *xr = reinterpret_cast<float *>(smem + 2u * tbytes);
+    float *ps = xr + MID_R * 2u, *ps2 = ps;
+    float *vin = ps + 16u * 2u * MID_R;
+    constexpr u32 P = 64u;
+    const u32 tid = threadIdx.x, j = blockIdx.x, Kf = a.Kf, kper = a.kper;
+    const u32 w = __builtin_amdgcn_readfirstlane(tid >> 6), r0 = 4u * (tid & 63u);
+    u32 nst = 0;
+    auto stamp = [&]() {
+        if (a.dbg && blockIdx.x == 32u && (tid & 63u) == 0u && nst < 8u) a.dbg[w * 8u + nst++] = __builtin_readcyclecounter();
+    };
+    stamp();
+    // ---- requests.  First what stage 1 needs (the sums of the previous launch: the long latency), then the constants.
+    // A row of the view is 256 bytes: 16 lanes x 16 bytes, so a wave instruction reads 4 whole rows (one row per thread -- 128
+    // bytes at a 256-byte stride -- touched 64 cache lines per instruction: 11 us for the launch).  Rounds 0..2: gate rows
+    // (tid / 16) + 64 i, rounds 3..5: up (the source of a round is uniform).
+    const u32 c16 = tid & 15u, rq = tid >> 4;
+    u32x4 xq[6];
+    {
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y32g), (short)0, (int)(a.parts * a.n * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y32u), (short)0, (int)(a.parts * a.n * 4u), 0x00020000);
+#pragma unroll
+        for (u32 i = 0; i < 3; i++) {
+            const u32 row = rq + 64u * i;
+            const u32 off = row < Kf ? (row * P + 4u * c16) * 4u : 0x80000000u;  // (rows beyond Kf: out of range -> zeros)
+            xq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 0));
+            xq[3 + i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, (int)off, 0, 0));
+        }
+    }
+    // the tables: flat 16-byte units, 4 per thread and table (a wave instruction moves 1 KiB: 8 instead of 32 requests per wave)
+    u32x4 tq[8];
+    {
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.hadT_out), (short)0, (int)tbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.had_in), (short)0, (int)tbytes, 0x00020000);
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            tq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (int)((tid + MID_T * i) * 16u), 0, 0));
+            tq[4 + i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)((tid + MID_T * i) * 16u), 0, 0));
+        }
+    }
+    float svg = 0.f, svu = 0.f, sud = 0.f;
+    if (tid < Kf) svg = a.sv32g[tid * P + j], svu = a.sv32u[tid * P + j], sud = a.su_down[tid * P + j];
+    auto h4 = [](uint2 hw, u32 i) -> float { return (float)__builtin_bit_cast(h16, (uint16_t)((i >> 1 ? hw.y : hw.x) >> (16u * (i & 1u)))); };
+    // ---- 1. column j of the row transforms: out_j = the butterfly tree of fwht_lds for output index j -- at the stage of bit m
+    // the pair (lo, hi) becomes lo + hi (bit m of j clear) or lo - hi = lo + (-hi) (set): the same additions, bit for bit.
+    // Bits 0, 1 inside the lane's 4 elements, bits 2..5 across the 16 lanes of the row (DPP butterflies: every lane ends with the sum)
+    {
+        auto flip = [](float v, u32 sm) { return __builtin_bit_cast(float, __builtin_bit_cast(u32, v) ^ sm); };
+        const u32 s0 = (j & 1u) << 31, s1 = ((j >> 1) & 1u) << 31;
+#pragma unroll
+        for (u32 i = 0; i < 6; i++) {
+            float e[4];
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {  // (through a scalar: this hipcc folds __builtin_bit_cast(float, vector[c]) to element 0)
+                const u32 t = xq[i][c];
+                e[c] = __builtin_bit_cast(float, t);
+            }
+            if (a.parts > 1u) {  // split-K parts, ascending (qtip_sum_parts)
+                const float *src = (i < 3u ? a.y32g : a.y32u);
+                const u32 row = rq + 64u * (i % 3u);
+                for (u32 p = 1; p < a.parts; p++)
+                    if (row < Kf) {
+                        const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)p * a.n + row * P + 4u * c16);
+                        e[0] += t.x, e[1] += t.y, e[2] += t.z, e[3] += t.w;
+                    }
+            }
+            float t = (e[0] + flip(e[1], s0)) + flip(e[2] + flip(e[3], s0), s1);
+#pragma unroll
+            for (u32 m = 2; m < 6; m++) {
+                int o = __builtin_bit_cast(int, t);
+                if (m == 2u) o = __builtin_amdgcn_update_dpp(0, o, 0xB1, 0xF, 0xF, false);       // lane ^ 1
+                else if (m == 3u) o = __builtin_amdgcn_update_dpp(0, o, 0x4E, 0xF, 0xF, false);  // lane ^ 2
+                else if (m == 4u) {                                                              // lane ^ 4 = (^ 3) then (^ 7)
+                    o = __builtin_amdgcn_update_dpp(0, o, 0x1B, 0xF, 0xF, false);
+                    o = __builtin_amdgcn_update_dpp(0, o, 0x141, 0xF, 0xF, false);
+                } else {                                                                         // lane ^ 8 = (^ 15) then (^ 7)
+                    o = __builtin_amdgcn_update_dpp(0, o, 0x140, 0xF, 0xF, false);
+                    o = __builtin_amdgcn_update_dpp(0, o, 0x141, 0xF, 0xF, false);
+                }
+                const float of = __builtin_bit_cast(float, o);
+                const bool upper = (c16 >> (m - 2u)) & 1u;
+                const float lo = upper ? of : t, hi = upper ? t : of;
+                t = lo + flip(hi, ((j >> m) & 1u) << 31);
+            }
+            const u32 row = rq + 64u * (i % 3u);
+            if (c16 == 0u && row < MID_R) xr[row * 2u + (i < 3u ? 0u : 1u)] = t;  // (rows beyond Kf: zeros)
+        }
+    }
+    stamp();
+#pragma unroll
+    for (u32 i = 0; i < 4; i++) {
+        const u32 u = tid + MID_T * i;
+        if (u * 16u < tbytes) {
+            *reinterpret_cast<u32x4 *>(smem + u * 16u) = tq[i];
+            *reinterpret_cast<u32x4 *>(smem + tbytes + u * 16u) = tq[4 + i];
+        }
+    }
+    __syncthreads();
+    stamp();
+    // ---- 2. out product, in the order of qtip_transform_kernel at P = 64: 16 k groups of kper terms, each summed from 0.f.
+    // Branch-free: every LDS read of the group is issued before the first multiply (with a branch per k the compiler waits for each
+    // read where it is used: 4,200 cycles for 11 terms); a term outside the group gets the factor 0 at a clamped address -- acc + 0 * x
+    {
+        float2 xk[MID_KP];
+        uint2 hk[MID_KP];
+#pragma unroll
+        for (u32 kk = 0; kk < MID_KP; kk++) {
+            const u32 k = w * kper + kk;
+            const bool ok = kk < kper && k < Kf;
+            const u32 kc = ok ? k : 0u;
+            xk[kk] = *reinterpret_cast<const float2 *>(xr + 2u * kc);
+            const uint2 hw = *reinterpret_cast<const uint2 *>(tabO + (kc * Kf + r0) * 2u);  // (lanes beyond Kf: inside the allocation, unused)
+            hk[kk] = (ok && r0 < Kf) ? hw : make_uint2(0u, 0u);
+        }
+        float ag[4] = {0.f, 0.f, 0.f, 0.f}, au[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (u32 kk = 0; kk < MID_KP; kk++)
+#pragma unroll
+            for (u32 i = 0; i < 4; i++) {
+                const float h = h4(hk[kk], i);
+                ag[i] = __builtin_fmaf(h, xk[kk].x, ag[i]);
+                au[i] = __builtin_fmaf(h, xk[kk].y, au[i]);
+            }
+        *reinterpret_cast<float4 *>(ps + (w * 2u + 0u) * MID_R + r0) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+        *reinterpret_cast<float4 *>(ps + (w * 2u + 1u) * MID_R + r0) = make_float4(au[0], au[1], au[2], au[3]);
+    }
+    __syncthreads();
+    stamp();
+    // ---- 3. the element-wise middle for row r = tid of column j (bitshift.py:470, model.py:266, bitshift.py:441)
+    if (tid < MID_R) {
+        float pg[16], pu[16];
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) pg[q] = ps[(q * 2u + 0u) * MID_R + tid], pu[q] = ps[(q * 2u + 1u) * MID_R + tid];
+        float yg = 0.f, yu = 0.f;
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) yg += pg[q], yu += pu[q];
+        yg *= a.nscale;
+        yu *= a.nscale;
+        const h16 g16 = (h16)gq_pin_f32(yg * svg), u16 = (h16)gq_pin_f32(yu * svu);
+        if (tid < Kf) {
+            if (a.gout) a.gout[tid * P + j] = __builtin_bit_cast(uint16_t, g16);
+            if (a.uout) a.uout[tid * P + j] = __builtin_bit_cast(uint16_t, u16);
+        }
+        const float gf = (float)g16;
+        const h16 hh = (h16)(gf / (1.0f + __expf(-gf))) * u16;
+        vin[tid] = tid < Kf ? (float)hh * sud : 0.f;
+    }
+    __syncthreads();
+    stamp();
+    // ---- 4. in product (hadK^T @, matmul_hadUt): z[r] = sum_k had[k][r] * vin[k], the 16 k groups added in ascending order
+    {
+        float xk[MID_KP];
+        uint2 hk[MID_KP];
+#pragma unroll
+        for (u32 kk = 0; kk < MID_KP; kk++) {
+            const u32 k = w * kper + kk;
+            const bool ok = kk < kper && k < Kf;
+            const u32 kc = ok ? k : 0u;
+            xk[kk] = vin[kc];
+            const uint2 hw = *reinterpret_cast<const uint2 *>(tabI + (kc * Kf + r0) * 2u);
+            hk[kk] = (ok && r0 < Kf) ? hw : make_uint2(0u, 0u);
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (u32 kk = 0; kk < MID_KP; kk++)
+#pragma unroll
+            for (u32 i = 0; i < 4; i++) acc[i] = __builtin_fmaf(h4(hk[kk], i), xk[kk], acc[i]);
+        *reinterpret_cast<float4 *>(ps2 + w * MID_R + r0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    stamp();
+    if (tid < Kf) {
+        float z = 0.f;
+#pragma unroll
+        for (u32 g = 0; g < 16; g++) z += ps2[g * MID_R + tid];
+        a.z32[tid * P + j] = z;
+    }
+    stamp();
+}
+
 // ------------------------------------------------------------------------------------------------ Hadamard (FWHT)
 __global__ void __launch_bounds__(1024) fwht_kernel(const float *x, float *y, u32 n, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1107,7 +1341,8 @@ extern "C" int gq_qtip_plan_ksplit(int n, const uint32_t *M, uint32_t K, int max
 
 namespace {
 int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, float eps, int prologue, uint32_t K, int R, int n,
-                        const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, const GqQtipOut *fin, void *counters, void *stream) {
+                        const GqQtipIn *lin, int n_prev, const GqQtipOut *prev, int ksplit, const GqQtipOut *fin, void *counters, void *stream,
+                        uint32_t rows_P = 0) {
     if (ksplit < 1 || ksplit > 4) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: ksplit must be 1..4.");
     if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 1..3 linears.");
     if (n_prev < 0 || n_prev > 2 || (n_prev && !prev)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 0..2 producing linears.");
@@ -1117,9 +1352,11 @@ int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, 
     if (R < 2 || R > 4) return gq_fail(GQ_ENOTSUP, "R (bits per weight) must be 2, 3 or 4 (kernel_check.py:1-14).");
     if (prologue == GQ_QPRO_PRETRANSFORMED) {
         if (K == 0 || K % 32u || K > 32768u || n_prev) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: pre-transformed input: K a multiple of 32, no folding.");
+    } else if (prologue == 4) {  // QPRO_ROWS (gq_qtip_linear_in_rows: checked there)
+        if (!rows_P || n_prev || fin) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: prologue 4 is reached through gq_qtip_linear_in_rows.");
     } else if (!pow2(K) || K < 32u || K > 16384u)
         return gq_fail(GQ_ENOTSUP, "fused QTIP linear: K must be a power of two in 32..16384.");
-    if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2 && !n_prev) || prologue < 0 || prologue > 3)
+    if ((prologue == GQ_QPRO_RMSNORM && !norm_weight) || (prologue == GQ_QPRO_SILU_MUL && !x2 && !n_prev) || prologue < 0 || prologue > 4)
         return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: prologue operand missing.");
     const u32 nK2 = K / 32u;
     if ((u32)ksplit > nK2) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: more K ranges than tile blocks.");
@@ -1131,9 +1368,10 @@ int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, 
     a.kscale = (float)pow((double)K, -0.5);
     a.K = K;
     a.n = (u32)n;
+    a.P = rows_P;
     u32 bands[3] = {0, 0, 0}, nblk[3] = {0, 0, 0};
     for (int i = 0; i < n; i++) {
-        if (!lin[i].trellis || (!lin[i].SU && prologue != GQ_QPRO_PRETRANSFORMED) || !lin[i].tlut || !lin[i].y32 || lin[i].M == 0 || lin[i].M % 32u)
+        if (!lin[i].trellis || (!lin[i].SU && prologue != GQ_QPRO_PRETRANSFORMED && prologue != 4) || !lin[i].tlut || !lin[i].y32 || lin[i].M == 0 || lin[i].M % 32u)
             return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: null pointer or M not a multiple of 32.");
         if (((uintptr_t)lin[i].trellis | (uintptr_t)lin[i].tlut) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
         bands[i] = lin[i].M / 32u;
@@ -1214,6 +1452,7 @@ int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, 
         if (prologue == GQ_QPRO_RMSNORM) GQ_LAUNCH_QIN_S(RR, QPRO_RMSNORM);     \
         else if (prologue == GQ_QPRO_SILU_MUL) GQ_LAUNCH_QIN_S(RR, QPRO_SILUMUL); \
         else if (prologue == GQ_QPRO_PRETRANSFORMED) GQ_LAUNCH_QIN_S(RR, QPRO_PRE); \
+        else if (prologue == 4) GQ_LAUNCH_QIN_S(RR, QPRO_ROWS);                   \
         else GQ_LAUNCH_QIN_S(RR, QPRO_NONE);                                    \
     } while (0)
     if (R == 2) GQ_LAUNCH_QIN_R(2);
@@ -1237,6 +1476,38 @@ extern "C" int gq_qtip_linear(const void *x, const void *x2, const void *norm_we
                               const GqQtipIn *lin, const GqQtipOut *finish, int ksplit, void *counters, void *stream) {
     if (!finish) return gq_fail(GQ_EINVAL, "gq_qtip_linear: finish descriptors missing.");
     return qtip_linear_in_impl(x, x2, norm_weight, eps, prologue, K, R, n, lin, 0, nullptr, ksplit, finish, counters, stream);
+}
+
+extern "C" int gq_qtip_mlp_mid(const GqQtipMid *m, uint32_t parts, uint32_t n, uint32_t Kf, void *stream) {
+    if (!m || !m->y32_gate || !m->y32_up || !m->SV32_gate || !m->SV32_up || !m->hadT_right16 || !m->SU_down || !m->had_left_down16 || !m->z32)
+        return gq_fail(GQ_EINVAL, "gq_qtip_mlp_mid: null pointer argument.");
+    if (Kf < 2u || n == 0 || n % Kf) return gq_fail(GQ_EINVAL, "gq_qtip_mlp_mid: n a multiple of Kf.");
+    if (n / Kf != 64u || Kf > 176u || Kf % 4u)  // (both fp16 tables in LDS: 4 Kf^2 + 35 KiB <= 160 KiB)
+        return gq_fail(GQ_ENOTSUP, "gq_qtip_mlp_mid: serves n = Kf * 64 with Kf <= 176, Kf % 4 == 0 (other widths: two gq_qtip_transform launches).");
+    if (parts < 1u || parts > 4u) return gq_fail(GQ_EINVAL, "gq_qtip_mlp_mid: parts must be 1..4.");
+    if (((uintptr_t)m->y32_gate | (uintptr_t)m->y32_up) & 15u) return gq_fail(GQ_EINVAL, "gq_qtip_mlp_mid: the sums must be 16-byte aligned.");
+    if (((uintptr_t)m->hadT_right16 | (uintptr_t)m->had_left_down16) & 7u) return gq_fail(GQ_EINVAL, "gq_qtip_mlp_mid: the tables must be 8-byte aligned.");
+    QtipMidArgs a{};
+    a.y32g = m->y32_gate, a.y32u = m->y32_up, a.sv32g = m->SV32_gate, a.sv32u = m->SV32_up;
+    a.hadT_out = (const uint16_t *)m->hadT_right16, a.had_in = (const uint16_t *)m->had_left_down16;
+    a.su_down = m->SU_down, a.z32 = m->z32;
+    a.gout = (uint16_t *)m->gate_out, a.uout = (uint16_t *)m->up_out;
+    a.parts = parts, a.n = n, a.Kf = Kf;
+    a.kper = (Kf + 15u) / 16u;  // (qtip_transform_kernel: KQ = 1024 / 64 = 16 k groups)
+    a.nscale = (float)pow((double)n, -0.5);
+    a.dbg = g_qdbg;
+    const size_t smem = 2u * (size_t)Kf * Kf * 2u + (MID_R * 2u + 16u * 2u * MID_R + MID_R) * 4u;
+    static GqPerDeviceOnce once;
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(qtip_mlp_mid_kernel), 160 * 1024));
+    hipLaunchKernelGGL(qtip_mlp_mid_kernel, dim3(64u), dim3(MID_T), smem, (hipStream_t)stream, a);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_qtip_linear_in_rows(const float *z32, uint32_t K, uint32_t P, int R, int n, const GqQtipIn *lin, int ksplit, void *stream) {
+    if (!z32 || ((uintptr_t)z32 & 15u)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in_rows: z32 null or not 16-byte aligned.");
+    if (P < 2u || !pow2(P) || K == 0 || K % P || K % 32u || K > 16384u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in_rows: K = Kf * P <= 16384, P a power of two, K % 32 == 0.");
+    return qtip_linear_in_impl(z32, nullptr, nullptr, 0.f, 4, K, R, n, lin, 0, nullptr, ksplit, nullptr, nullptr, stream, P);
 }
 
 extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {

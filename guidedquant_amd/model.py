@@ -19,6 +19,7 @@ Two execution paths:
 Model table: the reference's entries (model.py:53-61) plus Llama-3.2-1B-Instruct and Llama-3.3-70B-Instruct, which
 BASELINE.json's configs name and the reference table lacks.
 """
+import ctypes
 import math
 import os
 from dataclasses import dataclass
@@ -462,7 +463,7 @@ class Transformer(nn.Module):
         st["u"] = torch.zeros(c.intermediate_size, dtype=torch.float16, device=dev)
         mmax = max(c.dim, c.intermediate_size)
         # [linear][split-K part][M]; rows 3 / 4: the sums of wo / down while their transform-out is folded into the next launch
-        st["y32"] = torch.zeros(5, 2 * mmax, dtype=torch.float32, device=dev)
+        st["y32"] = torch.zeros(5, 4 * mmax, dtype=torch.float32, device=dev)
         st["xs16"] = torch.zeros(3, mmax, dtype=torch.float16, device=dev)     # transformed inputs (factor widths)
         keep = []    # fp32 copies and descriptor arrays the plans point into
         tables = {}  # one fp32 device copy per distinct Hadamard factor table (every layer's module holds its own buffer)
@@ -478,22 +479,43 @@ class Transformer(nn.Module):
                 tables[key] = f32(t)
             return tables[key]
 
+        def table16(t):  # (gq_qtip_mlp_mid reads its factor tables as fp16: +-1 entries, checked by pm1)
+            t16 = t.detach().to(dev).half().contiguous()
+            key = ("h", tuple(t16.shape), hash(t16.cpu().numpy().tobytes()))
+            if key not in tables:
+                keep.append(t16)
+                tables[key] = t16.data_ptr()
+            return tables[key]
+
+        def pm1(t):
+            return bool((t.detach().float().abs() == 1.0).all())
+
         def ksplit(m):  # K ranges per band: the split with the fewest band-equivalents per block (wo, down: 128 bands on 256 units -> 2)
             if os.environ.get("GQ_QTIP_KSPLIT", "1") == "0":
                 return 1
-            import ctypes
             return int(_lib.lib().gq_qtip_plan_ksplit(1, (ctypes.c_uint32 * 1)(m.out_features), m.in_features, 2))
+
+        def ksplit_group(mods):  # the same for linears that share a launch (q / k / v: 384 bands on 256 units -> 2 K ranges, 3 rounds of half a band)
+            if os.environ.get("GQ_QTIP_KSPLIT", "1") == "0" or os.environ.get("GQ_QTIP_KSPLIT_GROUP", "1") == "0":
+                return 1
+            return int(_lib.lib().gq_qtip_plan_ksplit(len(mods), (ctypes.c_uint32 * len(mods))(*[m.out_features for m in mods]), mods[0].in_features, 4))
 
         y32, xs16 = st["y32"], st["xs16"]
 
-        def group(mods, xp, x2p, normw, pro, outs, resid, prev=None, defer=None, out_to=None):
+        def group(mods, xp, x2p, normw, pro, outs, resid, prev=None, defer=None, out_to=None, parts_ok=False):
             """launches of one group: mods share the input vector xp (x2p for silu*mul); outs[i] fp16 destinations.
             prev: GqQtipOut of the linear that PRODUCES xp, its transform-out folded into this group's first launch (which then
             stores xp itself); defer = row of y32: this group's own transform-out is left to the consumer (-> returned descriptor)"""
             R, K = mods[0].K, mods[0].in_features
             plan = []
-            # split-K partial sums are added by the fused transform-out only: single linears with a power-of-two output width
-            ks = ksplit(mods[0]) if len(mods) == 1 and mods[0].K_right == 1 else 1
+            # split-K partial sums are added by the consumer of the sums: the fused transform-out (single linears with a power-of-two
+            # output width), the attention launch with the q / k / v transform-out folded in (out_to), gq_qtip_mlp_mid (parts_ok)
+            if len(mods) == 1:
+                ks = ksplit(mods[0]) if mods[0].K_right == 1 else 1
+            elif mods[0].K_left == 1 and ((out_to is not None and all(m.K_right == 1 for m in mods)) or parts_ok):
+                ks = ksplit_group(mods)
+            else:
+                ks = 1
             ysl = [y32[defer]] if defer is not None else [y32[i] for i in range(len(mods))]
             if mods[0].K_left == 1:  # fused transform-in + matvec, all linears in one launch
                 arr = (_lib.GqQtipIn * len(mods))(*[_lib.GqQtipIn(m.trellis.data_ptr(), f32(m.SU), m.tlut.data_ptr(), ysl[i].data_ptr(), m.out_features)
@@ -570,6 +592,7 @@ class Transformer(nn.Module):
         # launch they save.
         one_launch = os.environ.get("GQ_QTIP_ONE_LAUNCH", "0") != "0"
         out_seg = os.environ.get("GQ_QTIP_OUT_SEG", "1") != "0"
+        mlp_mid = os.environ.get("GQ_QTIP_MLP_MID", "1") != "0"
         # GQ_QTIP_ATTN_FOLD (default ON): the transform-out of q / k / v runs inside the attention launch -- every head block needs
         # head_dim of the outputs: the segments combined with the signs of its row, then one head_dim-point transform (equal to
         # gq_qtip_linear_out up to fp32 rounding) --: one launch (4.8 us) per layer less.  Needs power-of-two q / k / v widths.
@@ -583,6 +606,16 @@ class Transformer(nn.Module):
             at, ff = b.attention, b.feed_forward
             qkv_outs = [qkv.data_ptr(), qkv.data_ptr() + c.dim * e, qkv.data_ptr() + (c.dim + kv) * e]
             can_o = fold and at.wo.K_right == 1 and ff.w1.K_left == 1
+            # GQ_QTIP_MLP_MID (default ON): a factor MLP width n = Kf * 64 (Llama-2-7b: 172 * 64) -- the two gq_qtip_transform launches
+            # between the matvecs of gate / up and down (output side, then input side with silu * up) become ONE launch that works
+            # column by column (gq_qtip_mlp_mid), the 64-point row transforms of the input side move into the prologue of down's
+            # matvec launch (gq_qtip_linear_in_rows).  gate / up bit-identical, the input of down equal up to fp32 rounding.
+            w1, w3, w2 = ff.w1, ff.w3, ff.w2
+            n_mlp, Kf = w2.in_features, w2.K_left
+            mid_ok = (mlp_mid and not can_o and not one_launch and Kf != 1 and w1.K_right == Kf and w3.K_right == Kf and n_mlp == Kf * 64
+                      and Kf <= 176 and Kf % 4 == 0 and w1.K_left == 1 and w3.K_left == 1 and w2.K_right == 1
+                      and w1.out_features == n_mlp and w3.out_features == n_mlp
+                      and torch.equal(w1.had_right, w3.had_right) and pm1(w1.had_right) and pm1(w2.had_left))
             can_d = fold and ff.w2.K_right == 1 and at.wq.K_left == 1
         
             fold_here = attn_fold and all(m.K_right == 1 for m in (at.wq, at.wk, at.wv))
@@ -600,11 +633,24 @@ class Transformer(nn.Module):
             else:
                 d["o"] = group([at.wo], y.data_ptr(), None, None, 0, [h.data_ptr()], x.data_ptr())
                 d["gu"] = group([ff.w1, ff.w3], h.data_ptr(), None, b.post_attention_layernorm.weight.data_ptr(), 1,
-                                [st["g"].data_ptr(), st["u"].data_ptr()], None)
+                                [st["g"].data_ptr(), st["u"].data_ptr()], None, parts_ok=mid_ok)
             if can_d:
                 d["d"], prev_down, d["d_out"] = group([ff.w2], st["g"].data_ptr(), st["u"].data_ptr(), None, 2, [x.data_ptr()], h.data_ptr(), defer=4)
             else:
                 d["d"], prev_down, d["d_out"] = group([ff.w2], st["g"].data_ptr(), st["u"].data_ptr(), None, 2, [x.data_ptr()], h.data_ptr()), None, None
+            if mid_ok:
+                assert (d["gu"][-1][0] == "gq_qtip_transform" and d["d"][0][0] == "gq_qtip_transform"
+                        and d["d"][1][0] == "gq_qtip_linear_in" and d["d"][1][1][4] == 3), "unexpected launch plan of a factor-width MLP"
+                ks_gu = d["gu"][0][1][11]  # (split-K parts of the gate / up sums)
+                if "z32" not in st:
+                    st["z32"] = torch.zeros(mmax, dtype=torch.float32, device=dev)
+                mid = _lib.GqQtipMid(y32[0].data_ptr(), y32[1].data_ptr(), f32(w1.SV, 32.0), f32(w3.SV, 32.0),
+                                     table16(w1.had_right.t()), f32(w2.SU), table16(w2.had_left), st["z32"].data_ptr(), None, None)
+                keep.append(mid)
+                a_in = d["d"][1][1]  # (xs16, None, None, 0.0, 3, K, R, 1, arr, 0, None, ks)
+                d["gu"] = d["gu"][:-1]
+                d["d"] = [("gq_qtip_mlp_mid", (ctypes.pointer(mid), ks_gu, n_mlp, Kf)),
+                          ("gq_qtip_linear_in_rows", (st["z32"].data_ptr(), n_mlp, 64, a_in[6], 1, a_in[8], a_in[11]))] + d["d"][2:]
             layers.append(d)
         st["qtip_layers"] = layers
         st["qtip_keep"] = keep

@@ -264,6 +264,39 @@ int gq_qtip_transform(int input_side, const void *x, const void *x2, const void 
                       int n_lin, const GqQtipXf *lin, uint32_t n, uint32_t Kf, int transpose, void *stream);
 
 /*
+ * The middle of a gated MLP whose width n = Kf * 64 carries a Hadamard factor (Llama-2-7b: 11008 = 172 * 64), in ONE launch:
+ * transform-out of gate and up (bitshift.py:466-470), silu(gate) * up (model.py:266), * SU of down and the FACTOR side of
+ * down's transform-in (bitshift.py:441, matmul_had.py:69-94) -- what two gq_qtip_transform launches (output side for gate / up,
+ * then input side with GQ_QPRO_SILU_MUL) do, except that the 64-point row transforms of the input side are left to the
+ * consumer: z32 [n] (fp32) goes to gq_qtip_linear_in_rows, which runs them in its prologue.  hadK (x) H_64 acts on the two sides
+ * of the [Kf][64] view, so the order of the sides is free: gate / up are computed in gq_qtip_transform's order (bit-identical
+ * fp16 values; stored to gate_out / up_out when non-NULL), the input side in the other order (equal to the two-launch chain
+ * up to fp32 rounding).
+ *   hadT_right16    fp16 [Kf][Kf]: the right-side table of gate / up TRANSPOSED (hadT[k][r] = had_right[r][k]; both projections
+ *                   have width n, hence the same table -- matmul_had.py get_hadK(n))
+ *   had_left_down16 fp16 [Kf][Kf]: the left-side table of down as stored (the input side multiplies with its transpose)
+ * The tables are passed in fp16 (every block reads both of them): their entries must be fp16 values -- a Hadamard factor's +-1 are,
+ * and with +-1 entries every product is exact and the results are those of the fp32 tables; the caller checks its table.
+ * parts: split-K parts of y32_gate / y32_up ([parts][n], added in ascending order).  Kf <= 176, Kf % 4 == 0.
+ */
+typedef struct GqQtipMid {
+    const float *y32_gate, *y32_up;
+    const float *SV32_gate, *SV32_up; /* SV * 32, f32 [n] */
+    const void *hadT_right16;
+    const float *SU_down;             /* f32 [n] */
+    const void *had_left_down16;
+    float *z32;                       /* out: f32 [n] */
+    void *gate_out, *up_out;          /* fp16 [n] or NULL */
+} GqQtipMid;
+int gq_qtip_mlp_mid(const GqQtipMid *m, uint32_t parts, uint32_t n, uint32_t Kf, void *stream);
+/*
+ * gq_qtip_linear_in for an input whose transform-in lacks only the row transforms: x = z32 (f32 [K], K = Kf * P, from
+ * gq_qtip_mlp_mid) -> P-point Sylvester transform of every row -> * K^-1/2 / 32 -> fp16 -> trellis matvec into lin[i].y32
+ * (lin[i].SU is ignored).  Other arguments as gq_qtip_linear_in.
+ */
+int gq_qtip_linear_in_rows(const float *z32, uint32_t K, uint32_t P, int R, int n, const GqQtipIn *lin, int ksplit, void *stream);
+
+/*
  * Single-query attention of a QTIP model with the transform-out of its q, k and v linears folded in: qkv_lin[0..2] are the
  * descriptors gq_qtip_linear_out would take (y32 sums, SV32, M, parts; resid / out are ignored), every other argument as in
  * gq_attn_decode_split (declared below).  Each head rebuilds its head_dim outputs of q (its KV group's of k and v): the

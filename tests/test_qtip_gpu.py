@@ -441,8 +441,82 @@ def test_factor_transform_goldens(name):
         np.testing.assert_allclose(out2.float().cpu().numpy(), want_t, rtol=4e-3, atol=4e-3 * np.abs(want_t).max())
 
 
-@pytest.mark.parametrize("inter,key", [(11008, "had172"), (28672, "had28")])
-def test_qtip_native_decode_with_factor_width(tmp_path, monkeypatch, inter, key):
+@pytest.mark.parametrize("parts", [1, 2])
+def test_mlp_mid_equals_the_two_transform_chain(parts):
+    """gq_qtip_mlp_mid + gq_qtip_linear_in_rows against gq_qtip_transform (output side of gate / up) -> gq_qtip_transform (input side,
+    silu * up) -> gq_qtip_linear_in (pre-transformed) at Llama-2-7b's MLP width 11008 = 172 * 64: gate / up fp16 bit-identical
+    (same additions in the same order), the matvec input equal up to fp32 rounding of the re-ordered input side (a few fp16 ulps
+    on a few elements), the sums of down within that noise."""
+    import os
+    from guidedquant_amd import _lib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "had_n11008.npz"))
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    n, Kf, M, R = 11008, 172, 256, 2
+    hk = torch.from_numpy(g["hadK"].astype(np.float32)).to(d).contiguous()
+    hkT16, hk16 = hk.t().contiguous().half(), hk.half().contiguous()
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    yg = (torch.randn(parts, n, generator=gen) * 3.0).to(d)
+    yu = (torch.randn(parts, n, generator=gen) * 3.0).to(d)
+    svg = ((torch.rand(n, generator=gen) + 0.5) * torch.sign(torch.randn(n, generator=gen)) * 32.0 * 0.02).to(d)
+    svu = ((torch.rand(n, generator=gen) + 0.5) * torch.sign(torch.randn(n, generator=gen)) * 32.0 * 0.02).to(d)
+    sud = torch.sign(torch.randn(n, generator=gen)).to(d)
+    # two-launch chain (parts: the output side of gq_qtip_transform reads one vector -- add the parts the way the kernels do)
+    ysum_g, ysum_u = yg[0].clone(), yu[0].clone()
+    for p in range(1, parts):
+        ysum_g += yg[p]
+        ysum_u += yu[p]
+    g16 = torch.empty(n, dtype=torch.float16, device=d)
+    u16 = torch.empty(n, dtype=torch.float16, device=d)
+    xf = (_lib.GqQtipXf * 2)(_lib.GqQtipXf(ysum_g.data_ptr(), svg.data_ptr(), hk.data_ptr(), None, g16.data_ptr()),
+                             _lib.GqQtipXf(ysum_u.data_ptr(), svu.data_ptr(), hk.data_ptr(), None, u16.data_ptr()))
+    _lib.check(L.gq_qtip_transform(0, None, None, None, 0.0, 0, 2, xf, n, Kf, 0, None), "out side")
+    xs16 = torch.empty(n, dtype=torch.float16, device=d)
+    xf2 = (_lib.GqQtipXf * 1)(_lib.GqQtipXf(None, sud.data_ptr(), hk.data_ptr(), None, xs16.data_ptr()))
+    _lib.check(L.gq_qtip_transform(1, g16.data_ptr(), u16.data_ptr(), None, 0.0, 2, 1, xf2, n, Kf, 1, None), "in side")
+    # one launch
+    z32 = torch.full((n,), float("nan"), dtype=torch.float32, device=d)
+    g16b = torch.full((n,), float("nan"), dtype=torch.float16, device=d)
+    u16b = torch.full((n,), float("nan"), dtype=torch.float16, device=d)
+    mid = _lib.GqQtipMid(yg.data_ptr(), yu.data_ptr(), svg.data_ptr(), svu.data_ptr(), hkT16.data_ptr(), sud.data_ptr(), hk16.data_ptr(),
+                         z32.data_ptr(), g16b.data_ptr(), u16b.data_ptr())
+    import ctypes
+    _lib.check(L.gq_qtip_mlp_mid(ctypes.pointer(mid), parts, n, Kf, None), "mid")
+    torch.cuda.synchronize()
+    assert torch.equal(g16.view(torch.int16), g16b.view(torch.int16))
+    assert torch.equal(u16.view(torch.int16), u16b.view(torch.int16))
+    assert bool(torch.isfinite(z32).all())
+    # the row transforms that are left, in float64, against the chain's fp16 matvec input
+    z = z32.double().cpu().numpy().reshape(Kf, 64)
+    H = np.array([[1.0]])
+    while H.shape[0] < 64:
+        H = np.block([[H, H], [H, -H]])
+    want = (z @ H).reshape(-1) * n ** -0.5 / 32.0
+    got = xs16.float().cpu().numpy().astype(np.float64)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1.5e-3 * scale, np.abs(got - want).max() / scale
+    # and through the matvec: sums of a 256-row linear from both inputs
+    rng = np.random.default_rng(5)
+    comp = torch.from_numpy(rng.integers(0, 2 ** 32, size=R * M * n // 32, dtype=np.uint32).view(np.int32)).to(d)
+    tlut = (torch.randn(1024, generator=gen) * 0.5).half().to(d)
+    y_a = torch.zeros(M, dtype=torch.float32, device=d)
+    y_b = torch.zeros(M, dtype=torch.float32, device=d)
+    arr_a = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(comp.data_ptr(), None, tlut.data_ptr(), y_a.data_ptr(), M))
+    arr_b = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(comp.data_ptr(), None, tlut.data_ptr(), y_b.data_ptr(), M))
+    _lib.check(L.gq_qtip_linear_in(xs16.data_ptr(), None, None, 0.0, 3, n, R, 1, arr_a, 0, None, 1, None), "pre")
+    _lib.check(L.gq_qtip_linear_in_rows(z32.data_ptr(), n, 64, R, 1, arr_b, 1, None), "rows")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y_b).all())
+    ref = float(torch.abs(y_a).max())
+    assert float(torch.abs(y_a - y_b).max()) <= 4e-3 * ref, float(torch.abs(y_a - y_b).max()) / ref
+    # the row prologue itself: fp16 input of the matvec bit-identical to rounding the float64 rows?  (not required; the envelope
+    # above is the contract)  Validation: wrong widths are refused, not mis-served
+    assert L.gq_qtip_mlp_mid(ctypes.pointer(mid), parts, 28672, 28, None) == _lib.GQ_ENOTSUP
+    assert L.gq_qtip_linear_in(z32.data_ptr(), None, None, 0.0, 4, n, R, 1, arr_b, 0, None, 1, None) != 0
+
+
+@pytest.mark.parametrize("inter,key,mid", [(11008, "had172", "1"), (11008, "had172", "0"), (28672, "had28", "1")])
+def test_qtip_native_decode_with_factor_width(tmp_path, monkeypatch, inter, key, mid):
     """MLP width 11008 = 172 * 64 (Llama-2-7b's) / 28672 = 28 * 1024 (Llama-2-70b's): the table comes from the caller (GQ_HADAMARD_TABLES; here the golden
     fixture's copy).  Native decode (fused kernels on the power-of-two sides, gq_qtip_transform + gq_qtip_matvec on the
     factor side) against the module-by-module forward."""
@@ -462,7 +536,10 @@ def test_qtip_native_decode_with_factor_width(tmp_path, monkeypatch, inter, key)
         qtip._tables = None
     with torch.device("cuda:0"):
         m.setup_caches(max_batch_size=1, max_seq_length=64)
+    monkeypatch.setenv("GQ_QTIP_MLP_MID", mid)
     assert m._native_kind() == "qtip"
+    names = [nm for nm, _ in m._native_state()["qtip_layers"][0]["d"]]
+    assert ("gq_qtip_mlp_mid" in names) == (mid == "1" and inter == 11008), names  # (28672 = 28 * 1024: two transform launches)
     toks = [3, 77, 401]
     ref = []
     with torch.no_grad():

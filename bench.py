@@ -111,6 +111,10 @@ def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
     res = torch.randn(N, device=d, generator=g).half()
     out = torch.empty(1, 1, N, dtype=torch.float16, device=d)
     L = _lib.lib()
+    ws = None
+    if fused == "resid_ws":
+        nb = int(L.gq_anyprec_gemv_fused_ws_bytes(N, K, bits, 1))
+        ws = torch.zeros(nb // 4, dtype=torch.float32, device=d) if nb else None
     rope = None
     if fused == "qkv_rope":
         rope = dict(pos=torch.tensor([17], dtype=torch.int32, device=d), cos=torch.randn(256, 128, device=d).half(),
@@ -130,6 +134,9 @@ def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
             rc = L.gq_anyprec_gemv_qkv_rope(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, nw.data_ptr(), 1e-5,
                                             rope["pos"].data_ptr(), rope["cos"].data_ptr(), rope["sin"].data_ptr(), rope["kc"].data_ptr(),
                                             rope["vc"].data_ptr(), 4 * hkv, hkv, hd, 256, sp)
+        elif fused == "resid_ws":  # residual epilogue with the workspace the model passes (K > 16384: K split over blocks)
+            rc = L.gq_anyprec_gemv_fused_ws(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, None, 0.0,
+                                            res.data_ptr(), 1, ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0, sp)
         else:
             rc = L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, None, 0.0,
                                          res.data_ptr(), 1, sp)

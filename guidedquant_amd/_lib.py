@@ -20,7 +20,7 @@ EXPORTS = [
     "gq_attn_decode_qtip", "gq_qtip_linear_out_seg",
     "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
     "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck", "gq_hop_send", "gq_hop_wait",
-    "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows",
+    "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows", "gq_anyprec_gemv_fused_ws", "gq_anyprec_gemv_fused_ws_bytes",
 ]
 _VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer")
 
@@ -88,6 +88,8 @@ def lib():
         L.gq_qtip_mlp_mid.argtypes = [ctypes.POINTER(GqQtipMid), u32, u32, u32, vp]
         L.gq_qtip_linear_in_rows.argtypes = [vp, u32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, vp]
         L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]
+        L.gq_anyprec_gemv_fused_ws.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp, ctypes.c_size_t, vp]
+        L.gq_anyprec_gemv_fused_ws_bytes.argtypes = [u32, u32, i32, u32]
         L.gq_set_ap_mode.argtypes = [i32]
         L.gq_embed_lookup.argtypes = [vp, vp, vp, u32, u32, vp]
         L.gq_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, vp]
@@ -115,9 +117,10 @@ def lib():
         for name in EXPORTS:
             if name in _VOID:
                 getattr(L, name).restype = None
-            elif name not in ("gq_last_error", "gq_anyprec_gemm_ws_bytes"):
+            elif name not in ("gq_last_error", "gq_anyprec_gemm_ws_bytes", "gq_anyprec_gemv_fused_ws_bytes"):
                 getattr(L, name).restype = i32
         L.gq_anyprec_gemm_ws_bytes.restype = ctypes.c_size_t
+        L.gq_anyprec_gemv_fused_ws_bytes.restype = ctypes.c_size_t
         L.gq_last_error.restype = ctypes.c_char_p
         _lib = L
         # one-time hardware self-check (LDS out-of-range reads return zero: csrc/capi.hip) -- fail loudly, never corrupt sums

@@ -32,6 +32,8 @@ struct ApArgs {
     u32 SPB;               // row steps per block
     u32 epilogue;
     float eps;
+    void *ws;              // optional caller workspace (gq_anyprec_gemv_fused_ws) and its size
+    size_t ws_bytes;
 };
 
 __device__ __forceinline__ uint4 ld16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -495,7 +497,8 @@ int launch_generic(const ApArgs &a, u32 M, hipStream_t s) {
 }  // namespace
 
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
-                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream);
+                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, void *ws, size_t ws_bytes);
+size_t gq_stream_ksplit_ws_bytes(uint32_t N, uint32_t K, int bits);  // ap_stream.hip
 bool gq_plane_local_shape(uint32_t N, uint32_t K, int bits);
 
 namespace {
@@ -530,7 +533,7 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : def_min) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {
-        int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s);
+        int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s, a.ws, a.ws_bytes);
         if (rc != GQ_ENOTSUP) return rc;
     }
     const uint64_t qbytes = (uint64_t)bits * a.N * (a.K / 8u);
@@ -581,10 +584,21 @@ extern "C" int gq_anyprec_gemv(const void *x, void *out, const uint32_t *qweight
     return ap_gemv_dispatch(a, M, bits, (hipStream_t)stream);
 }
 
+extern "C" size_t gq_anyprec_gemv_fused_ws_bytes(uint32_t N, uint32_t K, int bits, uint32_t epilogue) {
+    if ((epilogue & (GQ_PRO_SILU_MUL | GQ_EPI_SILU_PAIRS)) || exact_mode()) return 0;
+    return gq_stream_ksplit_ws_bytes(N, K, bits);
+}
 extern "C" int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
                                      uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
                                      uint32_t epilogue, void *stream) {
+    return gq_anyprec_gemv_fused_ws(x, out, qweight, lut, N, K, bits, norm_weight, eps, residual, epilogue, nullptr, 0, stream);
+}
+extern "C" int gq_anyprec_gemv_fused_ws(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
+                                        uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
+                                        uint32_t epilogue, void *workspace, size_t workspace_bytes, void *stream) {
     ApArgs a{};
+    a.ws = workspace;
+    a.ws_bytes = workspace ? workspace_bytes : 0;
     a.qw = qweight;
     a.lut = (const uint16_t *)lut;
     a.x = (const uint16_t *)x;

@@ -1536,8 +1536,10 @@ bool gq_plane_local_shape(uint32_t N, uint32_t K, int bits) {
 }
 
 // returns GQ_ENOTSUP when the shape is not served by this path (caller falls back to the exact kernels)
+int gq_stream_gemv_ksplit(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                          const void *resid, void *ws, size_t ws_bytes, hipStream_t stream);  // ap_stream.hip
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
-                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
+                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, void *ws, size_t ws_bytes) {
     if (bits < 2 || bits > 4) return GQ_ENOTSUP;
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
@@ -1557,6 +1559,10 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
     // epilogue (out[n] = out[n] + y2[n], every element read and written by the same lane).  Two fp16 roundings instead
     // of one; plain and residual epilogues only.
     if (K > 32768u || K % 256u || pro != PRO_NONE || pairs) return GQ_ENOTSUP;
+    if (ws && M == 1u) {  // with a workspace: K split over blocks, one fp16 rounding (ap_stream.hip)
+        const int rc = gq_stream_gemv_ksplit(x, out, qweight, lut, N, K, bits, resid, ws, ws_bytes, stream);
+        if (rc != GQ_ENOTSUP) return rc;
+    }
     const uint32_t k1 = ((K / 2u + 1023u) / 1024u) * 1024u;
     PlaneCfg c;
     if (!pick_plane_cfg(N, k1, bits, c) || !pick_plane_cfg(N, K - k1, bits, c)) return GQ_ENOTSUP;

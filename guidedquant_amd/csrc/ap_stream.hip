@@ -57,6 +57,10 @@ struct StreamArgs {
     const uint16_t *cos_t, *sin_t;
     uint16_t *kc, *vc;
     u32 rope, H, Hkv, lhd, max_seq;  // lhd = log2(head_dim)
+    // K split over blocks (gq_stream_gemv_ksplit: rows wider than 16384, the 70B down projection): blockIdx.y = K slice of a.K
+    // activations out of Kx; the block leaves the fp32 sums of its slice in part_out[slice][N], ap_ksplit_reduce_kernel adds them
+    float *part_out;
+    u32 Kx;  // activations per row of x / per stored row (a.K = the slice this block multiplies); 0: a.K
 };
 
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILUMUL = 2 };
@@ -345,6 +349,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     float *xpart = reinterpret_cast<float *>(hotl + (size_t)NC2 * HOTCAP);  // [NC2][4][16]
     float *part = xpart + (size_t)NC2 * 64u;
     const u32 rg0 = blockIdx.x * a.RGB;
+    const u32 ksl = blockIdx.y;  // K slice (0 without a K split over blocks)
     // Which 16 rows a row group is: any 16 rows do (every lane addresses its own row).  Plain: 16 consecutive rows.  RoPE epilogue:
     // MFMA row i of group rg is row  head * hd + 8 (rg % (hd / 16)) + i / 2 + (hd / 2) (i % 2),  head = rg / (hd / 16): rows (2 m,
     // 2 m + 1) of a group are the rotation partners (d, d + hd / 2) of one head (rotate_half, inference/model.py:330-341), so the
@@ -356,15 +361,16 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     const u32 xg = l >> 4, xc = l & 3u, xtt = 4u * xg + ((l >> 2) & 3u);
     u32x4 xv[NPU], nv[NPU];
     if (is_pro) {
-        const rsrc_t rsx = make_rsrc(a.x, (PRO == PRO_SILUMUL ? 4u : 2u) * a.K);
-        const rsrc_t rsn = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * a.K);
+        const rsrc_t rsx = make_rsrc(a.x, (PRO == PRO_SILUMUL ? 4u : 2u) * a.Kx);
+        const rsrc_t rsn = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * a.Kx);
+        const u32 xs0 = 2u * ksl * a.K;  // (the block's K slice)
 #pragma unroll
         for (u32 n = 0; n < (u32)NPU; n++) {
             const u32 q = w + n * W;
             const u32 voff = q < NC2 ? 2u * (1024u * (q >> 1) + 256u * xc + 8u * (16u * (q & 1u) + xtt)) : OOB;
-            xv[n] = bload128<0>(rsx, voff, 0u);
-            if constexpr (PRO == PRO_RMSNORM) nv[n] = bload128<0>(rsn, voff, 0u);
-            if constexpr (PRO == PRO_SILUMUL) nv[n] = bload128<0>(rsx, voff, 2u * a.K);
+            xv[n] = bload128<0>(rsx, voff, xs0);
+            if constexpr (PRO == PRO_RMSNORM) nv[n] = bload128<0>(rsn, voff, xs0);
+            if constexpr (PRO == PRO_SILUMUL) nv[n] = bload128<0>(rsx, voff, xs0 + 2u * a.Kx);
         }
     }
     stamp2(0);
@@ -410,7 +416,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     u32 i_q = q0, i_rg = rgs, i_ri = 0, iu = 0;  // next unit to request
     auto issue = [&](auto SLOT) {
         constexpr u32 s = decltype(SLOT)::value;
-        const u32 soff = (grp_base(rg0 + i_rg) * a.wpr_ld + 16u * NH * i_q) * 4u;
+        const u32 soff = (grp_base(rg0 + i_rg) * a.wpr_ld + 16u * NH * i_q) * 4u + ksl * (a.K >> 3);  // (+ the K slice: K / 32 words)
 #pragma unroll
         for (u32 hh = 0; hh < (u32)NH; hh++)
 #pragma unroll
@@ -818,6 +824,19 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
             const float gv = (float)yg;
             const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * yu;
             if ((PSUM ? true : e_c == 0u) && k < 2u && row + 2u * k + 1u < a.N) gq_store_wt(a.out + (row >> 1) + k, __builtin_bit_cast(uint16_t, o));
+        } else if (a.part_out) {
+            // K split over blocks: the fp32 sums of this slice (coefficient terms included: they are linear in x) for the reduce launch
+            if (e_c == 0u && e_col == 0u) {
+                float *po = a.part_out + (size_t)ksl * a.N + row;
+                if (row + 3u < a.N) {
+                    gq_store_wt(reinterpret_cast<uint2 *>(po), make_uint2(__builtin_bit_cast(u32, y[0]), __builtin_bit_cast(u32, y[1])));
+                    gq_store_wt(reinterpret_cast<uint2 *>(po + 2), make_uint2(__builtin_bit_cast(u32, y[2]), __builtin_bit_cast(u32, y[3])));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (row + (u32)r < a.N) gq_store_wt(po + r, y[r]);
+                }
+            }
         } else if (e_c == 0u && e_col == 0u) {
             uint16_t o[4];
 #pragma unroll
@@ -844,12 +863,13 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
 }
 
 struct StreamCfg {
-    u32 grid, RGB, NPU, W, img_off;
+    u32 grid, gy, RGB, NPU, W, img_off;
     bool psum;
     size_t smem;
 };
 
-bool pick_stream_cfg(u32 N, u32 K, int bits, StreamCfg &c) {
+bool pick_stream_cfg(u32 N, u32 K, int bits, StreamCfg &c, u32 rgb_force = 0) {
+    c.gy = 1u;
     if (K % 2048u || K > 32768u) return false;  // (the epilogue adds the K-split partial sums four units at a time)
     const u32 nchunks = K / 1024u, NC2 = 2u * nchunks;
     if (NC2 > 64u) return false;  // (meta: 64 entries at a fixed offset)
@@ -860,7 +880,7 @@ bool pick_stream_cfg(u32 N, u32 K, int bits, StreamCfg &c) {
     c.NPU = (NC2 + c.W - 1u) / c.W;
     if (c.NPU == 3u) c.NPU = 4u;
     if (c.NPU > (bits == 2 ? 4u : 2u)) return false;  // (images per builder wave compiled in)
-    u32 rgb = (RGt + ncu - 1u) / ncu;
+    u32 rgb = rgb_force ? rgb_force : (RGt + ncu - 1u) / ncu;
     if (rgb < 1u) rgb = 1u;
     c.RGB = rgb;
     c.grid = (RGt + rgb - 1u) / rgb;
@@ -868,7 +888,7 @@ bool pick_stream_cfg(u32 N, u32 K, int bits, StreamCfg &c) {
     c.img_off = (4096u + 128u + rgb * 16u * np * 4u + 1023u) / 1024u * 1024u;
     const size_t fixed = c.img_off + (size_t)NC2 * 2048u + (size_t)NC2 * HOTCAP * 8u + (size_t)NC2 * 256u;
     const size_t raw = (size_t)rgb * NCU * np1 * 4u * 16u * 4u, lds = 160u * 1024u;
-    c.psum = bits > 2 || fixed + raw > lds || gq_env_int("GQ_ST_PSUM", 0);
+    c.psum = bits > 2 || fixed + raw > lds || (size_t)rgb * 4u * np * 4u > 64u * c.W || gq_env_int("GQ_ST_PSUM", 0);
     if ((size_t)rgb * 4u * np * (c.psum ? 1u : 4u) > 64u * c.W) return false;  // epilogue lanes
     if (rgb * 16u > 64u * c.W) return false;                                    // coefficient lanes
     c.smem = fixed + (c.psum ? raw / 4u : raw);
@@ -880,7 +900,7 @@ int launch_inst(const StreamArgs &a, const StreamCfg &c, hipStream_t s) {
     static GqPerDeviceOnce once;
     auto kern = ap_stream_kernel<BITS, PRO, NPU, PSUM>;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
-    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(64u * c.W), c.smem, s, a);
+    hipLaunchKernelGGL(kern, dim3(c.grid, c.gy), dim3(64u * c.W), c.smem, s, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }
@@ -909,14 +929,24 @@ int launch_pro(const StreamArgs &a, const StreamCfg &c, int pro, hipStream_t s) 
 unsigned long long *gq_debug_timing_buffer();  // ap_plane.hip (gq_debug_set_timing_buffer)
 
 namespace {
+struct KSplit {
+    float *part;      // [KS][N] fp32
+    u32 KS, kslice;   // K = KS * kslice
+};
 int stream_launch(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits, const void *normw,
-                  float eps, const void *resid, int pro, int pairs, const StreamArgs *rope, hipStream_t stream) {
+                  float eps, const void *resid, int pro, int pairs, const StreamArgs *rope, hipStream_t stream, const KSplit *ksp = nullptr) {
     if (bits < 2 || bits > gq_env_int("GQ_ST_MAXBITS", 4)) return GQ_ENOTSUP;
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
     if (((uintptr_t)qweight | (uintptr_t)x | (uintptr_t)normw | (uintptr_t)lut) & 15u) return GQ_ENOTSUP;
     StreamCfg c;
-    if (!pick_stream_cfg(N, K, bits, c)) return GQ_ENOTSUP;
+    const u32 Kk = ksp ? ksp->kslice : K;  // activations a block multiplies
+    if (ksp) {
+        // K slices x row slices ~ one block per CU: row groups per block so that KS * ceil(RGt / rgb) <= CUs
+        const u32 RGt = (N + 15u) / 16u, ncu = (u32)gq_cu_count(), rs = ncu / ksp->KS ? ncu / ksp->KS : 1u;
+        if (!pick_stream_cfg(N, Kk, bits, c, (RGt + rs - 1u) / rs)) return GQ_ENOTSUP;
+        c.gy = ksp->KS;
+    } else if (!pick_stream_cfg(N, K, bits, c)) return GQ_ENOTSUP;
     if (rope && c.psum) return GQ_ENOTSUP;
     StreamArgs a{};
     if (rope) a = *rope;
@@ -927,12 +957,14 @@ int stream_launch(const void *x, void *out, const uint32_t *qweight, const void 
     a.normw = (const uint16_t *)normw;
     a.resid = (const uint16_t *)resid;
     a.N = N;
-    a.K = K;
+    a.K = Kk;
+    a.Kx = K;
+    a.part_out = ksp ? ksp->part : nullptr;
     a.wpr_ld = K / 32u;
     a.RGB = c.RGB;
     a.img_off = c.img_off;
     {
-        const u32 NCU = 2u * (K / 1024u) / (u32)ST_NH;
+        const u32 NCU = 2u * (Kk / 1024u) / (u32)ST_NH;
         a.lw = c.W == 16u ? 4u : 3u;
         a.lq = 31u;
         if (NCU < c.W)
@@ -960,6 +992,75 @@ int stream_launch(const void *x, void *out, const uint32_t *qweight, const void 
     return GQ_ENOTSUP;
 }
 }  // namespace
+
+// ---- rows wider than 16384 activations (the 70B down projection, K = 28672): K split over BLOCKS.  One block multiplying the
+// whole row builds 56 unit images for 2 row groups of work (measured: 25.9 us in one launch, 21.8 us as two round-3 launches); a
+// block of the split form builds the 4 or 8 images of its K slice and multiplies them with ~15 row groups, the fp32 sums of the
+// slices meet in a second, tiny launch (ascending slice order, ONE fp16 rounding like the reference's kernel, anyprec.cu:505-512
+// -- the two-launch form rounds twice).  The partial sums live in a caller-supplied workspace (gq_anyprec_gemv_fused_ws).
+namespace {
+__global__ void __launch_bounds__(256) ap_ksplit_reduce_kernel(const float *part, const uint16_t *resid, uint16_t *out, u32 N, u32 KS) {
+    const u32 i4 = blockIdx.x * 256u + threadIdx.x;  // 4 outputs per thread
+    if (i4 * 4u >= N) return;
+    if (i4 * 4u + 3u < N) {
+        uint2 rw = make_uint2(0u, 0u);
+        if (resid) rw = *reinterpret_cast<const uint2 *>(resid + 4u * i4);
+        float4 p[16];
+#pragma unroll
+        for (u32 k = 0; k < 16; k++)
+            if (k < KS) p[k] = *reinterpret_cast<const float4 *>(part + (size_t)k * N + 4u * i4);
+        float4 acc = p[0];
+#pragma unroll
+        for (u32 k = 1; k < 16; k++)
+            if (k < KS) acc = make_float4(acc.x + p[k].x, acc.y + p[k].y, acc.z + p[k].z, acc.w + p[k].w);
+        const float y[4] = {acc.x, acc.y, acc.z, acc.w};
+        uint16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            _Float16 yh = (_Float16)y[r];
+            if (resid) yh = __builtin_bit_cast(_Float16, (uint16_t)((r >> 1 ? rw.y : rw.x) >> (16 * (r & 1)))) + yh;
+            o[r] = __builtin_bit_cast(uint16_t, yh);
+        }
+        gq_store_wt(reinterpret_cast<uint2 *>(out + 4u * i4), make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)));
+        return;
+    }
+    for (u32 i = 4u * i4; i < N; i++) {
+        float acc = part[i];
+        for (u32 k = 1; k < KS; k++) acc += part[(size_t)k * N + i];
+        _Float16 yh = (_Float16)acc;
+        if (resid) yh = __builtin_bit_cast(_Float16, resid[i]) + yh;
+        out[i] = __builtin_bit_cast(uint16_t, yh);
+    }
+}
+// the K slice of the split form: 4096 activations where they divide K (8 images per block), else 2048; 0: shape not served
+u32 ksplit_slice(u32 K) {
+    const u32 want = (u32)gq_env_int("GQ_ST_KSLICE", 0);
+    if (want && want % 2048u == 0u && K % want == 0u && K / want <= 16u && K / want >= 2u) return want;
+    if (K % 4096u == 0u && K / 4096u <= 16u) return 4096u;
+    if (K % 2048u == 0u && K / 2048u <= 16u) return 2048u;
+    return 0u;
+}
+}  // namespace
+
+size_t gq_stream_ksplit_ws_bytes(uint32_t N, uint32_t K, int bits) {
+    if (bits != 2 || K <= 16384u || K > 65536u || !gq_env_int("GQ_ST_KSPLIT", 1)) return 0;
+    const u32 ksl = ksplit_slice(K);
+    return ksl ? (size_t)(K / ksl) * N * 4u : 0;
+}
+// plain / residual epilogue, no prologue; GQ_ENOTSUP when the shape is not served or the workspace is too small
+int gq_stream_gemv_ksplit(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                          const void *resid, void *ws, size_t ws_bytes, hipStream_t stream) {
+    const size_t need = gq_stream_ksplit_ws_bytes(N, K, bits);
+    if (!need || !ws || ws_bytes < need || ((uintptr_t)ws & 15u) || ((uintptr_t)out & 7u) || ((uintptr_t)resid & 7u)) return GQ_ENOTSUP;
+    KSplit ks{(float *)ws, 0u, ksplit_slice(K)};
+    ks.KS = K / ks.kslice;
+    const int rc = stream_launch(x, out, qweight, lut, N, K, bits, nullptr, 0.f, nullptr, PRO_NONE, 0, nullptr, stream, &ks);
+    if (rc != GQ_OK) return rc;
+    hipLaunchKernelGGL(ap_ksplit_reduce_kernel, dim3((N / 4u + 256u) / 256u), dim3(256), 0, stream, (const float *)ws, (const uint16_t *)resid,
+                       (uint16_t *)out, N, ks.KS);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
 
 // returns GQ_ENOTSUP when the shape is not served by this kernel (the caller goes on to ap_plane.hip / the exact kernels)
 int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K, int bits,

@@ -439,8 +439,16 @@ class Transformer(nn.Module):
             # up_1, ..) rows so that the w1w3 GEMV writes silu(gate) * up directly (model.py:266 of the reference) and w2
             # reads a plain vector; state_dict() still exports the reference layout (pair_gate_up_rows_).
             self._native["pairs"] = False
+            self._native["ap_ws"] = None
             if self._native_kind() == "qtip":
                 self._native_qtip_state(self._native)
+            else:
+                # workspace of the down projection where the library splits its rows along K over blocks (K > 16384: 70B)
+                wb = max(int(_lib.lib().gq_anyprec_gemv_fused_ws_bytes(c.dim, c.intermediate_size, b.feed_forward.w2.bitwidth, 1)) for b in self.layers)
+                if wb:
+                    self._native["ap_ws"] = torch.zeros(wb // 4, dtype=torch.float32, device=dev)
+            if self._native_kind() == "qtip":
+                pass
             elif os.environ.get("GQ_NATIVE_PAIRS", "1") != "0":
                 for b in self.layers:
                     pair_gate_up_rows_(b.feed_forward.w1w3)
@@ -714,6 +722,7 @@ class Transformer(nn.Module):
         c = self.config
         b = self._native_state()
         h, y, qkv, gu, pairs = b["h"], b["y"], b["qkv"], b["gu"], b["pairs"]
+        apws = b["ap_ws"]
         if pairs:  # a load_state_dict into a sub-module bypasses _reset_native: the rows must still be paired at launch
             for blk in self.layers[l0:l1]:
                 if not getattr(blk.feed_forward.w1w3, "gq_row_pairs", False):
@@ -748,8 +757,9 @@ class Transformer(nn.Module):
                 ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(), 2 * c.intermediate_size, c.dim,
                                            ff.w1w3.bitwidth, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 4, st),
                    "w1w3")
-                ck(L.gq_anyprec_gemv_fused(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,
-                                           c.intermediate_size, ff.w2.bitwidth, None, 0.0, h.data_ptr(), 1, st), "w2")
+                ck(L.gq_anyprec_gemv_fused_ws(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,
+                                              c.intermediate_size, ff.w2.bitwidth, None, 0.0, h.data_ptr(), 1,
+                                              apws.data_ptr() if apws is not None else None, apws.numel() * 4 if apws is not None else 0, st), "w2")
                 continue
             ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(),
                                        2 * c.intermediate_size, c.dim, ff.w1w3.bitwidth,

@@ -324,6 +324,17 @@ int gq_attn_decode_qtip(const GqQtipOut *qkv_lin, const int *pos, const void *co
 int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
                           uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
                           uint32_t epilogue, void *stream);
+/*
+ * The same with a caller-supplied workspace (device memory, 16-byte aligned, private to the stream of launches that use it):
+ * rows wider than 16384 activations (Llama-3 70B's down projection, K = 28672) are then split along K over BLOCKS -- fp32 sums
+ * per K slice in the workspace, a second launch adds the slices in ascending order and rounds ONCE (anyprec.cu:505-512) --
+ * instead of over two launches through the fp16 output (two roundings).  gq_anyprec_gemv_fused_ws_bytes: the bytes this shape
+ * wants (0: no workspace form; the call then equals gq_anyprec_gemv_fused).  workspace NULL or too small: gq_anyprec_gemv_fused.
+ */
+size_t gq_anyprec_gemv_fused_ws_bytes(uint32_t N, uint32_t K, int bits, uint32_t epilogue);
+int gq_anyprec_gemv_fused_ws(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
+                             uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
+                             uint32_t epilogue, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The non-quantized pieces of one bs=1 decode step (inference/model.py:121-130,151-166,206-241).  Token id and

@@ -19,7 +19,7 @@ def _fast(force_plane=True, local=1):
         _lib.lib().gq_reset_env_cache()
 
 
-def _check_fast(got, x, q, lut, bits, oracle, rows=None):
+def _check_fast(got, x, q, lut, bits, oracle, rows=None, nround=None):
     """Fast (plane-MFMA) mode.  The reference kernel accumulates in fp16 and is itself ~1e-3 (rms, relative) away
     from the exact product, so a kernel that is MORE accurate cannot be elementwise within 1e-3 of it.  What is
     asserted instead, per element:
@@ -43,7 +43,9 @@ def _check_fast(got, x, q, lut, bits, oracle, rows=None):
         assert np.array_equal(got.view(np.uint16), ref16h.view(np.uint16))
         return
     # 16384 < K <= 32768 is served as two K-halves, the second added to the fp16 result of the first: two roundings
-    nround = 2.0 if K > 16384 else 1.0
+    # (with a workspace -- gq_anyprec_gemv_fused_ws -- the K slices meet in fp32 and are rounded once: the caller passes nround = 1)
+    if nround is None:
+        nround = 2.0 if K > 16384 else 1.0
     y64 = oracle.ap_gemv_f64(x, q, lut, bits)[0]
     ref16 = ref16h.astype(np.float64)
     W = np.abs(oracle.ap_dequant(q, lut, bits).astype(np.float64))
@@ -116,8 +118,9 @@ def lnq_like_layer(N, K, bits, seed, oracle=None):
     return q, lut, np.clip(x, -6e4, 6e4).astype(np.float16)
 
 
-def run_fused(x, q, lut, bits, norm_weight=None, eps=1e-5, residual=None, flags=0, out_elems=None):
-    """gq_anyprec_gemv_fused through the C ABI on cuda:0 (numpy in, numpy out); out is pre-filled with NaN"""
+def run_fused(x, q, lut, bits, norm_weight=None, eps=1e-5, residual=None, flags=0, out_elems=None, workspace=False):
+    """gq_anyprec_gemv_fused through the C ABI on cuda:0 (numpy in, numpy out); out is pre-filled with NaN.
+    workspace: gq_anyprec_gemv_fused_ws with the bytes gq_anyprec_gemv_fused_ws_bytes asks for (NaN-filled)"""
     import torch
     from guidedquant_amd import _lib
     d = torch.device("cuda:0")
@@ -126,6 +129,16 @@ def run_fused(x, q, lut, bits, norm_weight=None, eps=1e-5, residual=None, flags=
     xt, qt, lt = t(x, np.float16), torch.from_numpy(np.ascontiguousarray(q)).to(d), t(lut, np.float16)
     nw, rs = t(norm_weight, np.float16), t(residual, np.float16)
     out = torch.full((out_elems or N, ), float("nan"), dtype=torch.float16, device=d)
+    if workspace:
+        nb = int(_lib.lib().gq_anyprec_gemv_fused_ws_bytes(N, K, bits, flags))
+        assert nb > 0, "no workspace form for this shape"
+        ws = torch.full((nb // 4, ), float("nan"), dtype=torch.float32, device=d)
+        rc = _lib.lib().gq_anyprec_gemv_fused_ws(xt.data_ptr(), out.data_ptr(), qt.data_ptr(), lt.data_ptr(), N, K, bits,
+                                                 nw.data_ptr() if nw is not None else None, eps, rs.data_ptr() if rs is not None else None,
+                                                 flags, ws.data_ptr(), nb, _lib.current_stream_ptr())
+        _lib.check(rc, "gq_anyprec_gemv_fused_ws")
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
     rc = _lib.lib().gq_anyprec_gemv_fused(xt.data_ptr(), out.data_ptr(), qt.data_ptr(), lt.data_ptr(), N, K, bits,
                                           nw.data_ptr() if nw is not None else None, eps, rs.data_ptr() if rs is not None else None,
                                           flags, _lib.current_stream_ptr())

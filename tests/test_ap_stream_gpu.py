@@ -106,3 +106,48 @@ def test_stream_kernel_massive_channels(oracle, lr):
     nw = (1 + 0.1 * rng.normal(0, 1, K)).astype(np.float16)
     check_nonhot_accuracy(run_fused(x, q, lut, bits), x, hot, q, lut, bits, oracle)
     check_nonhot_accuracy(run_fused(x, q, lut, bits, norm_weight=nw, eps=EPS), rmsnorm_ref(x, nw, EPS), hot, q, lut, bits, oracle)
+
+
+# ----------------------------------------------------------------------------- rows wider than 16384: K split over blocks
+@pytest.mark.parametrize("kslice", ["0", "2048"])  # default slice (4096 where it divides K) / 2048 (summed parking, 4 images per block)
+@pytest.mark.parametrize("N,K", [(8192, 28672), (520, 28672), (1000, 20480), (4096, 18432)])
+def test_k_split_over_blocks_with_a_workspace(oracle, monkeypatch, N, K, kslice):
+    """gq_anyprec_gemv_fused_ws on the 70B down projection (8192 x 28672) and other rows wider than 16384: every block multiplies one
+    K slice, the fp32 sums of the slices are added in a second launch and rounded ONCE (nround = 1; the two-launch form without a
+    workspace rounds twice) -- anyprec.cu:430-436,505-512; the residual epilogue is the fp16 add of the same sums (model.py:311-313)."""
+    from guidedquant_amd import _lib
+    monkeypatch.setenv("GQ_ST_KSLICE", kslice)
+    monkeypatch.delenv("GQ_ST", raising=False)  # (the default dispatch: the K split does not depend on GQ_ST)
+    _lib.lib().gq_reset_env_cache()
+    assert _lib.lib().gq_anyprec_gemv_fused_ws_bytes(N, K, 2, 1) == (K // (4096 if kslice == "0" and K % 4096 == 0 else 2048)) * N * 4
+    assert _lib.lib().gq_anyprec_gemv_fused_ws_bytes(N, 14336, 2, 1) == 0 and _lib.lib().gq_anyprec_gemv_fused_ws_bytes(N, K, 2, 4) == 0
+    rng, q, lut = _layer(N, K, 2, N + K)
+    x = rng.normal(0, 1, K)
+    x[rng.choice(K, 6, replace=False)] *= 40.0  # massive channels (the SiLU * up product is where Llama has them)
+    x = x.astype(np.float16)
+    rows = _rows(rng, N)
+    got = run_fused(x, q, lut, 2, workspace=True)
+    assert np.isfinite(got).all()
+    _check_fast(got, x, q, lut, 2, oracle, rows=rows, nround=1.0)
+    res = rng.normal(0, 1, N).astype(np.float16)
+    got_r = run_fused(x, q, lut, 2, residual=res, flags=1, workspace=True)
+    assert np.array_equal(got_r.view(np.uint16), half_add(res, got).view(np.uint16))
+    _lib.lib().gq_reset_env_cache()
+
+
+def test_k_split_hot_channels_at_the_70b_down_projection(oracle):
+    """massive activation channels through the K split at (8192, 28672): the elements above the extraction threshold leave the image
+    of their unit and are multiplied on their own -- the other elements keep fp32-class accuracy relative to sum|w||x| of the
+    NON-hot elements (tests/ap_helpers.py::check_nonhot_accuracy), with ONE fp16 rounding."""
+    from guidedquant_amd import _lib
+    os.environ.pop("GQ_ST", None)
+    _lib.lib().gq_reset_env_cache()
+    N, K = 8192, 28672
+    rng, q, lut = _layer(N, K, 2, 77)
+    x = rng.normal(0, 0.05, K)
+    hot = rng.choice(K, 5, replace=False)
+    x[hot] = rng.choice([-1.0, 1.0], 5) * rng.uniform(40.0, 120.0, 5)
+    x = x.astype(np.float16)
+    rows = _rows(rng, N, n=24)
+    got = run_fused(x, q, lut, 2, workspace=True)
+    check_nonhot_accuracy(got[rows], x, hot, np.ascontiguousarray(q[:, rows, :]), lut[rows], 2, oracle, nround=1.0)

@@ -29,7 +29,8 @@ def _stream_everywhere():
     os.environ["GQ_ST"] = "3"
     _lib.lib().gq_reset_env_cache()
     yield
-    os.environ.pop("GQ_ST", None)
+    for k in ("GQ_ST", "GQ_PL_MIN_MWEIGHTS", "GQ_PL_MAX_BITS", "GQ_PL_LOCAL"):  # (_fast() lifts the dispatch thresholds: not for the tests that follow)
+        os.environ.pop(k, None)
     _lib.lib().gq_reset_env_cache()
     _lib.lib().gq_set_ap_mode(-1)
 

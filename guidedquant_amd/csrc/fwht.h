@@ -22,7 +22,6 @@ __device__ __forceinline__ void fwht_lds(float *v, u32 n, u32 P) {
     const u32 T = blockDim.x, tid = threadIdx.x;
     u32 h0 = 1;
     if (P >= 64u) {
-        const bool wide = P >= 512u;  // (then n / 8 is a multiple of 64: the partner threads t ^ 8, ^ 16, ^ 32 are lanes of the same wave)
         // n / 8 work items: whole waves, or the first n / 8 lanes of wave 0 (a set closed under t ^ 1, t ^ 2, t ^ 4)
         for (u32 t = tid; t < n / 8u; t += T) {
             float r[8];
@@ -57,30 +56,10 @@ __device__ __forceinline__ void fwht_lds(float *v, u32 n, u32 P) {
                     r[k] = __builtin_bit_cast(float, o) + __builtin_bit_cast(float, __builtin_bit_cast(u32, r[k]) ^ smask);
                 }
             }
-            // P >= 512: three more stages (element stride 64, 128, 256 = thread t ^ 8, ^ 16, ^ 32, all inside the wave) before the
-            // values go back to LDS -- a 4096-point transform is two LDS passes instead of three (each pass costs ~1,200 cycles of
-            // barrier + LDS latency in the prologue of every block of the fused linears).  Same butterflies, same order.
-            if (wide) {
-#pragma unroll
-                for (u32 m = 8; m < 64; m <<= 1) {
-                    const u32 smask = (t & m) ? 0x80000000u : 0u;
-#pragma unroll
-                    for (u32 k = 0; k < 8; k++) {
-                        int o = __builtin_bit_cast(int, r[k]);
-                        if (m == 8u) {  // lane ^ 8 = row mirror (^ 15) of the half-row mirror (^ 7)
-                            o = __builtin_amdgcn_update_dpp(0, o, 0x141, 0xF, 0xF, true);
-                            o = __builtin_amdgcn_update_dpp(0, o, 0x140, 0xF, 0xF, true);
-                        } else {
-                            o = __builtin_amdgcn_ds_bpermute((int)(((t & 63u) ^ m) << 2), o);  // (the LDS crossbar: no memory, no barrier)
-                        }
-                        r[k] = __builtin_bit_cast(float, o) + __builtin_bit_cast(float, __builtin_bit_cast(u32, r[k]) ^ smask);
-                    }
-                }
-            }
             *reinterpret_cast<float4 *>(v + 8u * t) = make_float4(r[0], r[1], r[2], r[3]);
             *reinterpret_cast<float4 *>(v + 8u * t + 4u) = make_float4(r[4], r[5], r[6], r[7]);
         }
-        h0 = wide ? 512u : 64u;
+        h0 = 64u;
         __syncthreads();
     }
     while (h0 < P) {

@@ -314,21 +314,29 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
 #ifndef GQ_ATTN_SPEC
 #define GQ_ATTN_SPEC 32  // cached rows requested before the position is known (a multiple of 16)
 #endif
-template <int HD>
+// QH = 1: one query head per block (grid n_head x n_split).  QH > 1 (grouped-query models, long caches): the QH query heads of a
+// KV group share a block (grid n_head / QH x n_split), every cached row is loaded ONCE and multiplied with all of them -- at
+// 4096 positions the per-head form reads each K / V row four times and waits a full memory round trip per 128-position pass
+// (19 us per layer on Llama-3-8B); here the next pass is requested before the current one is multiplied.  Per head the
+// arithmetic, the position -> stream assignment and the merge order are those of the QH = 1 form: bit-identical outputs.
+// A short context (the `solo` rule) is finished by ONE block per head: block (hq, sp < QH) takes head hq * QH + sp alone.
+template <int HD, int QH>
 __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint16_t *q, const int *pos_ptr, const uint16_t *kc, const uint16_t *vc,
                                                                      uint16_t *out, u32 H, u32 Hkv, u32 max_seq, float scale, u32 nsplit, float *ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 NW = ATTN_WAVES;
     constexpr int LPP = HD / 8, PPW = 64 / LPP, U = 4;
     constexpr u32 NS = NW * PPW, PASS = NW * PPW * U;
-    float *sc = reinterpret_cast<float *>(smem);  // [2 * NS] running max / sum of the position streams
-    float *red2 = sc + 2u * NS;                   // [NS][HD] partial outputs
+    float *sc = reinterpret_cast<float *>(smem);  // [QH][2 * NS] running max / sum of the position streams
+    float *red2 = sc + (size_t)QH * 2u * NS;      // [QH][NS][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
-    const u32 h = blockIdx.x, g = h / (H / Hkv), sp = blockIdx.y;
+    const u32 h0 = blockIdx.x * QH, g = h0 / (H / Hkv), sp = blockIdx.y;
     const u32 sub = l / LPP, ld = l % LPP;
     const uint16_t *kcg = kc + (size_t)g * max_seq * HD, *vcg = vc + (size_t)g * max_seq * HD;
-    // requests that do not depend on the position: q, and (first split) the first batch of cached rows
-    const uint4 q4 = *reinterpret_cast<const uint4 *>(q + (size_t)h * HD + ld * 8);
+    // requests that do not depend on the position: q, and (blocks that may start at row 0) the first batch of cached rows
+    uint4 q4[QH];
+#pragma unroll
+    for (int qh = 0; qh < QH; qh++) q4[qh] = *reinterpret_cast<const uint4 *>(q + (size_t)(h0 + qh) * HD + ld * 8);
     uint4 kv[U], vv[U];
     u32 t0 = w * PPW * U;
 #pragma unroll
@@ -336,107 +344,159 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint1
         const u32 t = t0 + (u32)u * PPW + sub;
         // (only the first GQ_ATTN_SPEC rows: every row requested ahead of the position is HBM traffic whether it is needed or not --
         // 128 rows x 32 heads = 2 MiB per layer, which costs what the saved round trip gains)
-        const bool in = sp == 0u && t < max_seq && t < (u32)GQ_ATTN_SPEC;
+        const bool in = sp < (u32)QH && t < max_seq && t < (u32)GQ_ATTN_SPEC;
         kv[u] = in ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
         vv[u] = in ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
     }
     const u32 pos = (u32)pos_ptr[0];
     if (pos >= max_seq) {  // decoding past the cache: the head's output is poisoned (NaN logits), like attn_decode_kernel
-        if (sp == 0u && tid < HD) out[(size_t)h * HD + tid] = 0x7e00u;
+        if (sp == 0u && tid < (u32)QH * HD) out[(size_t)h0 * HD + tid] = 0x7e00u;
         return;
     }
     const bool solo = nsplit > 1u && pos + 1u <= 2u * PASS;  // a short context is not worth splitting (see attn_decode_kernel)
+    u32 nh = QH, hb = h0;  // heads of this block: [hb, hb + nh)
     if (solo) {
-        if (sp > 0u) return;
+        if (sp >= (u32)QH) return;
+        if (QH > 1) nh = 1u, hb = h0 + sp;
         nsplit = 1u;
     }
+    const u32 spx = solo ? 0u : sp;
     const u32 per = nsplit > 1u ? (((pos + nsplit) / nsplit + PASS - 1u) / PASS) * PASS : pos + 1u;
-    const u32 p0 = sp * per, p1 = min(pos + 1u, p0 + per);
-    float qreg[8];
-    {
-        const u32 qw[4] = {q4.x, q4.y, q4.z, q4.w};
+    const u32 p0 = spx * per, p1 = min(pos + 1u, p0 + per);
+    float qreg[QH][8];
 #pragma unroll
-        for (int e = 0; e < 4; e++) qreg[2 * e] = h2f((uint16_t)(qw[e] & 0xFFFF)), qreg[2 * e + 1] = h2f((uint16_t)(qw[e] >> 16));
-    }
-    float m_run = -3.0e38f, s_run = 0.f, acc[8];
+    for (int qh = 0; qh < QH; qh++) {
+        uint4 qq = q4[qh];
+        if (QH > 1 && solo) {  // (the one head of this block: q of head h0 + sp)
 #pragma unroll
-    for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    bool have = sp == 0u && t0 + PPW * U <= (u32)GQ_ATTN_SPEC;  // the batch at t0 is already in registers
-    for (t0 = p0 + w * PPW * U; t0 < p1; t0 += NW * PPW * U) {
-        if (!have) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const u32 t = t0 + (u32)u * PPW + sub;
-                const bool in = t < p1;
-                kv[u] = in ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
-                vv[u] = in ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
-            }
+            for (int j = 1; j < QH; j++)
+                if (sp == (u32)j) qq = q4[j];
         }
-        have = false;
-        float pu[U], vfu[U][8];
+        const u32 qw[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) qreg[qh][2 * e] = h2f((uint16_t)(qw[e] & 0xFFFF)), qreg[qh][2 * e + 1] = h2f((uint16_t)(qw[e] >> 16));
+    }
+    float m_run[QH], s_run[QH], acc[QH][8];
+#pragma unroll
+    for (int qh = 0; qh < QH; qh++) {
+        m_run[qh] = -3.0e38f, s_run[qh] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[qh][e] = 0.f;
+    }
+    auto request = [&](uint4 (&kd)[U], uint4 (&vd)[U], u32 tb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 t = tb + (u32)u * PPW + sub;
+            const bool in = t < p1;
+            kd[u] = in ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+            vd[u] = in ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    t0 = p0 + w * PPW * U;
+    const bool have = p0 == 0u && t0 + PPW * U <= (u32)GQ_ATTN_SPEC;  // the batch at t0 is already in registers
+    if (!have && t0 < p1) request(kv, vv, t0);
+    for (; t0 < p1; t0 += NW * PPW * U) {
+        uint4 kn[U], vn[U];
+        const bool more = QH > 1 && t0 + NW * PPW * U < p1;  // (QH > 1: the next pass is on its way while this one is multiplied)
+        if (more) request(kn, vn, t0 + NW * PPW * U);
+        float pu[QH][U], vfu[U][8];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const u32 t = t0 + (u32)u * PPW + sub;
             const bool valid = t < p1;
             const u32 kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w}, vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
-            float p = 0.f;
+            float kf[8];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                p += qreg[2 * e] * h2f((uint16_t)(kw[e] & 0xFFFF));
-                p += qreg[2 * e + 1] * h2f((uint16_t)(kw[e] >> 16));
+                kf[2 * e] = h2f((uint16_t)(kw[e] & 0xFFFF));
+                kf[2 * e + 1] = h2f((uint16_t)(kw[e] >> 16));
                 vfu[u][2 * e] = valid ? h2f((uint16_t)(vw[e] & 0xFFFF)) : 0.f;
                 vfu[u][2 * e + 1] = valid ? h2f((uint16_t)(vw[e] >> 16)) : 0.f;
             }
-            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
-            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
-            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
-            if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
-            pu[u] = valid ? p * scale : -3.0e38f;  // (a stale row past the position may have produced anything, NaN included)
+#pragma unroll
+            for (int qh = 0; qh < QH; qh++) {
+                if (QH > 1 && (u32)qh >= nh) continue;
+                float p = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) p += qreg[qh][e] * kf[e];
+                p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
+                p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
+                p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
+                if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
+                pu[qh][u] = valid ? p * scale : -3.0e38f;  // (a stale row past the position may have produced anything, NaN included)
+            }
         }
-        float m_new = m_run;
 #pragma unroll
-        for (int u = 0; u < U; u++) m_new = fmaxf(m_new, pu[u]);
-        const float resc = __expf(m_run - m_new);
-        s_run *= resc;
+        for (int qh = 0; qh < QH; qh++) {
+            if (QH > 1 && (u32)qh >= nh) continue;  // (wave-uniform: a solo block multiplies one head)
+            float m_new = m_run[qh];
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] *= resc;
+            for (int u = 0; u < U; u++) m_new = fmaxf(m_new, pu[qh][u]);
+            const float resc = __expf(m_run[qh] - m_new);
+            s_run[qh] *= resc;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float wgt = pu[u] > -2.0e38f ? __expf(pu[u] - m_new) : 0.f;
-            s_run += wgt;
+            for (int e = 0; e < 8; e++) acc[qh][e] *= resc;
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[e] += wgt * vfu[u][e];
+            for (int u = 0; u < U; u++) {
+                const float wgt = pu[qh][u] > -2.0e38f ? __expf(pu[qh][u] - m_new) : 0.f;
+                s_run[qh] += wgt;
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[qh][e] += wgt * vfu[u][e];
+            }
+            m_run[qh] = m_new;
         }
-        m_run = m_new;
+        if (QH > 1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) kv[u] = kn[u], vv[u] = vn[u];
+        } else if (t0 + NW * PPW * U < p1) {
+            request(kv, vv, t0 + NW * PPW * U);
+        }
     }
     const u32 stream = w * PPW + sub;
 #pragma unroll
-    for (int e = 0; e < 8; e++) red2[stream * HD + ld * 8 + e] = acc[e];
-    if (ld == 0) {
-        sc[stream] = m_run;
-        sc[NS + stream] = s_run;
+    for (int qh = 0; qh < QH; qh++) {
+        if (QH > 1 && (u32)qh >= nh) continue;
+#pragma unroll
+        for (int e = 0; e < 8; e++) red2[((size_t)qh * NS + stream) * HD + ld * 8 + e] = acc[qh][e];
+        if (ld == 0) {
+            sc[qh * 2u * NS + stream] = m_run[qh];
+            sc[qh * 2u * NS + NS + stream] = s_run[qh];
+        }
     }
     __syncthreads();
-    if (tid < HD) {
+    // the factors e^(m_i - M) of the streams once per head (one thread per stream) instead of once per output element: the same
+    // values, 32 exponentials less on the tail of every thread
+    float *fl = red2 + (size_t)QH * NS * HD;  // [QH][NS] factors, [QH] maxima
+    if (tid < nh * NS) {
+        const u32 qh = tid / NS, i = tid % NS;
+        const float *scq = sc + qh * 2u * NS;
         float M = -3.0e38f;
 #pragma unroll
-        for (u32 i = 0; i < NS; i++) M = fmaxf(M, sc[i]);
+        for (u32 k = 0; k < NS; k++) M = fmaxf(M, scq[k]);
+        fl[qh * NS + i] = __expf(scq[i] - M);
+        if (i == 0u) fl[(u32)QH * NS + qh] = M;
+    }
+    __syncthreads();
+    if (tid < nh * HD) {  // thread (head, dim): the streams of the head merged in ascending order
+        const u32 qh = tid / HD, dd = tid % HD, h = hb + qh;
+        const float *scq = sc + qh * 2u * NS, *rq = red2 + (size_t)qh * NS * HD, *fq = fl + qh * NS;
+        const float M = fl[(u32)QH * NS + qh];
         float o = 0.f, sum = 0.f;
 #pragma unroll
         for (u32 i = 0; i < NS; i++) {
-            const float f = __expf(sc[i] - M);
-            sum += sc[NS + i] * f;
-            o += red2[i * HD + tid] * f;
+            const float f = fq[i];
+            sum += scq[NS + i] * f;
+            o += rq[i * HD + dd] * f;
         }
         if (nsplit > 1u) {
             float *wp = ws + ((size_t)h * nsplit + sp) * (HD + 2u);
-            wp[tid] = o;
-            if (tid == 0) {
+            wp[dd] = o;
+            if (dd == 0) {
                 wp[HD] = M;
                 wp[HD + 1] = sum;
             }
         } else {
-            out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
+            out[(size_t)h * HD + dd] = h2u((h16)(o / sum));
         }
     }
 }
@@ -451,13 +511,39 @@ __global__ void __launch_bounds__(HD) attn_combine_kernel(const float *ws, uint1
         if (pos >= max_seq || pos + 1u <= 2u * PASS) return;
     }
     const float *wp = ws + (size_t)h * nsplit * (HD + 2u);
-    float M = -3.0e38f;
-    for (u32 s = 0; s < nsplit; s++) M = fmaxf(M, wp[s * (HD + 2u) + HD]);
+    // Every load of this kernel reads what another CU has just written (an L2 miss each): a loop with one dependent load per split
+    // costs n_split memory round trips (measured: 19 -> 45 us per layer from 8 to 64 splits).  Lane s of every wave takes (M_s, l_s)
+    // in one round trip, the partial outputs come 8 splits per round trip; the sums keep the ascending split order.
+    const u32 l = tid & 63u;
+    const float Ms = l < nsplit ? wp[l * (HD + 2u) + HD] : -3.0e38f;  // (n_split <= 64; empty splits: M_s = -3e38, l_s = 0, o_s = 0)
+    const float ls = l < nsplit ? wp[l * (HD + 2u) + HD + 1] : 0.f;
+    // (the partial outputs of the first 32 splits are requested in the same round trip as the scalars)
+    float ov[32];
+#pragma unroll
+    for (u32 k = 0; k < 32; k++) ov[k] = k < nsplit ? wp[k * (HD + 2u) + tid] : 0.f;
+    float M = Ms;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) M = fmaxf(M, __shfl_xor(M, sh, 64));
+    const float fs = __expf(Ms - M);
     float o = 0.f, sum = 0.f;
-    for (u32 s = 0; s < nsplit; s++) {
-        const float f = __expf(wp[s * (HD + 2u) + HD] - M);  // empty splits: M_s = -3e38, l_s = 0, o_s = 0
-        sum += wp[s * (HD + 2u) + HD + 1] * f;
-        o += wp[s * (HD + 2u) + tid] * f;
+#pragma unroll
+    for (u32 k = 0; k < 32; k++)
+        if (k < nsplit) {  // (uniform)
+            const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fs), (int)k));
+            sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), (int)k)) * f;
+            o += ov[k] * f;
+        }
+    for (u32 s0 = 32u; s0 < nsplit; s0 += 8u) {
+        float ow[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) ow[k] = s0 + k < nsplit ? wp[(s0 + k) * (HD + 2u) + tid] : 0.f;
+#pragma unroll
+        for (u32 k = 0; k < 8; k++)
+            if (s0 + k < nsplit) {
+                const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fs), (int)(s0 + k)));
+                sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), (int)(s0 + k))) * f;
+                o += ow[k] * f;
+            }
     }
     out[(size_t)h * HD + tid] = h2u((h16)(o / sum));
 }
@@ -787,22 +873,30 @@ extern "C" int gq_attn_decode_roped(const void *q, const int *pos, const void *k
     if (n_split < 1u || n_split > 64u || (n_split > 1u && !workspace)) return gq_fail(GQ_EINVAL, "n_split in 1..64, with a workspace when > 1.");
     if (((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
     const u32 nstreams = (u32)ATTN_WAVES * 64u / (head_dim / 8u);
-    const size_t smem = ((size_t)2u * nstreams + (size_t)nstreams * head_dim) * 4u;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(n_head, n_split);
+    // grouped-query models with a split cache: the 4 query heads of a KV group in one block (every cached row loaded once)
+    const bool gqa = n_split >= 4u && n_head == 4u * n_kv_head && gq_env_int("GQ_ATTN_GQA", 1);
+    const u32 qh = gqa ? 4u : 1u;
+    const size_t smem = (size_t)qh * ((size_t)2u * nstreams + (size_t)nstreams * head_dim + nstreams + 1u) * 4u;
+    const dim3 grid(n_head / qh, n_split);
+#define GQ_LAUNCH_ROPED(HD_, QH_)                                                                                                    \
+    do {                                                                                                                             \
+        static GqPerDeviceOnce once;                                                                                                 \
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_roped_kernel<HD_, QH_>), 160 * 1024));                  \
+        hipLaunchKernelGGL((attn_roped_kernel<HD_, QH_>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)q, pos,             \
+                           (const uint16_t *)k_cache, (const uint16_t *)v_cache, (uint16_t *)out, n_head, n_kv_head, max_seq, scale,   \
+                           n_split, workspace);                                                                                      \
+        if (n_split > 1u)                                                                                                            \
+            hipLaunchKernelGGL(attn_combine_kernel<HD_>, dim3(n_head), dim3(HD_), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq); \
+    } while (0)
     if (head_dim == 128) {
-        static GqPerDeviceOnce once;
-        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_roped_kernel<128>), 160 * 1024));
-        hipLaunchKernelGGL((attn_roped_kernel<128>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)q, pos, (const uint16_t *)k_cache,
-                           (const uint16_t *)v_cache, (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
-        if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(n_head), dim3(128), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
+        if (gqa) GQ_LAUNCH_ROPED(128, 4);
+        else GQ_LAUNCH_ROPED(128, 1);
     } else {
-        static GqPerDeviceOnce once;
-        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_roped_kernel<64>), 160 * 1024));
-        hipLaunchKernelGGL((attn_roped_kernel<64>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)q, pos, (const uint16_t *)k_cache,
-                           (const uint16_t *)v_cache, (uint16_t *)out, n_head, n_kv_head, max_seq, scale, n_split, workspace);
-        if (n_split > 1u) hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(n_head), dim3(64), 0, s, workspace, (uint16_t *)out, n_split, pos, max_seq);
+        if (gqa) GQ_LAUNCH_ROPED(64, 4);
+        else GQ_LAUNCH_ROPED(64, 1);
     }
+#undef GQ_LAUNCH_ROPED
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

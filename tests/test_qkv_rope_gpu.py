@@ -138,3 +138,43 @@ def test_decode_step_with_the_fused_launch_matches_the_two_launch_step():
         os.environ.pop("GQ_QKV_ROPE", None)
         L.gq_reset_env_cache()
         L.gq_set_ap_mode(-1)
+
+
+@pytest.mark.parametrize("H,Hkv,hd,max_seq,nsplit", [(32, 8, 128, 4224, 32), (32, 8, 128, 2048, 16), (16, 4, 64, 1500, 8), (8, 2, 128, 700, 4)])
+def test_attention_with_the_heads_of_a_kv_group_in_one_block(H, Hkv, hd, max_seq, nsplit):
+    """gq_attn_decode_roped on a grouped-query model with a split cache: the four query heads of a KV group share a block (every cached
+    row loaded once, GQ_ATTN_GQA default on) -- bit-identical to one block per head (GQ_ATTN_GQA=0), at short positions (one block per
+    head finishes the context), at split boundaries and at the end of the cache; and both against a float64 softmax(q k^T) v."""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d)
+    g.manual_seed(H + hd + max_seq)
+    q = torch.randn(H * hd, device=d, generator=g).half()
+    kc = torch.randn(Hkv, max_seq, hd, device=d, generator=g).half()
+    vc = torch.randn(Hkv, max_seq, hd, device=d, generator=g).half()
+    ws = torch.zeros(H * nsplit * (hd + 2), dtype=torch.float32, device=d)
+    scale = 1.0 / math.sqrt(hd)
+    per_pass = 8 * (64 // (hd // 8)) * 4
+    positions = sorted({0, 5, 2 * per_pass - 1, 2 * per_pass, 2 * per_pass + 1, max_seq // 3, max_seq // 2 + 7, max_seq - 2, max_seq - 1})
+    try:
+        for p in positions:
+            pos = torch.tensor([p], dtype=torch.int32, device=d)
+            outs = []
+            for flag in ("1", "0"):
+                os.environ["GQ_ATTN_GQA"] = flag
+                L.gq_reset_env_cache()
+                out = torch.full((H * hd,), float("nan"), dtype=torch.float16, device=d)
+                _lib.check(L.gq_attn_decode_roped(q.data_ptr(), pos.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), H, Hkv, hd, max_seq,
+                                                  scale, nsplit, ws.data_ptr(), None), "attn")
+                torch.cuda.synchronize()
+                outs.append(out.clone())
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), p
+            qf = q.double().view(Hkv, H // Hkv, hd)
+            sc = torch.einsum("gqd,gtd->gqt", qf, kc[:, :p + 1].double()) * scale
+            want = torch.einsum("gqt,gtd->gqd", torch.softmax(sc, dim=-1), vc[:, :p + 1].double()).reshape(-1)
+            err = (outs[0].double() - want).abs().max().item()
+            assert err <= 2e-3 * max(1.0, want.abs().max().item()), (p, err)
+    finally:
+        os.environ.pop("GQ_ATTN_GQA", None)
+        L.gq_reset_env_cache()

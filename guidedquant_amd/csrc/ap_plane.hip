@@ -1548,7 +1548,9 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
     // launches of the widths up to 4096 at 2 bits (8B wqkv / w1w3); GQ_ST = 0 never, 2 every shape it serves, 3 every prologue too
     {
         const int st = gq_env_int("GQ_ST", 1);
-        if (st >= 3 || (st == 2 && pro == PRO_RMSNORM) || (st == 1 && pro == PRO_RMSNORM && bits == 2 && K <= 4096u)) {
+        // (and the 70B attention output projection, 8192 x 8192 without a prologue: 7.6 vs 7.9 us)
+        if (st >= 3 || (st == 2 && pro == PRO_RMSNORM) || (st == 1 && pro == PRO_RMSNORM && bits == 2 && K <= 4096u) ||
+            (st == 1 && pro == PRO_NONE && !pairs && bits == 2 && K == 8192u && N >= 8192u && M == 1u)) {
             const int rc = gq_stream_gemv_try(x, out, qweight, lut, M, N, K, bits, normw, eps, resid, pro, pairs, stream);
             if (rc != GQ_ENOTSUP) return rc;
         }

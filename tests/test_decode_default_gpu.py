@@ -27,13 +27,13 @@ def _restore():
     _mode(-1)
 
 
-def _model(bits, n_layer=2, seed=0):
+def _model(bits, n_layer=2, seed=0, dim=4096, inter=14336, vocab=128256, n_head=32, n_kv=8):
     from guidedquant_amd.APLinear import APLinear
     from guidedquant_amd.generate import random_init_
     from guidedquant_amd.model import ModelArgs, Transformer
     d = torch.device("cuda:0")
-    cfg = ModelArgs(block_size=8192, vocab_size=128256, n_layer=n_layer, n_head=32, dim=4096, intermediate_size=14336,
-                    n_local_heads=8, rope_base=500000, model_name="Llama-3.1-8B-2layers")
+    cfg = ModelArgs(block_size=8192, vocab_size=vocab, n_layer=n_layer, n_head=n_head, dim=dim, intermediate_size=inter,
+                    n_local_heads=n_kv, rope_base=500000, model_name="Llama-3.1-8B-2layers")
     m = Transformer(torch.float16, cfg, linear_class=APLinear, linear_kwargs=dict(bitwidth=bits, device=d))
     m = m.to(device=d, dtype=torch.float16)
     random_init_(m, seed=seed + bits)
@@ -85,6 +85,45 @@ def test_default_mode_decode_at_8b_widths_matches_torch_forward(bits):
     for i, b in enumerate(m.layers):
         dk = (b.attention.kv_cache.k_cache[:, :, :n].float() - ref_k[i][:, :, :n].float()).abs().max().item()
         assert dk <= TOL * ref_k[i][:, :, :n].float().abs().max().item(), (i, dk)
+
+
+def test_decode_with_the_down_projection_split_along_k_over_blocks():
+    """an MLP wider than 16384 (the 70B pattern: 28672; here 18432 = 9 slices of 2048 and 20480 = 5 slices of 4096 at dim 2048): the native
+    step hands the down projection a workspace (gq_anyprec_gemv_fused_ws, K split over blocks, one fp16 rounding) -- logits and
+    caches against the module forward in exact mode, and against the native step without the K split (GQ_ST_KSPLIT=0: two chained
+    launches, two roundings) within the same envelope"""
+    import os
+    from guidedquant_amd import _lib
+    d = torch.device("cuda:0")
+    for inter in (18432, 20480):
+        m = _model(2, dim=2048, inter=inter, vocab=4096, n_head=16, n_kv=4)
+        m.setup_caches(1, 32)
+        assert m.native_ready()
+        toks = [5, 17, 900, 3, 3, 512]
+        ref = []
+        with torch.no_grad():
+            _mode(1)
+            for p, t in enumerate(toks):
+                ref.append(m(torch.tensor([[t]], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d)).float().view(-1).clone())
+            for flag in ("1", "0"):
+                os.environ["GQ_ST_KSPLIT"] = flag
+                _lib.lib().gq_reset_env_cache()
+                m._reset_native()
+                try:
+                    _zero_caches(m)
+                    _mode(0)
+                    assert (m._native_state()["ap_ws"] is not None) == (flag == "1")
+                    for p, t in enumerate(toks):
+                        a = m.decode_native(torch.tensor([t], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d)).float().view(-1)
+                        torch.cuda.synchronize()
+                        assert torch.isfinite(a).all()
+                        err = (a - ref[p]).abs().max().item()
+                        assert err <= TOL * ref[p].abs().max().item(), (inter, flag, p, err)
+                        assert ((a - ref[p]).norm() / ref[p].norm()).item() <= 6e-3
+                finally:
+                    os.environ.pop("GQ_ST_KSPLIT", None)
+                    _lib.lib().gq_reset_env_cache()
+        del m
 
 
 def test_default_vs_exact_mode_greedy_tokens_over_100_steps():

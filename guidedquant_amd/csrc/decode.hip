@@ -875,7 +875,7 @@ extern "C" int gq_attn_decode_roped(const void *q, const int *pos, const void *k
     const u32 nstreams = (u32)ATTN_WAVES * 64u / (head_dim / 8u);
     hipStream_t s = (hipStream_t)stream;
     // grouped-query models with a split cache: the 4 query heads of a KV group in one block (every cached row loaded once)
-    const bool gqa = n_split >= 4u && n_head == 4u * n_kv_head && gq_env_int("GQ_ATTN_GQA", 1);
+    const bool gqa = n_split >= 4u && (n_head / n_kv_head) % 4u == 0u && gq_env_int("GQ_ATTN_GQA", 1);  // (8 heads per group: two blocks of 4)
     const u32 qh = gqa ? 4u : 1u;
     const size_t smem = (size_t)qh * ((size_t)2u * nstreams + (size_t)nstreams * head_dim + nstreams + 1u) * 4u;
     const dim3 grid(n_head / qh, n_split);

@@ -435,9 +435,9 @@ class Transformer(nn.Module):
             # grouped-query models whose wqkv launch rotates q / k (gq_attn_decode_roped): the four query heads of a KV group share a
             # block, so the splits can be as short as one 128-position pass -- n_kv_head x n_split blocks ~ one per CU
             l0 = self.layers[0].attention
-            if (S > 1024 and c.n_head == 4 * c.n_local_heads and self._native_kind() != "qtip" and os.environ.get("GQ_ATTN_GQA", "1") != "0"
+            if (S > 1024 and c.n_head % (4 * c.n_local_heads) == 0 and self._native_kind() != "qtip" and os.environ.get("GQ_ATTN_GQA", "1") != "0"
                     and _lib.lib().gq_anyprec_qkv_rope_supported(l0.wqkv.out_features, c.dim, l0.wqkv.bitwidth, c.head_dim)):
-                ns = max(4, min(32, (S + 127) // 128, 256 // max(1, c.n_local_heads)))
+                ns = max(4, min(32, (S + 127) // 128, 256 // max(1, c.n_head // 4)))
             ns = int(os.environ.get("GQ_ATTN_SPLIT", ns))
             self._native["attn_split"] = ns
             self._native["attn_ws"] = torch.zeros(c.n_head * ns * (c.head_dim + 2), dtype=torch.float32, device=dev) if ns > 1 else None

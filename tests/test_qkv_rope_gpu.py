@@ -140,7 +140,7 @@ def test_decode_step_with_the_fused_launch_matches_the_two_launch_step():
         L.gq_set_ap_mode(-1)
 
 
-@pytest.mark.parametrize("H,Hkv,hd,max_seq,nsplit", [(32, 8, 128, 4224, 32), (32, 8, 128, 2048, 16), (16, 4, 64, 1500, 8), (8, 2, 128, 700, 4)])
+@pytest.mark.parametrize("H,Hkv,hd,max_seq,nsplit", [(32, 8, 128, 4224, 32), (32, 8, 128, 2048, 16), (16, 4, 64, 1500, 8), (8, 2, 128, 700, 4), (16, 2, 128, 1200, 8)])
 def test_attention_with_the_heads_of_a_kv_group_in_one_block(H, Hkv, hd, max_seq, nsplit):
     """gq_attn_decode_roped on a grouped-query model with a split cache: the four query heads of a KV group share a block (every cached
     row loaded once, GQ_ATTN_GQA default on) -- bit-identical to one block per head (GQ_ATTN_GQA=0), at short positions (one block per

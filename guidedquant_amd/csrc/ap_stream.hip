@@ -293,6 +293,9 @@ constexpr u32 META_W = 16u;
 #ifndef ST_W34
 #define ST_W34 8  // ... at 3 and 4 bits (more accumulators and plane words per wave)
 #endif
+#ifndef ST_PF
+#define ST_PF 2
+#endif
 #ifndef ST_NH
 #define ST_NH 1   // unit halves per consumer unit: 1 = a wave multiplies half chunks (32 image registers), 2 = whole chunks (64)
 #endif
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
     constexpr u32 W = WV, T = 64u * W;
     constexpr u32 RING = 4u;   // plane-word register slots (consumer units) per wave
-    constexpr u32 PF = 2u;     // consumer units requested ahead
+    constexpr u32 PF = ST_PF;  // consumer units requested ahead (< RING)
     constexpr u32 LPU = (u32)BITS * NH;  // plane loads per consumer unit
     constexpr u32 NCOL = PSUM ? 1u : 4u;
     static_assert(PSUM || BITS == 2, "raw parking: the (column, Moebius index) lanes of a row quad must fit a DPP row");
@@ -622,9 +625,12 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     }
     stamp2(6);
     if (1u < n_units) issue(std::integral_constant<u32, 1>{});
+    if constexpr (PF >= 3u) {
+        if (2u < n_units) issue(std::integral_constant<u32, 2>{});
+    }
     stamp2(7);
     if (!is_pro) {
-        wait_vm_units<LPU>(iu > 1u ? 1u : 0u);  // everything in front of the second unit
+        wait_vm_units<LPU>(iu > 1u ? iu - 1u : 0u);  // everything in front of the second unit
         coefficients();
     }
 
@@ -677,9 +683,8 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
             }
             if (!stamped) stamp(2), stamped = true;
         }
-        // the requests behind this unit's: one more unit, or none at the tail
-        if (iu - 1u - u) wait_vm<LPU>();
-        else wait_vm<0>();
+        // the requests behind this unit's: up to PF - 1 more units, or none at the tail
+        wait_vm_units<LPU>(iu - 1u - u);
 #pragma unroll
         for (u32 hh = 0; hh < (u32)NH; hh++)
 #pragma unroll

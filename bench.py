@@ -397,12 +397,15 @@ def qtip_roofline(cfg, R, shape=None):
     gbs = b_qtip(R, M, K) / us / 1e3
     # HBM bytes per launch from the PMC counters: offline --pmc passes of the same kernel / shape (tools/prof_qtip_traffic.sh)
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r03_qtip_matvec_traffic.json")
-    if os.path.exists(tpath):
+    for fn in ("r04_qtip_matvec_traffic.json", "r03_qtip_matvec_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", fn)
+        if traffic is not None or not os.path.exists(tpath):
+            continue
         with open(tpath) as f:
             t = json.load(f)
-        if t.get("M") == M and t.get("K") == K and t.get("R") == R:
-            traffic, traffic_src = t.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/r03_qtip_matvec_traffic.json)" % t.get("kernel")
+        for rec in t.get("shapes", [t]):
+            if rec.get("M") == M and rec.get("K") == K and rec.get("R") == R:
+                traffic, traffic_src = rec.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/%s)" % (rec.get("kernel"), fn)
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBPS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "kernel": "QTIP trellis matvec %dx%d R=%d (gq_qtip_matvec)" % (M, K, R),
             "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": b_qtip(R, M, K)}

@@ -116,14 +116,36 @@ def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
         nb = int(L.gq_anyprec_gemv_fused_ws_bytes(N, K, bits, 1))
         ws = torch.zeros(nb // 4, dtype=torch.float32, device=d) if nb else None
     rope = None
-    if fused == "qkv_rope":
+    if fused in ("qkv_rope", "qkv_rope_ho"):
         rope = dict(pos=torch.tensor([17], dtype=torch.int32, device=d), cos=torch.randn(256, 128, device=d).half(),
                     sin=torch.randn(256, 128, device=d).half(), kc=torch.zeros(N // 128 // 6, 256, 128, dtype=torch.float16, device=d),
                     vc=torch.zeros(N // 128 // 6, 256, 128, dtype=torch.float16, device=d))
 
+    # "_ho" forms: the statistics hand-over of the decode graph (include/gq_hip.h, round 5) -- RMSNorm prologues read the partial sums
+    # of squares of x (written here once by gq_ssq_rows), residual epilogues write those of their outputs
+    ho = fused is not None and fused.endswith("_ho")
+    if ho:
+        fused = fused[:-3]
+    ssq = torch.zeros(_lib.SSQ_SLOTS, dtype=torch.float32, device=d)
+    if ho:
+        assert L.gq_ssq_rows(x.data_ptr(), K, ssq.data_ptr(), _lib.current_stream_ptr()) == 0, L.gq_last_error()
+    ssq_in = ssq.data_ptr() if ho else None
+
     def run(i):
         sp = _lib.current_stream_ptr()
-        if fused is None:
+        if ho and fused in ("norm", "norm_pairs"):
+            rc = L.gq_anyprec_gemv_fused_ho(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, nw.data_ptr(),
+                                            1e-5, None, 4 if fused == "norm_pairs" else 0, None, 0, ssq_in, None, sp)
+        elif ho and fused == "qkv_rope":
+            hd = 128
+            hkv = N // hd // 6
+            rc = L.gq_anyprec_gemv_qkv_rope_ho(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, nw.data_ptr(), 1e-5,
+                                               rope["pos"].data_ptr(), rope["cos"].data_ptr(), rope["sin"].data_ptr(), rope["kc"].data_ptr(),
+                                               rope["vc"].data_ptr(), 4 * hkv, hkv, hd, 256, ssq_in, sp)
+        elif ho and fused == "resid":
+            rc = L.gq_anyprec_gemv_fused_ho(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, None, 0.0,
+                                            res.data_ptr(), 1, None, 0, None, ssq.data_ptr(), sp)
+        elif fused is None:
             rc = L.gq_anyprec_gemv(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), 1, N, K, bits, 0, sp)
         elif fused in ("norm", "norm_pairs"):
             rc = L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), qs[i].data_ptr(), luts[i].data_ptr(), N, K, bits, nw.data_ptr(),
@@ -144,7 +166,7 @@ def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
 
     us = graph_time_us(run, nbuf, iters)
     gbs = b_ap(bits, N, K) / us / 1e3
-    return {"shape": name, "N": N, "K": K, "bits": bits, "launch": fused or "plain", "us": round(us, 3), "GBps": round(gbs, 1),
+    return {"shape": name, "N": N, "K": K, "bits": bits, "launch": (fused or "plain") + ("_ho" if ho else ""), "us": round(us, 3), "GBps": round(gbs, 1),
             "frac": round(gbs / HBM_PEAK_GBPS, 4)}
 
 
@@ -152,15 +174,16 @@ def decode_tok_s(model, dev, steps, warmup, torch_sampling=False):
     """tokens/s of the captured decode step (BOS prompt, sequences of 100 new tokens), wall clock around `steps` replays"""
     import torch
     from guidedquant_amd.generate import DecodeGraph
-    graph = DecodeGraph(model, dev, native_sampling=not torch_sampling, temperature=0.0, top_k=32)
+    # (round 5: the embedding lookup of the NEXT token rides in the sampler's last block -- GQ_FOLD_EMBED=0 restores the launch)
+    graph = DecodeGraph(model, dev, native_sampling=not torch_sampling, temperature=0.0, top_k=32,
+                        fold_embed=os.environ.get("GQ_FOLD_EMBED", "1") != "0")
     bos = torch.tensor([[(128000 if model.config.vocab_size > 100000 else 1)]], dtype=torch.int32, device=dev)
     zero = torch.zeros((1, ), dtype=torch.int32, device=dev)
 
     def run_steps(n):
         done = 0
         while done < n:
-            graph.tok.copy_(bos)
-            graph.pos.copy_(zero)
+            graph.set_token(bos, zero)
             for _ in range(min(SEQ_NEW_TOKENS, n - done)):
                 graph.step()
             done += min(SEQ_NEW_TOKENS, n - done)
@@ -485,11 +508,11 @@ def long_context_record(dev, start=4096, steps=100):
     torch.manual_seed(1234)
     model = load_model(MODEL, dev, "ap", 2, random_init=True)
     model.setup_caches(1, start + steps + 1)
-    graph = DecodeGraph(model, dev, native_sampling=True, temperature=0.0, top_k=32)
+    graph = DecodeGraph(model, dev, native_sampling=True, temperature=0.0, top_k=32, fold_embed=True)
     p0 = torch.tensor([start], dtype=torch.int32, device=dev)
 
     def run():
-        graph.pos.copy_(p0)
+        graph.set_token(1, p0)
         for _ in range(steps):
             graph.step()
 

@@ -21,7 +21,9 @@ EXPORTS = [
     "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
     "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck", "gq_hop_send", "gq_hop_wait",
     "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows", "gq_anyprec_gemv_fused_ws", "gq_anyprec_gemv_fused_ws_bytes",
+    "gq_sample_topk_ex", "gq_anyprec_gemv_fused_ho", "gq_ssq_rows", "gq_anyprec_handover_plan", "gq_embed_lookup_ho", "gq_anyprec_gemv_qkv_rope_ho",
 ]
+SSQ_SLOTS = 1024  # include/gq_hip.h GQ_SSQ_SLOTS
 _VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer")
 
 
@@ -90,6 +92,11 @@ def lib():
         L.gq_anyprec_gemv_fused.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp]
         L.gq_anyprec_gemv_fused_ws.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp, ctypes.c_size_t, vp]
         L.gq_anyprec_gemv_fused_ws_bytes.argtypes = [u32, u32, i32, u32]
+        L.gq_anyprec_gemv_fused_ho.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, u32, vp, ctypes.c_size_t, vp, vp, vp]
+        L.gq_ssq_rows.argtypes = [vp, u32, vp, vp]
+        L.gq_anyprec_handover_plan.argtypes = [u32, u32, i32, i32, u32]
+        L.gq_embed_lookup_ho.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+        L.gq_anyprec_gemv_qkv_rope_ho.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, vp, vp, vp, vp, u32, u32, u32, u32, vp, vp]
         L.gq_set_ap_mode.argtypes = [i32]
         L.gq_embed_lookup.argtypes = [vp, vp, vp, u32, u32, vp]
         L.gq_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, vp]
@@ -97,6 +104,7 @@ def lib():
         L.gq_attn_decode_qtip.argtypes = [ctypes.POINTER(GqQtipOut), vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp]
         L.gq_dense_gemv_f16.argtypes = [vp, vp, vp, u32, u32, vp, f32, vp]
         L.gq_sample_topk.argtypes = [vp, u32, i32, f32, u32, vp, vp, vp, vp, vp, vp, vp]
+        L.gq_sample_topk_ex.argtypes = [vp, u32, i32, f32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, u32, vp, vp]
         L.gq_anyprec_gemv_cpu.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, i32, i32]
         L.gq_anyprec_dequant_cpu.argtypes = [vp, vp, vp, u32, u32, i32, i32]
         L.gq_anyprec_gemm.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, vp]

@@ -34,6 +34,8 @@ struct ApArgs {
     float eps;
     void *ws;              // optional caller workspace (gq_anyprec_gemv_fused_ws) and its size
     size_t ws_bytes;
+    const float *ssq_in;   // statistics hand-over (gq_anyprec_gemv_fused_ho): partial sums of squares of x / of the outputs
+    float *ssq_out;
 };
 
 __device__ __forceinline__ uint4 ld16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -160,7 +162,7 @@ __device__ __forceinline__ uint16_t reduce_row(const RowGeom &G, const uint16_t 
 // vmcnt bookkeeping stays exact.  The lane's activations stay in 64 VGPRs for the whole loop.
 // ----------------------------------------------------------------------------------------------
 template <int BITS, int D, int PRO>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <= 3 ? 3 : 2))) ap_gemv_quad_kernel(ApArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <= 3 && D == 1 ? 3 : 2))) ap_gemv_quad_kernel(ApArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RowGeom G;
     G.init(a.K);
@@ -433,9 +435,15 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
     c.T = bestT;
     c.RS = bestT / Q;
     const u32 steps = (N + c.RS - 1) / c.RS;
-    // persistent-style grid: about `bpc` blocks per CU, every block the same number of steps
+    // ring depth D (steps of plane words + LUT row in flight per lane).  Register budget (tests/test_kernel_resources_cpu.py checks that
+    // no instance the dispatcher can pick spills): D = 1 fits 3 waves per SIMD at 2 / 3 bits (<= 168 VGPRs); deeper rings and 4 bits are
+    // compiled for 2 waves per SIMD (256 VGPRs), where 4 bits fits D <= 3
+    int d = gq_env_int("GQ_AP_D", 0);
+    if (d < 1 || d > 4) d = bits <= 3 ? 1 : 2;
+    if (bits == 4 && d > 3) d = 3;
+    // persistent-style grid: about `bpc` blocks per CU (what the kernel's occupancy allows), every block the same number of steps
     const u32 cus = (u32)num_cus();
-    u32 bpc = (u32)gq_env_int("GQ_AP_BPC", bits <= 3 ? 3 : 2);
+    u32 bpc = (u32)gq_env_int("GQ_AP_BPC", bits <= 3 && d == 1 ? 3 : 2);
     if (bpc < 1) bpc = 1;
     u32 target = cus * bpc;
     u32 spb = (steps + target - 1) / target;
@@ -447,8 +455,6 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
     if (smem_for(spb) > 160u * 1024u) return false;
     c.SPB = spb;
     c.grid = (steps + spb - 1) / spb;
-    int d = gq_env_int("GQ_AP_D", 0);
-    if (d < 1 || d > 4) d = bits <= 3 ? 1 : 2;
     if ((u32)d > spb) d = (int)spb;
     c.D = (u32)d;
     c.smem = smem_for(spb);
@@ -472,7 +478,9 @@ int launch_quad_d(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
         case 1: return launch_quad_inst<BITS, 1, PRO>(a, c, M, s);
         case 2: return launch_quad_inst<BITS, 2, PRO>(a, c, M, s);
         case 3: return launch_quad_inst<BITS, 3, PRO>(a, c, M, s);
-        default: return launch_quad_inst<BITS, 4, PRO>(a, c, M, s);
+        default:
+            if constexpr (BITS <= 3) return launch_quad_inst<BITS, 4, PRO>(a, c, M, s);
+            else return launch_quad_inst<BITS, 3, PRO>(a, c, M, s);  // (pick_quad_cfg never asks for more at 4 bits: D = 4 would spill)
     }
 }
 
@@ -497,7 +505,8 @@ int launch_generic(const ApArgs &a, u32 M, hipStream_t s) {
 }  // namespace
 
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
-                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, void *ws, size_t ws_bytes);
+                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, void *ws, size_t ws_bytes,
+                      GqHandover *ho);
 size_t gq_stream_ksplit_ws_bytes(uint32_t N, uint32_t K, int bits);  // ap_stream.hip
 bool gq_plane_local_shape(uint32_t N, uint32_t K, int bits);
 
@@ -512,7 +521,32 @@ bool exact_mode() {
 bool gq_ap_exact_mode() { return exact_mode(); }  // (ap_stream.hip: the fused q / k / v + RoPE launch is a fast-mode kernel)
 namespace {
 
+// Stand-alone producer of the hand-over statistics: GQ_SSQ_SLOTS partial sums of squares of an fp16 vector (slot t: elements t, t + 1024,
+// ..).  What a GEMV launch without the in-epilogue form is followed by when the caller asked for ssq_out; also gq_ssq_rows.
+__global__ void __launch_bounds__(GQ_SSQ_SLOTS) ssq_rows_kernel(const uint16_t *x, u32 n, float *ssq) {
+    float acc = 0.f;
+    for (u32 i = threadIdx.x; i < n; i += (u32)GQ_SSQ_SLOTS) {
+        const float v = h2f(x[i]);
+        acc += v * v;
+    }
+    gq_store_wt(ssq + threadIdx.x, acc);
+}
+
+int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover *ho);
 int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
+    GqHandover ho;
+    ho.ssq_in = a.ssq_in;
+    ho.ssq_out = a.ssq_out;
+    if (ho.ssq_out && ((a.epilogue & GQ_EPI_SILU_PAIRS) || M != 1u)) return gq_fail(GQ_EINVAL, "ssq_out: plain / residual epilogue, M = 1 only.");
+    const int rc = ap_gemv_dispatch_inner(a, M, bits, s, &ho);
+    if (rc == GQ_OK && ho.ssq_out && !ho.ssq_written) {  // the kernel that served the shape has no in-epilogue form: one small launch more
+        hipLaunchKernelGGL(ssq_rows_kernel, dim3(1), dim3(GQ_SSQ_SLOTS), 0, s, a.out, a.N, ho.ssq_out);
+        GQ_HIP_CHECK(hipGetLastError());
+    }
+    return rc;
+}
+
+int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover *ho) {
     if (bits < 2 || bits > 8) return gq_fail(GQ_EINVAL, "Bitwidth must be between 2 and 8.");
     if (M < 1 || M > 8) return gq_fail(GQ_EINVAL, "batch size M must be between 1 and 8 (anyprec.cu:602).");
     if (a.K == 0 || a.K % 32u) return gq_fail(GQ_EINVAL, "input_feat (K) must be a positive multiple of 32.");
@@ -533,9 +567,10 @@ int ap_gemv_dispatch(ApArgs a, u32 M, int bits, hipStream_t s) {
     const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : def_min) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {
-        int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s, a.ws, a.ws_bytes);
+        int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s, a.ws, a.ws_bytes, ho);
         if (rc != GQ_ENOTSUP) return rc;
     }
+    if (ho && ho->dry) return GQ_OK;  // (the exact-mode kernels have no hand-over form)
     const uint64_t qbytes = (uint64_t)bits * a.N * (a.K / 8u);
     if (!force_generic && bits <= 4 && qbytes < 0x7FFFFFFFull && pick_quad_cfg(a.N, a.K, bits, c) &&
         (((uintptr_t)a.qw | (uintptr_t)a.x | (uintptr_t)a.normw) & 15u) == 0 && ((uintptr_t)a.lut & 15u) == 0 &&
@@ -596,7 +631,42 @@ extern "C" int gq_anyprec_gemv_fused(const void *x, void *out, const uint32_t *q
 extern "C" int gq_anyprec_gemv_fused_ws(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
                                         uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
                                         uint32_t epilogue, void *workspace, size_t workspace_bytes, void *stream) {
+    return gq_anyprec_gemv_fused_ho(x, out, qweight, lut, N, K, bits, norm_weight, eps, residual, epilogue, workspace, workspace_bytes, nullptr,
+                                    nullptr, stream);
+}
+extern "C" int gq_anyprec_handover_plan(uint32_t N, uint32_t K, int bits, int has_norm, uint32_t epilogue) {
+    // which kernel would serve the launch, without launching: 1 = its RMSNorm prologue reads ssq_in, 2 = its epilogue writes ssq_out
     ApArgs a{};
+    alignas(16) static const unsigned char al[16] = {0};  // (a 16-byte aligned stand-in for every pointer: never dereferenced)
+    a.qw = (const u32 *)al;
+    a.lut = (const uint16_t *)al;
+    a.x = (const uint16_t *)al;
+    a.out = (uint16_t *)al;
+    a.normw = has_norm ? (const uint16_t *)al : nullptr;
+    a.resid = (epilogue & GQ_EPI_RESIDUAL) ? (const uint16_t *)al : nullptr;
+    a.N = N;
+    a.K = K;
+    a.epilogue = epilogue;
+    GqHandover ho;
+    ho.dry = true;
+    ho.ssq_in = (const float *)al;
+    ho.ssq_out = (epilogue & GQ_EPI_SILU_PAIRS) ? nullptr : (float *)al;
+    if (ap_gemv_dispatch_inner(a, 1, bits, nullptr, &ho) != GQ_OK) return 0;
+    return (ho.ssq_consumed ? 1 : 0) | (ho.ssq_written ? 2 : 0);
+}
+extern "C" int gq_ssq_rows(const void *x, uint32_t n, float *ssq_out, void *stream) {
+    if (!x || !ssq_out || n == 0) return gq_fail(GQ_EINVAL, "null pointer argument / empty vector.");
+    hipLaunchKernelGGL(ssq_rows_kernel, dim3(1), dim3(GQ_SSQ_SLOTS), 0, (hipStream_t)stream, (const uint16_t *)x, n, ssq_out);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+extern "C" int gq_anyprec_gemv_fused_ho(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
+                                        uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
+                                        uint32_t epilogue, void *workspace, size_t workspace_bytes, const float *ssq_in, float *ssq_out,
+                                        void *stream) {
+    ApArgs a{};
+    a.ssq_in = norm_weight ? ssq_in : nullptr;
+    a.ssq_out = ssq_out;
     a.ws = workspace;
     a.ws_bytes = workspace ? workspace_bytes : 0;
     a.qw = qweight;

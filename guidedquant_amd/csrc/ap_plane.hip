@@ -56,8 +56,12 @@ struct PlaneArgs {
                  // 256 late waves request only their first item up front, 1024 no plane loads (the MFMA phase runs on stale LDS)
     float eps;
     unsigned long long *dbg;  // optional: per-wave phase timestamps of block 0 (tools/phase_timing.py)
+    float *ssq_out;           // statistics hand-over (gq_hip.h GQ_SSQ_SLOTS): block b leaves the sum of squares of its fp16 outputs in slot b
 };
 
+#ifndef PL_SSQ_MODE
+#define PL_SSQ_MODE 2  // statistics hand-over slots: plain stores, slots grouped by XCD (see plane_epilogue)
+#endif
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILUMUL = 2 };
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
@@ -430,7 +434,36 @@ __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lu
             if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[(size_t)m * a.N + row]) + yh;
             store_out16(a.out + (size_t)m * a.N + row, __builtin_bit_cast(uint16_t, yh));
         }
+        if (a.ssq_out) {
+            // hand-over to the RMSNorm prologue of the NEXT launch (include/gq_hip.h, GQ_SSQ_SLOTS): the sum of squares of the fp16
+            // values just stored, one slot per epilogue wave (whole waves: 16 RGB 2^b is a multiple of 64; host: one pass of this
+            // loop, M = 1, plain / residual epilogue).  Fixed DPP tree: deterministic.
+            const float v = (c == 0u && row < a.N) ? (float)yh * (float)yh : 0.f;
+            const float tot = wave_reduce<false>(v);
+            // slot: blocks go to the XCDs round-robin (block b on XCD b % 8) -- the 32 slots of a 128-byte line belong to ONE XCD's
+            // blocks, so the line is assembled in that XCD's L2 and written once (PL_SSQ_MODE: 0 write-through + linear slots, which
+            // measured +0.6 us on wo / w2: 8 XCDs read-modify-write each 32-byte sector)
+            const u32 sl = blockIdx.x * ((a.RGB * 16u * (u32)NP) >> 6) + (tid >> 6);
+#if PL_SSQ_MODE == 0
+            if ((tid & 63u) == 63u) gq_store_wt(a.ssq_out + sl, tot);
+#elif PL_SSQ_MODE == 1
+            if ((tid & 63u) == 63u) gq_store_wt(a.ssq_out + ((sl & 7u) * ((u32)GQ_SSQ_SLOTS / 8u) + (sl >> 3)), tot);
+#elif PL_SSQ_MODE == 2
+            if ((tid & 63u) == 63u) a.ssq_out[(sl & 7u) * ((u32)GQ_SSQ_SLOTS / 8u) + (sl >> 3)] = tot;
+#else
+            if ((tid & 63u) == 63u) a.ssq_out[sl] = tot;
+#endif
+        }
     }
+    // (the consumer adds all GQ_SSQ_SLOTS: block 0 clears the slots no wave of the grid writes)
+    if (a.ssq_out && blockIdx.x == 0u)
+        for (u32 i = gridDim.x * ((a.RGB * 16u * (u32)NP) >> 6) + tid; i < (u32)GQ_SSQ_SLOTS; i += T) {
+#if PL_SSQ_MODE == 1 || PL_SSQ_MODE == 2
+            a.ssq_out[(i & 7u) * ((u32)GQ_SSQ_SLOTS / 8u) + (i >> 3)] = 0.f;
+#else
+            a.ssq_out[i] = 0.f;
+#endif
+        }
 }
 
 // F.silu(gate) * up on two packed fp16 pairs -- inference/model.py:266
@@ -1455,12 +1488,12 @@ unsigned long long *g_dbg = nullptr;
 extern "C" void gq_debug_set_timing_buffer(void *p) { g_dbg = (unsigned long long *)p; }
 unsigned long long *gq_debug_timing_buffer() { return g_dbg; }  // (ap_stream.hip stamps into the same buffer)
 int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K, int bits,
-                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream);  // ap_stream.hip
+                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, GqHandover *ho);  // ap_stream.hip
 
 namespace {
 int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t Kfull,
                        uint32_t k0, uint32_t Ks, int bits, const void *normw, float eps, const void *resid, int pro, int pairs,
-                       hipStream_t stream) {
+                       hipStream_t stream, GqHandover *ho = nullptr) {
     PlaneCfg c;
     // M = 2 .. 8 batch rows: up to 4 of them share ONE pass over the planes (shared-image kernel, one image per row) when the images
     // fit LDS next to the rings and the staged copy -- K <= 4096 for 4 rows, K <= 8192 for 2 --; else one block row per batch row
@@ -1513,6 +1546,12 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
     a.xflags = (u32)gq_env_int("GQ_PL_XFLAGS", 0);
     a.eps = eps;
     a.dbg = g_dbg;
+    // the block's outputs in whole epilogue waves of ONE pass, one slot per wave (plane_epilogue)
+    if (ho && ho->ssq_out && M == 1u && !pairs && c.RGB * 16u * (1u << bits) <= c.T && c.grid * ((c.RGB * 16u * (1u << bits)) >> 6) <= (u32)GQ_SSQ_SLOTS) {
+        a.ssq_out = ho->ssq_out;
+        ho->ssq_written = true;
+    }
+    if (ho && ho->dry) return GQ_OK;
     if (local) {
         a.rawx = a.himg = 0u;
         switch (bits) {
@@ -1539,7 +1578,8 @@ bool gq_plane_local_shape(uint32_t N, uint32_t K, int bits) {
 int gq_stream_gemv_ksplit(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
                           const void *resid, void *ws, size_t ws_bytes, hipStream_t stream);  // ap_stream.hip
 int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K,
-                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, void *ws, size_t ws_bytes) {
+                      int bits, const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, void *ws, size_t ws_bytes,
+                      GqHandover *ho) {
     if (bits < 2 || bits > 4) return GQ_ENOTSUP;
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
@@ -1551,11 +1591,11 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
         // (and the 70B attention output projection, 8192 x 8192 without a prologue: 7.6 vs 7.9 us)
         if (st >= 3 || (st == 2 && pro == PRO_RMSNORM) || (st == 1 && pro == PRO_RMSNORM && bits == 2 && K <= 4096u) ||
             (st == 1 && pro == PRO_NONE && !pairs && bits == 2 && K == 8192u && N >= 8192u && M == 1u)) {
-            const int rc = gq_stream_gemv_try(x, out, qweight, lut, M, N, K, bits, normw, eps, resid, pro, pairs, stream);
+            const int rc = gq_stream_gemv_try(x, out, qweight, lut, M, N, K, bits, normw, eps, resid, pro, pairs, stream, ho);
             if (rc != GQ_ENOTSUP) return rc;
         }
     }
-    if (K <= 16384u) return plane_launch_slice(x, out, qweight, lut, M, N, K, 0u, K, bits, normw, eps, resid, pro, pairs, stream);
+    if (K <= 16384u) return plane_launch_slice(x, out, qweight, lut, M, N, K, 0u, K, bits, normw, eps, resid, pro, pairs, stream, ho);
     // 16384 < K <= 32768 (the 70B down projection): the B image of the whole row does not fit LDS, so the row is split at a
     // chunk boundary into two launches; the second adds its half to the first one's fp16 result through the residual
     // epilogue (out[n] = out[n] + y2[n], every element read and written by the same lane).  Two fp16 roundings instead

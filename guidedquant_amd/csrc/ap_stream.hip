@@ -61,6 +61,8 @@ struct StreamArgs {
     // activations out of Kx; the block leaves the fp32 sums of its slice in part_out[slice][N], ap_ksplit_reduce_kernel adds them
     float *part_out;
     u32 Kx;  // activations per row of x / per stored row (a.K = the slice this block multiplies); 0: a.K
+    // statistics hand-over (include/gq_hip.h, GQ_SSQ_SLOTS): the partial sums of squares of x, left by the launch that wrote x
+    const float *ssq_in;
 };
 
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILUMUL = 2 };
@@ -175,8 +177,14 @@ __device__ __forceinline__ void wait_vm_units(u32 n) {
 
 // The MFMAs of one (unit half hh, nibble bit NB) block: FP4 operands of the plane subsets built on the fly (the mask commutes
 // with AND; depth-first over the subset lattice).  Plane p holds code bit BITS-1-p; subset index cm = OR of the code bits.
-template <int BITS, int NB>
+template <int BITS, int NB, bool FIRST = false>
 __device__ __forceinline__ void mfma_b(v4f (&acc)[(1 << BITS) - 1], const u32x4 (&A)[BITS], v8i Bv, int sb) {
+    // FIRST: every accumulator is written by this block (each subset has one MFMA per nibble bit) -- SrcC is the inline constant 0
+    // instead of a register cleared with 4 v_mov per subset and unit
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int i = 0; i < (1 << BITS) - 1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
     v4i Mp[BITS];
 #pragma unroll
     for (int p = 0; p < BITS; p++)
@@ -296,6 +304,13 @@ constexpr u32 META_W = 16u;
 #ifndef ST_PF
 #define ST_PF 2
 #endif
+#ifndef ST_KO
+#define ST_KO 0   // build-time knock-outs, WRONG numerics, timing only (bit mask): 1 no sum-of-squares exchange, 8 no image reads
+#endif
+#ifndef ST_TAU_SCALE
+#define ST_TAU_SCALE 1  // a unit's power of two from its extraction threshold (what stays in the image is <= tau) instead of its maximum:
+                        // one wave-wide reduction less per unit; the extracted elements take their own power of two (round 5)
+#endif
 #ifndef ST_NH
 #define ST_NH 1   // unit halves per consumer unit: 1 = a wave multiplies half chunks (32 image registers), 2 = whole chunks (64)
 #endif
@@ -363,6 +378,38 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // ---------------------------------------------------------------- 0. requests: activations first, then one unit of planes
     const u32 xg = l >> 4, xc = l & 3u, xtt = 4u * xg + ((l >> 2) & 3u);
     u32x4 xv[NPU], nv[NPU];
+    // RMSNorm with the sum of squares handed over by the producing launch (a.ssq_in: GQ_SSQ_SLOTS partial sums): ONE wave -- the
+    // first that builds no image, else the last -- adds them (4 x 16 bytes per lane, requested first thing) and leaves the scale in
+    // LDS in front of the launch barrier; the builders read it back behind the barrier while their activations are still in
+    // flight.  No exchange of per-wave sums (an LDS counter, a spin, a read-back) between the activations' arrival and the
+    // normalisation: measured upper bound 0.4 us of the wqkv launch (profiles/r05_stream_knockouts.txt).
+    const bool ho = PRO == PRO_RMSNORM && a.ssq_in != nullptr;
+    if (PRO == PRO_RMSNORM && ho && w == (npw < W ? npw : W - 1u)) {
+        // Requests, wait and sum inside ONE branch, from inline asm: left to the compiler, the wait for these loads lands at the
+        // join behind the branch as vmcnt(0) for EVERY wave -- the builders then drain their activation loads, the last waves
+        // their LUT rows, in front of the launch barrier (measured: barrier at 4,000 instead of 2,200 cycles).  The wave is an
+        // idle consumer at this point; its own first plane request waits for the round trip.
+        const u32x4 rss = make_rsrc4(a.ssq_in, (u32)GQ_SSQ_SLOTS * 4u);
+        u32x4 sqv[GQ_SSQ_SLOTS / 256];
+#pragma unroll
+        for (u32 i = 0; i < (u32)GQ_SSQ_SLOTS / 256u; i++) {
+            asm volatile("" : "=v"(sqv[i]));
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "+v"(sqv[i]) : "v"(16u * l), "s"(rss), "n"(1024 * i) : "memory");
+        }
+        wait_vm<0>();
+        float ss = 0.f;
+#pragma unroll
+        for (u32 i = 0; i < (u32)GQ_SSQ_SLOTS / 256u; i++) {
+            asm volatile("" : "+v"(sqv[i]));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 t = sqv[i][k];  // (through a scalar: a bit_cast of a vector element folds to element 0 with this hipcc)
+                ss += __builtin_bit_cast(float, t);
+            }
+        }
+        ss = wave_reduce<false>(ss);
+        if (l == 63u) lds_store(reinterpret_cast<u32 *>(red), __builtin_bit_cast(u32, 1.0f / sqrtf(ss / (float)a.Kx + a.eps)));
+    }
     if (is_pro) {
         const rsrc_t rsx = make_rsrc(a.x, (PRO == PRO_SILUMUL ? 4u : 2u) * a.Kx);
         const rsrc_t rsn = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * a.Kx);
@@ -461,7 +508,11 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // ---------------------------------------------------------------- 1. images of this wave's units
     if (is_pro) {
         float nscale = 1.f;
-        if constexpr (PRO == PRO_RMSNORM) {
+        if (PRO == PRO_RMSNORM && ho) {
+            nscale = __builtin_bit_cast(float, lds_load(reinterpret_cast<const u32 *>(red)));  // (published by the launch barrier)
+            stamp2(2);
+            stamp2(3);
+        } else if constexpr (PRO == PRO_RMSNORM) {
             float ss = 0.f;
             asm volatile("" : "+v"(xv[0]));
             stamp2(2);
@@ -471,6 +522,9 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
                 for (int k = 0; k < 4; k++)  // (requests outside the vector returned zeros)
                     ss = __builtin_amdgcn_fdot2(u2h2(xv[n][k]), u2h2(xv[n][k]), ss, false);
             ss = wave_reduce<false>(ss);
+#if ST_KO & 1
+            nscale = 1.0f / sqrtf(lane63(ss) * (float)npw / (float)a.K + a.eps);
+#else
             if (l == 63) {
                 reinterpret_cast<u32 *>(red)[w] = __builtin_bit_cast(u32, ss);
                 asm volatile("" ::: "memory");
@@ -486,6 +540,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
 #pragma unroll
             for (u32 i = 0; i < W; i++) tot += i < npw ? rp[i / 4u][i % 4u] : 0.f;
             nscale = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+#endif
         }
         stamp(7);
 #pragma unroll
@@ -516,23 +571,36 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
             // soon as the blocks of a unit differed -- the scale operand does not act per 32-element block the way that assumed),
             // mean magnitude -> extraction threshold; per DPP row the sum for the coef[0] term
             const u32 mxl = max((u32)mxp[0], (u32)mxp[1]);
-            const float xmax = lane63(wave_reduce<true>(h2f((uint16_t)mxl)));
             const float tot1 = lane63(wave_reduce<false>(s1));
             xsum = row_sum(xsum);
-            stamp2(4);
-            // x * 2^k with max|x| * 2^k in [2^14, 2^15) (plane_core.h piece_shift): k + 15 = 44 - (biased fp16 exponent of the maximum)
-            const u32 ke = (u32)(piece_shift(xmax) + 15);
-            const u32 k16 = ke << 10;  // fp16 bits of 2^k
             // threshold of the extraction as an fp16 bit pattern (rounded up): 64 x the unit's mean magnitude, + 1 % for the roundings
             u32 tau = 0x7C00u;
             {
                 const float tf = GQ_ST_HOT_T * 1.01f * tot1 * (1.0f / 512.0f);
                 if (tf < 65000.f) tau = (u32)__builtin_bit_cast(uint16_t, (_Float16)tf) + 1u;
             }
+#if ST_TAU_SCALE
+            // what stays in the image is <= tau: the unit's power of two from the threshold, no maximum over the wave (a unit whose
+            // threshold is not finite -- mean magnitude above 1000 -- takes its maximum)
+            float xmax = h2f((uint16_t)tau);
+            if (__builtin_expect(tau >= 0x7C00u, 0)) xmax = lane63(wave_reduce<true>(h2f((uint16_t)mxl)));
+            if (tot1 == 0.f) xmax = 0.f;
+#else
+            const float xmax = lane63(wave_reduce<true>(h2f((uint16_t)mxl)));
+#endif
+            stamp2(4);
+            // x * 2^k with max|x| * 2^k in [2^14, 2^15) (plane_core.h piece_shift): k + 15 = 44 - (biased fp16 exponent of the maximum)
+            const u32 ke = (u32)(piece_shift(xmax) + 15);
+            const u32 k16 = ke << 10;  // fp16 bits of 2^k
             HotEnt *hl = hotl + (size_t)q * HOTCAP;
             u32 nh = 0;
+            u32 k16h = k16, keh = ke;  // the extracted elements' own power of two (ST_TAU_SCALE: the image's comes from the threshold)
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(mxl > tau) != 0ull, 0)) {
                 // rare: the lane's elements above the threshold leave the image (ascending lane order: deterministic list)
+#if ST_TAU_SCALE
+                keh = (u32)(piece_shift(lane63(wave_reduce<true>(h2f((uint16_t)mxl)))) + 15);
+                k16h = keh << 10;
+#endif
 #pragma unroll
                 for (u32 k = 0; k < 4; k++)
 #pragma unroll
@@ -544,7 +612,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
                         const u32 idx = nh + (u32)__builtin_popcountll(bal & ((1ull << l) - 1ull));
                         if (hot && idx < HOTCAP) {
                             const u32 j = 2u * k + hf, sbit = 7u - j;  // plane bit s = 7 - j: b = s & 3, nibble i = 2 (3 - c) + (s >> 2)
-                            _Float16 rem = __builtin_bit_cast(_Float16, (uint16_t)xh) * __builtin_bit_cast(_Float16, (uint16_t)k16);
+                            _Float16 rem = __builtin_bit_cast(_Float16, (uint16_t)xh) * __builtin_bit_cast(_Float16, (uint16_t)k16h);
                             u32 pieces = 0;
 #pragma unroll
                             for (u32 p = 0; p < 4; p++) {
@@ -594,6 +662,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
             if (l == 0u) {
                 meta[META_W * q + 1u] = nh;
                 meta[META_W * q + 2u] = 142u - ke;  // E8M0 byte of 2^-k: 127 - k
+                meta[META_W * q + 3u] = 142u - keh;
             }
             lds_store(meta + META_W * q, 1u);  // (every lane stores the same flag behind its own image bytes)
         }
@@ -674,7 +743,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
 #pragma unroll
                 for (u32 b = 0; b < 4; b++) {
                     uint4 b0 = make_uint4(0, 0, 0, 0), b1 = make_uint4(0, 0, 0, 0);
-                    if (col < 4u) {
+                    if (col < 4u && !(ST_KO & 8)) {
                         b0 = *reinterpret_cast<const uint4 *>(src + b * 512u);
                         b1 = *reinterpret_cast<const uint4 *>(src + b * 512u + 64u);
                     }
@@ -690,21 +759,22 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
 #pragma unroll
             for (u32 p = 0; p < (u32)BITS; p++) asm volatile("" : "+v"(Ar[s][hh][p]));
         v4f acc[NP1];
-#pragma unroll
-        for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
 #if !(ST_XFLAGS & 1)
         {
 #pragma unroll
             for (u32 hh = 0; hh < (u32)NH; hh++) {
-                mfma_b<BITS, 0>(acc, Ar[s][hh], Bv[hh][0], sb[hh]);
+                if (hh == 0u) mfma_b<BITS, 0, true>(acc, Ar[s][hh], Bv[hh][0], sb[hh]);
+                else mfma_b<BITS, 0>(acc, Ar[s][hh], Bv[hh][0], sb[hh]);
                 mfma_b<BITS, 1>(acc, Ar[s][hh], Bv[hh][1], sb[hh]);
                 mfma_b<BITS, 2>(acc, Ar[s][hh], Bv[hh][2], sb[hh]);
                 mfma_b<BITS, 3>(acc, Ar[s][hh], Bv[hh][3], sb[hh]);
                 if (__builtin_expect(nhot[hh] != 0u, 0))
-                    hot_unit<BITS>(acc, Ar[s][hh], hotl + (size_t)(c_q * NH + hh) * HOTCAP, nhot[hh], sb[hh], col, kb);
+                    hot_unit<BITS>(acc, Ar[s][hh], hotl + (size_t)(c_q * NH + hh) * HOTCAP, nhot[hh], (int)meta[META_W * (c_q * NH + hh) + 3u], col, kb);
             }
         }
 #else  // experiment: no MFMA work
+#pragma unroll
+        for (int i = 0; i < NP1; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (u32 hh = 0; hh < (u32)NH; hh++) acc[0][0] += __builtin_bit_cast(float, Ar[s][hh][0][0] ^ Ar[s][hh][BITS - 1][3]);
 #endif
@@ -939,7 +1009,8 @@ struct KSplit {
     u32 KS, kslice;   // K = KS * kslice
 };
 int stream_launch(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits, const void *normw,
-                  float eps, const void *resid, int pro, int pairs, const StreamArgs *rope, hipStream_t stream, const KSplit *ksp = nullptr) {
+                  float eps, const void *resid, int pro, int pairs, const StreamArgs *rope, hipStream_t stream, const KSplit *ksp = nullptr,
+                  GqHandover *ho = nullptr) {
     if (bits < 2 || bits > gq_env_int("GQ_ST_MAXBITS", 4)) return GQ_ENOTSUP;
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
@@ -965,6 +1036,9 @@ int stream_launch(const void *x, void *out, const uint32_t *qweight, const void 
     a.K = Kk;
     a.Kx = K;
     a.part_out = ksp ? ksp->part : nullptr;
+    a.ssq_in = (ho && pro == PRO_RMSNORM && !((uintptr_t)ho->ssq_in & 15u) && gq_env_int("GQ_SSQ_HANDOVER", 1)) ? ho->ssq_in : nullptr;
+    if (ho) ho->ssq_consumed = a.ssq_in != nullptr;
+    if (ho && ho->dry) return GQ_OK;
     a.wpr_ld = K / 32u;
     a.RGB = c.RGB;
     a.img_off = c.img_off;
@@ -1069,9 +1143,9 @@ int gq_stream_gemv_ksplit(const void *x, void *out, const uint32_t *qweight, con
 
 // returns GQ_ENOTSUP when the shape is not served by this kernel (the caller goes on to ap_plane.hip / the exact kernels)
 int gq_stream_gemv_try(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t M, uint32_t N, uint32_t K, int bits,
-                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream) {
+                       const void *normw, float eps, const void *resid, int pro, int pairs, hipStream_t stream, GqHandover *ho) {
     if (M != 1u) return GQ_ENOTSUP;
-    return stream_launch(x, out, qweight, lut, N, K, bits, normw, eps, resid, pro, pairs, nullptr, stream);
+    return stream_launch(x, out, qweight, lut, N, K, bits, normw, eps, resid, pro, pairs, nullptr, stream, nullptr, ho);
 }
 
 // The fused q / k / v projection of a decode step with RoPE and the KV-cache write in its epilogue (include/gq_hip.h).
@@ -1086,6 +1160,13 @@ extern "C" int gq_anyprec_gemv_qkv_rope(const void *x, void *q_out, const uint32
                                         const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
                                         void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
                                         void *stream) {
+    return gq_anyprec_gemv_qkv_rope_ho(x, q_out, qweight, lut, N, K, bits, norm_weight, eps, pos, cos_table, sin_table, k_cache, v_cache, n_head,
+                                       n_kv_head, head_dim, max_seq, nullptr, stream);
+}
+extern "C" int gq_anyprec_gemv_qkv_rope_ho(const void *x, void *q_out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                                           const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
+                                           void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim,
+                                           uint32_t max_seq, const float *ssq_in, void *stream) {
     if (!x || !q_out || !qweight || !lut || !norm_weight || !pos || !cos_table || !sin_table || !k_cache || !v_cache)
         return gq_fail(GQ_EINVAL, "null pointer argument.");
     if (N != (n_head + 2u * n_kv_head) * head_dim) return gq_fail(GQ_EINVAL, "N must be (n_head + 2 n_kv_head) * head_dim.");
@@ -1101,6 +1182,8 @@ extern "C" int gq_anyprec_gemv_qkv_rope(const void *x, void *q_out, const uint32
     r.Hkv = n_kv_head;
     r.lhd = head_dim == 128u ? 7u : 6u;
     r.max_seq = max_seq;
-    const int rc = stream_launch(x, q_out, qweight, lut, N, K, bits, norm_weight, eps, nullptr, PRO_RMSNORM, 0, &r, (hipStream_t)stream);
+    GqHandover ho;
+    ho.ssq_in = ssq_in;
+    const int rc = stream_launch(x, q_out, qweight, lut, N, K, bits, norm_weight, eps, nullptr, PRO_RMSNORM, 0, &r, (hipStream_t)stream, nullptr, &ho);
     return rc == GQ_ENOTSUP ? gq_fail(GQ_ENOTSUP, "gq_anyprec_gemv_qkv_rope: shape / bit width not served.") : rc;
 }

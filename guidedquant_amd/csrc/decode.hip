@@ -44,6 +44,26 @@ __global__ void embed_kernel(const int *tok, const uint16_t *table, uint16_t *ou
         reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(table + (size_t)t * D)[i];
 }
 
+// the same with the statistics hand-over for the RMSNorm prologue of layer 0's first launch (include/gq_hip.h, GQ_SSQ_SLOTS): one
+// block, thread t leaves the sum of squares of the 16-byte units it copied in slot t
+__global__ void __launch_bounds__(GQ_SSQ_SLOTS) embed_ssq_kernel(const int *tok, const uint16_t *table, uint16_t *out, u32 D, u32 V, float *ssq) {
+    u32 t = (u32)tok[0];
+    if (t >= V) t = 0;
+    float acc = 0.f;
+    for (u32 i = threadIdx.x; i < D / 8u; i += (u32)GQ_SSQ_SLOTS) {
+        const uint4 v = reinterpret_cast<const uint4 *>(table + (size_t)t * D)[i];
+        gq_store_wt(reinterpret_cast<uint4 *>(out) + i, v);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float a = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] & 0xFFFFu)), b = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] >> 16));
+            acc += a * a;
+            acc += b * b;
+        }
+    }
+    gq_store_wt(ssq + threadIdx.x, acc);
+}
+
 // ------------------------------------------------------------------------------------------------ attention
 // One block per query head.  RoPE exactly as apply_rotary_pos_emb on fp16 tensors (inference/model.py:336-341):
 //   q_embed = (q * cos) + (rotate_half(q) * sin)   -- three fp16-rounded operations, cos/sin are fp16 tables
@@ -556,7 +576,8 @@ __global__ void __launch_bounds__(HD) attn_combine_kernel(const float *ws, uint1
 // reference's sampling is not reproducible across runs either: no fixed generator on the sampled path).
 // Two launches: per-block candidates, then a single-block merge.  Writes the next token AND feeds it back into
 // `tok_io` / increments `pos_io` so a captured graph advances by itself.
-constexpr int SAMP_BLOCKS = 128, SAMP_K = 32;
+constexpr int SAMP_BLOCKS = 128, SAMP_K = 64;  // (the kernels are built for 32 and for 64 candidates per block)
+static_assert(GQ_SSQ_SLOTS == 1024, "sample_stage2 writes one hand-over slot per thread");
 
 __device__ __forceinline__ u32 hash32(u32 x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -608,71 +629,100 @@ __device__ __forceinline__ int wave_compact(const KeyT (&key)[EPT], KeyT t, KeyT
     return base;
 }
 
-// stage 1: each of the 128 blocks selects the top-32 of its slice (<= 1024 logits, 4 per thread in registers)
-__global__ void __launch_bounds__(256) sample_stage1(const uint16_t *logits, u32 V, float *cand_val, int *cand_idx) {
-    __shared__ u32 surv[4 * SAMP_K];
+// Extras of the extended entry point (gq_sample_topk_ex, round 5); all optional:
+//   ban: device words {n (<= 4), until_pos, id0..id3} -- while *pos_io < until_pos the listed tokens cannot be drawn (HF's
+//        MinNewTokensLengthLogitsProcessor: EOS is suppressed until min_new_tokens are out);
+//   seq_out[*pos_io + 1] = the drawn token (the host reads whole chunks of the sequence instead of cloning one word per step);
+//   emb_table / x_out / ssq_out: the embedding row of the drawn token -> the hidden-state buffer of the NEXT step (+ its statistics
+//        hand-over, gq_embed_lookup_ho) -- the step's graph then starts at layer 0's first GEMV, one launch less per token.
+struct SampleEx {
+    const int *ban;
+    int *seq_out;
+    u32 seq_cap;
+    const uint16_t *emb_table;
+    uint16_t *x_out;
+    u32 dim, vocab;
+    float *ssq_out;
+};
+
+// stage 1: each of the 128 blocks selects the top KM of its slice (<= 1024 logits, 4 per thread in registers); KM = 32 or 64
+template <int KM>
+__global__ void __launch_bounds__(256) sample_stage1(const uint16_t *logits, u32 V, float *cand_val, int *cand_idx, const int *ban, const int *pos_io) {
+    __shared__ u32 surv[4 * KM];
+    __shared__ u32 fin[KM];
     const u32 per = (V + SAMP_BLOCKS - 1) / SAMP_BLOCKS;  // <= 1024
     const u32 lo = blockIdx.x * per, hi = min(lo + per, V);
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    int nban = 0, bid[4] = {-1, -1, -1, -1};
+    if (ban) {  // (wave-uniform scalar loads)
+        nban = ban[0];
+        if (pos_io && pos_io[0] >= ban[1]) nban = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) bid[i] = i < nban ? ban[2 + i] : -1;
+    }
     u32 key[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const u32 li = tid * 4u + (u32)e, gi = lo + li;
         // key = (order-preserving image of the fp16 logit, position): unique, and both parts are recovered from it
-        key[e] = gi < hi ? ((ordered_key16(logits[gi]) << 10) | (1023u - li)) : 0u;
+        const bool banned = (int)gi == bid[0] || (int)gi == bid[1] || (int)gi == bid[2] || (int)gi == bid[3];
+        key[e] = (gi < hi && !banned) ? ((ordered_key16(logits[gi]) << 10) | (1023u - li)) : 0u;
     }
-    if (l < SAMP_K / 2) reinterpret_cast<unsigned long long *>(surv + w * SAMP_K)[l] = 0ull;  // (a wave's LDS ops are in order)
-    const u32 t = wave_select_threshold<4, u32>(key, 26, 10, SAMP_K);
-    wave_compact<4, u32>(key, t, surv + w * SAMP_K, SAMP_K, l);
+    if (l < KM / 2) reinterpret_cast<unsigned long long *>(surv + w * KM)[l] = 0ull;  // (a wave's LDS ops are in order)
+    const u32 t = wave_select_threshold<4, u32>(key, 26, 10, KM);
+    wave_compact<4, u32>(key, t, surv + w * KM, KM, l);
     __syncthreads();
-    if (w == 0) {  // top K of the 4 * K survivors
-        u32 k2[2] = {surv[l], surv[64u + l]};
-        const u32 t2 = wave_select_threshold<2, u32>(k2, 26, 10, SAMP_K);
-        __shared__ u32 fin[SAMP_K];
-        if (l < SAMP_K) fin[l] = 0u;
-        const int n = wave_compact<2, u32>(k2, t2, fin, SAMP_K, l);
-        if (l < SAMP_K) {
+    if (w == 0) {  // top KM of the 4 * KM survivors
+        u32 k2[KM / 16];
+#pragma unroll
+        for (int e = 0; e < KM / 16; e++) k2[e] = surv[(u32)e * 64u + l];
+        const u32 t2 = wave_select_threshold<KM / 16, u32>(k2, 26, 10, KM);
+        if (l < KM) fin[l] = 0u;
+        const int n = wave_compact<KM / 16, u32>(k2, t2, fin, KM, l);
+        if (l < KM) {
             const u32 k = fin[l];
             const bool ok = (int)l < n && k != 0u;
             const u32 li = 1023u - (k & 1023u);
-            cand_val[blockIdx.x * SAMP_K + l] = ok ? h2f(unordered_key16(k >> 10)) : -3.0e38f;  // slice shorter than K: padded
-            cand_idx[blockIdx.x * SAMP_K + l] = ok ? (int)(lo + li) : -1;
+            cand_val[blockIdx.x * KM + l] = ok ? h2f(unordered_key16(k >> 10)) : -3.0e38f;  // slice shorter than K: padded
+            cand_idx[blockIdx.x * KM + l] = ok ? (int)(lo + li) : -1;
         }
     }
 }
 
-// stage 2: one block, 4096 candidates (4 per thread), select the global top-k, then the exponential-race draw
+// stage 2: one block, 128 * KM candidates (KM / 8 per thread), select the global top-k, then the exponential-race draw
+template <int KM>
 __global__ void __launch_bounds__(1024) sample_stage2(const float *cand_val, const int *cand_idx, int top_k, float temperature,
-                                                      u32 seed, int *counter, int *tok_io, int *pos_io, int *next_tok) {
-    __shared__ float selv[SAMP_K];
-    __shared__ int seli[SAMP_K];
-    __shared__ unsigned long long surv[16 * SAMP_K];
-    __shared__ unsigned long long fin[SAMP_K];
-    __shared__ int slot;
+                                                      u32 seed, int *counter, int *tok_io, int *pos_io, int *next_tok, SampleEx ex) {
+    constexpr int EPT = KM / 8;  // candidates per thread
+    __shared__ float selv[KM];
+    __shared__ int seli[KM];
+    __shared__ unsigned long long surv[16 * KM];
+    __shared__ unsigned long long fin[KM];
+    __shared__ int slot, chosen;
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
-    unsigned long long key[4];
+    unsigned long long key[EPT];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const u32 c = tid * 4u + (u32)e;
+    for (int e = 0; e < EPT; e++) {
+        const u32 c = tid * (u32)EPT + (u32)e;
         const float v = cand_val[c];
         const int id = cand_idx[c];
         const uint16_t hb = __builtin_bit_cast(uint16_t, (h16)v);  // candidates are fp16 values: exact
         key[e] = id >= 0 ? (((unsigned long long)ordered_key16(hb) << 17) | (unsigned long long)(131071u - (u32)id)) : 0ull;
     }
-    const int K = top_k < 1 ? 1 : (top_k > SAMP_K ? SAMP_K : top_k);
-    if (l < SAMP_K) surv[w * SAMP_K + l] = 0ull;
-    const unsigned long long t = wave_select_threshold<4, unsigned long long>(key, 33, 17, K);
-    wave_compact<4, unsigned long long>(key, t, surv + w * SAMP_K, SAMP_K, l);
+    const int K = top_k < 1 ? 1 : (top_k > KM ? KM : top_k);
+    if (l < KM) surv[w * KM + l] = 0ull;
+    const unsigned long long t = wave_select_threshold<EPT, unsigned long long>(key, 33, 17, K);
+    wave_compact<EPT, unsigned long long>(key, t, surv + w * KM, KM, l);
     __syncthreads();
     if (w == 0) {
-        unsigned long long k8[8];
+        unsigned long long k8[KM / 4];
 #pragma unroll
-        for (int e = 0; e < 8; e++) k8[e] = surv[(u32)e * 64u + l];
-        const unsigned long long t2 = wave_select_threshold<8, unsigned long long>(k8, 33, 17, K);
-        if (l < SAMP_K) fin[l] = 0ull;
-        const int n2 = wave_compact<8, unsigned long long>(k8, t2, fin, SAMP_K, l);
+        for (int e = 0; e < KM / 4; e++) k8[e] = surv[(u32)e * 64u + l];
+        const unsigned long long t2 = wave_select_threshold<KM / 4, unsigned long long>(k8, 33, 17, K);
+        if (l < KM) fin[l] = 0ull;
+        const int n2 = wave_compact<KM / 4, unsigned long long>(k8, t2, fin, KM, l);
         if (l == 0) slot = n2;
-        if (l < SAMP_K) {
+        if (l < KM) {
             const unsigned long long k = fin[l];
             selv[l] = h2f(unordered_key16((u32)(k >> 17)));
             seli[l] = (int)(131071u - (u32)(k & 131071ull));
@@ -702,8 +752,29 @@ __global__ void __launch_bounds__(1024) sample_stage2(const float *cand_val, con
             next_tok[0] = tokc;
             counter[0] = (int)(ctr + 1u);
             if (tok_io) tok_io[0] = tokc;
-            if (pos_io) pos_io[0] = pos_io[0] + 1;
+            const int p = pos_io ? pos_io[0] : 0;
+            if (ex.seq_out && (u32)(p + 1) < ex.seq_cap) ex.seq_out[p + 1] = tokc;
+            if (pos_io) pos_io[0] = p + 1;
+            chosen = tokc;
         }
+    }
+    if (ex.x_out) {  // the next step's hidden state: tok_embeddings[token] (+ the statistics hand-over for layer 0's RMSNorm)
+        __syncthreads();
+        u32 tk = (u32)chosen;
+        if (tk >= ex.vocab) tk = 0;
+        float acc = 0.f;
+        for (u32 i = tid; i < ex.dim / 8u; i += 1024u) {
+            const uint4 v = reinterpret_cast<const uint4 *>(ex.emb_table + (size_t)tk * ex.dim)[i];
+            gq_store_wt(reinterpret_cast<uint4 *>(ex.x_out) + i, v);
+            const u32 wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float a = (float)__builtin_bit_cast(_Float16, (uint16_t)(wd[k] & 0xFFFFu)), b = (float)__builtin_bit_cast(_Float16, (uint16_t)(wd[k] >> 16));
+                acc += a * a;
+                acc += b * b;
+            }
+        }
+        if (ex.ssq_out) gq_store_wt(ex.ssq_out + tid, acc);  // (1024 threads = GQ_SSQ_SLOTS)
     }
 }
 
@@ -793,6 +864,15 @@ extern "C" int gq_embed_lookup(const int *token, const void *table, void *out, u
     if (dim % 8u) return gq_fail(GQ_EINVAL, "embedding dim must be a multiple of 8.");
     hipLaunchKernelGGL(embed_kernel, dim3((dim / 8u + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, token,
                        (const uint16_t *)table, (uint16_t *)out, dim, vocab);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+extern "C" int gq_embed_lookup_ho(const int *token, const void *table, void *out, uint32_t dim, uint32_t vocab, float *ssq_out, void *stream) {
+    if (!ssq_out) return gq_embed_lookup(token, table, out, dim, vocab, stream);
+    if (!token || !table || !out) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (dim % 8u) return gq_fail(GQ_EINVAL, "embedding dim must be a multiple of 8.");
+    hipLaunchKernelGGL(embed_ssq_kernel, dim3(1), dim3(GQ_SSQ_SLOTS), 0, (hipStream_t)stream, token, (const uint16_t *)table, (uint16_t *)out, dim,
+                       vocab, ssq_out);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }
@@ -932,15 +1012,48 @@ extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32
     return GQ_OK;
 }
 
-extern "C" int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
-                              float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, void *stream) {
+namespace {
+int sample_launch(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter, float *work_val, int *work_idx,
+                  int *tok_io, int *pos_io, int *next_tok, const SampleEx &ex, void *stream) {
     if (!logits || !counter || !work_val || !work_idx || !next_tok) return gq_fail(GQ_EINVAL, "null pointer argument.");
-    if (top_k > SAMP_K) return gq_fail(GQ_ENOTSUP, "top_k > 32 is not supported by the fused sampler.");
+    if (top_k > SAMP_K) return gq_fail(GQ_ENOTSUP, "top_k > 64 is not supported by the fused sampler.");
     const u32 per = (vocab + SAMP_BLOCKS - 1) / SAMP_BLOCKS;
     if (per > 1024u || vocab > 131072u) return gq_fail(GQ_ENOTSUP, "vocab too large for the fused sampler (<= 131072).");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sample_stage1, dim3(SAMP_BLOCKS), dim3(256), 0, s, (const uint16_t *)logits, vocab, work_val, work_idx);
-    hipLaunchKernelGGL(sample_stage2, dim3(1), dim3(1024), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok);
+    if (top_k <= 32) {
+        hipLaunchKernelGGL(sample_stage1<32>, dim3(SAMP_BLOCKS), dim3(256), 0, s, (const uint16_t *)logits, vocab, work_val, work_idx, ex.ban, pos_io);
+        hipLaunchKernelGGL(sample_stage2<32>, dim3(1), dim3(1024), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok, ex);
+    } else {
+        hipLaunchKernelGGL(sample_stage1<64>, dim3(SAMP_BLOCKS), dim3(256), 0, s, (const uint16_t *)logits, vocab, work_val, work_idx, ex.ban, pos_io);
+        hipLaunchKernelGGL(sample_stage2<64>, dim3(1), dim3(1024), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok, ex);
+    }
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
+}
+}  // namespace
+
+extern "C" int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
+                              float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, void *stream) {
+    if (top_k > 32) return gq_fail(GQ_ENOTSUP, "top_k > 32 is not supported by gq_sample_topk (work buffers of 128 * 32: gq_sample_topk_ex takes 64).");
+    return sample_launch(logits, vocab, top_k, temperature, seed, counter, work_val, work_idx, tok_io, pos_io, next_tok, SampleEx{}, stream);
+}
+
+extern "C" int gq_sample_topk_ex(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
+                                 float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, const int *ban, int *seq_out,
+                                 uint32_t seq_cap, const void *embed_table, void *x_out, uint32_t dim, float *ssq_out, void *stream) {
+    SampleEx ex{};
+    ex.ban = ban;
+    ex.seq_out = seq_out;
+    ex.seq_cap = seq_cap;
+    if (x_out) {
+        if (!embed_table || dim % 8u) return gq_fail(GQ_EINVAL, "x_out needs the embedding table and dim % 8 == 0.");
+        ex.emb_table = (const uint16_t *)embed_table;
+        ex.x_out = (uint16_t *)x_out;
+        ex.dim = dim;
+        ex.vocab = vocab;
+        ex.ssq_out = ssq_out;
+    } else if (ssq_out) {
+        return gq_fail(GQ_EINVAL, "ssq_out without x_out.");
+    }
+    return sample_launch(logits, vocab, top_k, temperature, seed, counter, work_val, work_idx, tok_io, pos_io, next_tok, ex, stream);
 }

@@ -11,6 +11,16 @@ int gq_fail_hip(hipError_t e, const char *where);  // records the HIP error stri
 int gq_env_int(const char *name, int dflt);        // cached getenv -> int (tuning knobs)
 int gq_cu_count();                                 // compute units of the CURRENT device (cached per device)
 
+// Statistics hand-over between the launches of a decode step (include/gq_hip.h: gq_anyprec_gemv_fused_ho): what the caller asked for,
+// and whether the GEMV kernel that ran wrote the partial sums itself (else the dispatcher adds gq_ssq_rows)
+struct GqHandover {
+    const float *ssq_in = nullptr;
+    float *ssq_out = nullptr;
+    bool ssq_written = false;   // the GEMV kernel writes ssq_out in its epilogue
+    bool ssq_consumed = false;  // the GEMV kernel's RMSNorm prologue reads ssq_in
+    bool dry = false;           // plan only (gq_anyprec_handover_plan): the launchers record the two flags and return without launching
+};
+
 // One-time per-DEVICE actions (function attributes such as the > 64 KiB dynamic-LDS opt-in are per device: a process that
 // drives several GPUs -- reference-style sequential sharding, device_map -- must repeat them on each one).
 struct GqPerDeviceOnce {

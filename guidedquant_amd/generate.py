@@ -68,21 +68,30 @@ class DecodeGraph:
     """One captured hipGraph of `decode_one_token` with static token / position / output tensors
     (the manual-graph path of generate.py:95-113)."""
 
-    def __init__(self, model: Transformer, device, native_sampling=False, seed=1234, **sampling_kwargs):
-        """native_sampling: draw the token with the fused HIP sampler (gq_sample_topk: same distribution as `sample`,
-        own counter-based RNG, top_k <= 32) and feed token / position back inside the graph; `next_prob` is then
-        not produced.  Default False = the reference's torch sampling ops, captured in the graph."""
+    def __init__(self, model: Transformer, device, native_sampling=False, seed=1234, fold_embed=False, seq_capacity=0, **sampling_kwargs):
+        """native_sampling: draw the token with the fused HIP sampler (gq_sample_topk_ex: same distribution as `sample`,
+        own counter-based RNG, top_k <= 64) and feed token / position back inside the graph; `next_prob` is then
+        not produced.  Default False = the reference's torch sampling ops, captured in the graph.
+        fold_embed (native sampling only): the sampler's last block also writes the NEXT step's hidden state (the embedding row of
+        the token it drew, model.py:121-130) and its hand-over statistics, so the captured step starts at layer 0's first GEMV -- one
+        launch less per token.  The token of the first step must then be set through `set_token` (which runs the lookup once);
+        writing `self.tok` directly is only valid without the fold.
+        seq_capacity > 0: the sampler also stores every token at `self.seq[pos + 1]` (int32 [seq_capacity]); `self.ban` (int32
+        {n, until_pos, id0..id3}) lists tokens that cannot be drawn while pos < until_pos (HF's min_new_tokens on EOS)."""
         self.model = model
-        self.native_sampling = bool(native_sampling) and model.native_ready() and (sampling_kwargs.get("top_k") or 0) <= 32 \
+        self.native_sampling = bool(native_sampling) and model.native_ready() and (sampling_kwargs.get("top_k") or 0) <= 64 \
             and sampling_kwargs.get("top_k") is not None
+        self.fold_embed = bool(fold_embed) and self.native_sampling
         self.seed = seed
         self.rng_counter = torch.zeros((1, ), dtype=torch.int32, device=device)
-        self.work_val = torch.zeros((128 * 32, ), dtype=torch.float32, device=device)
-        self.work_idx = torch.zeros((128 * 32, ), dtype=torch.int32, device=device)
+        self.work_val = torch.zeros((128 * 64, ), dtype=torch.float32, device=device)
+        self.work_idx = torch.zeros((128 * 64, ), dtype=torch.int32, device=device)
         self.tok = torch.zeros((1, 1), dtype=torch.int32, device=device)
         self.pos = torch.zeros((1, ), dtype=torch.int32, device=device)
         self.next_tok = torch.zeros((1, 1), dtype=torch.int32, device=device)
         self.next_prob = torch.zeros((1, model.config.vocab_size), dtype=torch.float32, device=device)
+        self.seq = torch.zeros((int(seq_capacity), ), dtype=torch.int32, device=device) if seq_capacity else None
+        self.ban = torch.zeros((6, ), dtype=torch.int32, device=device)
         self.sampling_kwargs = sampling_kwargs
         # warm up on a side stream (lazy kernel attributes, allocator), then capture
         s = torch.cuda.Stream()
@@ -117,16 +126,50 @@ class DecodeGraph:
             raise RuntimeError("the captured decode graph is bound to caches / buffers that have since been re-allocated "
                                "(setup_caches with a longer max_seq_length?): capture a new DecodeGraph")
 
+    def set_token(self, tok, pos):
+        """the token and position of the next step (device tensors or ints); with the embedding folded into the sampler, also the
+        hidden state of that token"""
+        if torch.is_tensor(tok):
+            self.tok.copy_(tok.view(1, 1))
+        else:
+            self.tok.fill_(int(tok))
+        if torch.is_tensor(pos):
+            self.pos.copy_(pos.view(1))
+        else:
+            self.pos.fill_(int(pos))
+        if self.fold_embed:
+            m = self.model
+            with torch.cuda.device(m.output.weight.device):
+                st = m._native_state()
+                m.native_embed(self.tok.view(1), st["x"], st["ssq"] if self._ho0() else None)
+
+    def _ho0(self):
+        m = self.model
+        return m._native_kind() == "ap" and bool(m._handover_plan(m.layers[0])["qkv_in"])
+
     def _step(self):
         if self.native_sampling:
             from . import _lib
-            logits = self.model.decode_native(self.tok.view(1), self.pos.view(1))
+            m = self.model
+            if self.fold_embed:
+                with torch.cuda.device(m.output.weight.device):
+                    st = m._native_state()
+                    ho0 = self._ho0()
+                    m.native_layers(st["x"], self.pos.view(1), 0, len(m.layers), ssq_ready=ho0)
+                    logits = m.native_head(st["x"])
+                emb, xo, so = m.tok_embeddings.weight.data_ptr(), st["x"].data_ptr(), (st["ssq"].data_ptr() if ho0 else None)
+            else:
+                logits = m.decode_native(self.tok.view(1), self.pos.view(1))
+                emb = xo = so = None
             kw = self.sampling_kwargs
-            _lib.check(_lib.lib().gq_sample_topk(logits.data_ptr(), self.model.config.vocab_size, int(kw["top_k"]),
-                                                float(kw.get("temperature", 1.0)), int(self.seed), self.rng_counter.data_ptr(),
-                                                self.work_val.data_ptr(), self.work_idx.data_ptr(), self.tok.data_ptr(),
-                                                self.pos.data_ptr(), self.next_tok.data_ptr(), _lib.current_stream_ptr()),
-                       "gq_sample_topk")
+            _lib.check(_lib.lib().gq_sample_topk_ex(logits.data_ptr(), m.config.vocab_size, int(kw["top_k"]),
+                                                   float(kw.get("temperature", 1.0)), int(self.seed), self.rng_counter.data_ptr(),
+                                                   self.work_val.data_ptr(), self.work_idx.data_ptr(), self.tok.data_ptr(),
+                                                   self.pos.data_ptr(), self.next_tok.data_ptr(), self.ban.data_ptr(),
+                                                   self.seq.data_ptr() if self.seq is not None else None,
+                                                   self.seq.numel() if self.seq is not None else 0, emb, xo, m.config.dim, so,
+                                                   _lib.current_stream_ptr()),
+                       "gq_sample_topk_ex")
             return
         t, p = decode_one_token(self.model, self.tok, self.pos, **self.sampling_kwargs)
         self.next_tok.copy_(t)
@@ -151,8 +194,7 @@ def decode_n_tokens(model: Transformer, cur_token: torch.Tensor, input_pos: torc
     new_tokens, new_probs = [], []
     if use_graph:
         g = graph or DecodeGraph(model, cur_token.device, **sampling_kwargs)
-        g.tok.copy_(cur_token.view(1, 1))
-        g.pos.copy_(input_pos.view(1))
+        g.set_token(cur_token, input_pos)
         for _ in range(num_new_tokens):
             g.step()
             new_tokens.append(g.next_tok.clone())

@@ -427,6 +427,7 @@ class Transformer(nn.Module):
             self._native = dict(
                 x=torch.zeros(c.dim, **f16), h=torch.zeros(c.dim, **f16), y=torch.zeros(c.dim, **f16),
                 qkv=torch.zeros((c.n_head + 2 * c.n_local_heads) * c.head_dim, **f16),
+                ssq=torch.zeros(_lib.SSQ_SLOTS, dtype=torch.float32, device=dev),  # statistics hand-over slots (gq_hip.h GQ_SSQ_SLOTS)
                 gu=torch.zeros(2 * c.intermediate_size, **f16), logits=torch.zeros(1, 1, c.vocab_size, **f16))
             # long caches: split-KV attention (gq_attn_decode_split), n_split blocks per head + a combine launch; a context of
             # up to 256 positions is still finished by one block per head at run time
@@ -714,13 +715,34 @@ class Transformer(nn.Module):
         if pending is not None:
             run(pending)
 
-    def native_embed(self, tok: Tensor, x: Tensor):
-        _lib.check(_lib.lib().gq_embed_lookup(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), self.config.dim,
-                                              self.config.vocab_size, _lib.current_stream_ptr()), "gq_embed_lookup")
+    def native_embed(self, tok: Tensor, x: Tensor, ssq: Optional[Tensor] = None):
+        """x = tok_embeddings[tok]; with `ssq` (the hand-over slots of _native_state) also the statistics of x for layer 0's RMSNorm"""
+        _lib.check(_lib.lib().gq_embed_lookup_ho(tok.data_ptr(), self.tok_embeddings.weight.data_ptr(), x.data_ptr(), self.config.dim,
+                                                 self.config.vocab_size, ssq.data_ptr() if ssq is not None else None,
+                                                 _lib.current_stream_ptr()), "gq_embed_lookup")
 
-    def native_layers(self, x: Tensor, pos: Tensor, l0: int, l1: int, slot: int = 0):
+    def _handover_plan(self, blk):
+        """Statistics hand-over (include/gq_hip.h, round 5) on the two RMSNorm edges of a layer -- (w2 or the embedding) -> wqkv and
+        wo -> w1w3: the producer's residual epilogue leaves the partial sums of squares of the hidden state it writes, the consumer's
+        RMSNorm prologue adds them instead of exchanging per-wave sums.  An edge is used only when BOTH ends have the form (the plan is
+        the library's own dispatch run dry): 8B-class 2-bit models.  OFF by default (GQ_SSQ_HANDOVER=1 turns it on): measured on the
+        8B decode it LOSES 1.4 % (855 vs 867 tokens/s, profiles/r05_handover.txt) -- the partial sums come out of memory no earlier
+        than the activations themselves, the wave that adds them holds the launch barrier ~700 cycles, and the producers pay 0.1 us."""
+        # (not cached: the answer follows gq_set_ap_mode / the environment like the dispatch itself; 4 host calls per layer, paid by
+        # eager steps and graph captures only)
+        L = _lib.lib()
+        c, at, ff = self.config, blk.attention, blk.feed_forward
+        on = os.environ.get("GQ_SSQ_HANDOVER", "0") != "0"
+        qkv_in = on and bool(L.gq_anyprec_handover_plan(at.wqkv.out_features, c.dim, at.wqkv.bitwidth, 1, 0) & 1)
+        w13_in = on and bool(L.gq_anyprec_handover_plan(2 * c.intermediate_size, c.dim, ff.w1w3.bitwidth, 1, 4) & 1)
+        wo_out = bool(L.gq_anyprec_handover_plan(c.dim, c.dim, at.wo.bitwidth, 0, 1) & 2)
+        w2_out = bool(L.gq_anyprec_handover_plan(c.dim, c.intermediate_size, ff.w2.bitwidth, 0, 1) & 2)
+        return dict(qkv_in=qkv_in, w13=w13_in and wo_out, w2_out=w2_out)
+
+    def native_layers(self, x: Tensor, pos: Tensor, l0: int, l1: int, slot: int = 0, ssq_ready: bool = False):
         """layers [l0, l1) of one decode step, in place on the hidden state `x` (fp16 [dim]); `slot` = batch index of
-        the KV caches to use (layer-pipelined decode keeps one sequence per slot)."""
+        the KV caches to use (layer-pipelined decode keeps one sequence per slot).  ssq_ready: the hand-over slots hold the
+        statistics of `x` (native_embed(..., ssq) ran on it)."""
         if self._native_kind() == "qtip":
             return self._native_layers_qtip(x, pos, l0, l1, slot)
         L = _lib.lib()
@@ -737,17 +759,24 @@ class Transformer(nn.Module):
         ck = _lib.check
         scale = 1.0 / math.sqrt(c.head_dim)
         kv_stride = c.n_local_heads * self.max_seq_length * c.head_dim * 2  # bytes per batch slot
+        ssq = b["ssq"].data_ptr()
+        x_has_ssq = ssq_ready  # the slots hold the statistics of the current x
         for li, blk in enumerate(self.layers[l0:l1]):
             at, ff = blk.attention, blk.feed_forward
             kc, vc = at.kv_cache.k_cache.data_ptr() + slot * kv_stride, at.kv_cache.v_cache.data_ptr() + slot * kv_stride
             ws = b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None
+            ho = self._handover_plan(blk)
+            nxt = self.layers[l0 + li + 1] if l0 + li + 1 < len(self.layers) else None
+            # (w2 writes the statistics only when the NEXT layer's wqkv reads them: the last layer feeds the lm_head's own norm)
+            w2_ssq = ssq if (pairs and ho["w2_out"] and nxt is not None and l0 + li + 1 < l1 and self._handover_plan(nxt)["qkv_in"]) else None
             # RoPE + KV-cache write in the epilogue of the wqkv GEMV, attention without them, where the library serves the layer's
             # wqkv that way (fast mode, 2-bit, K <= 4096: csrc/ap_stream.hip); else the two launches of rounds 1-3
             if L.gq_anyprec_qkv_rope_supported(at.wqkv.out_features, c.dim, at.wqkv.bitwidth, c.head_dim):
-                ck(L.gq_anyprec_gemv_qkv_rope(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
-                                              at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
-                                              c.norm_eps, pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), kc, vc,
-                                              c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, st), "wqkv+rope")
+                ck(L.gq_anyprec_gemv_qkv_rope_ho(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
+                                                 at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
+                                                 c.norm_eps, pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), kc, vc,
+                                                 c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length,
+                                                 ssq if (x_has_ssq and ho["qkv_in"]) else None, st), "wqkv+rope")
                 ck(L.gq_attn_decode_roped(qkv.data_ptr(), pos.data_ptr(), kc, vc, y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim,
                                           self.max_seq_length, scale, b["attn_split"], ws, st), "attn")
             else:
@@ -757,16 +786,22 @@ class Transformer(nn.Module):
                 ck(L.gq_attn_decode_split(qkv.data_ptr(), pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), kc, vc,
                                           y.data_ptr(), c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, scale, b["attn_split"],
                                           ws, st), "attn")
+            x_has_ssq = False
+            if pairs:
+                w13 = ssq if ho["w13"] else None
+                ck(L.gq_anyprec_gemv_fused_ho(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
+                                              at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, None, 0, None, w13, st), "wo")
+                ck(L.gq_anyprec_gemv_fused_ho(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(), 2 * c.intermediate_size,
+                                              c.dim, ff.w1w3.bitwidth, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 4,
+                                              None, 0, w13, None, st), "w1w3")
+                ck(L.gq_anyprec_gemv_fused_ho(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,
+                                              c.intermediate_size, ff.w2.bitwidth, None, 0.0, h.data_ptr(), 1,
+                                              apws.data_ptr() if apws is not None else None, apws.numel() * 4 if apws is not None else 0,
+                                              None, w2_ssq, st), "w2")
+                x_has_ssq = w2_ssq is not None
+                continue
             ck(L.gq_anyprec_gemv_fused(y.data_ptr(), h.data_ptr(), at.wo.qweight.data_ptr(), at.wo.lut.data_ptr(), c.dim, c.dim,
                                        at.wo.bitwidth, None, 0.0, x.data_ptr(), 1, st), "wo")
-            if pairs:
-                ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(), 2 * c.intermediate_size, c.dim,
-                                           ff.w1w3.bitwidth, blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 4, st),
-                   "w1w3")
-                ck(L.gq_anyprec_gemv_fused_ws(gu.data_ptr(), x.data_ptr(), ff.w2.qweight.data_ptr(), ff.w2.lut.data_ptr(), c.dim,
-                                              c.intermediate_size, ff.w2.bitwidth, None, 0.0, h.data_ptr(), 1,
-                                              apws.data_ptr() if apws is not None else None, apws.numel() * 4 if apws is not None else 0, st), "w2")
-                continue
             ck(L.gq_anyprec_gemv_fused(h.data_ptr(), gu.data_ptr(), ff.w1w3.qweight.data_ptr(), ff.w1w3.lut.data_ptr(),
                                        2 * c.intermediate_size, c.dim, ff.w1w3.bitwidth,
                                        blk.post_attention_layernorm.weight.data_ptr(), c.norm_eps, None, 0, st), "w1w3")
@@ -836,7 +871,9 @@ class Transformer(nn.Module):
         (a persistent buffer, like the quantized linears' outputs).  Enqueues on the current stream only."""
         assert tok.dtype == torch.int32 and pos.dtype == torch.int32 and tok.is_cuda and pos.is_cuda
         with torch.cuda.device(self.output.weight.device):  # (launches go to the model's device's current stream)
-            x = self._native_state()["x"]
-            self.native_embed(tok, x)
-            self.native_layers(x, pos, 0, len(self.layers))
+            st = self._native_state()
+            x = st["x"]
+            ho0 = self._native_kind() == "ap" and self._handover_plan(self.layers[0])["qkv_in"]
+            self.native_embed(tok, x, st["ssq"] if ho0 else None)
+            self.native_layers(x, pos, 0, len(self.layers), ssq_ready=bool(ho0))
             return self.native_head(x)

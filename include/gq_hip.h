@@ -337,11 +337,38 @@ int gq_anyprec_gemv_fused_ws(const void *x, void *out, const uint32_t *qweight, 
                              uint32_t epilogue, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Round 5: statistics hand-over between the launches of a decode step.  The hidden state an RMSNorm prologue normalises was written
+ * by the previous launch (the residual epilogue of wo / w2, or the embedding lookup): that launch leaves the partial sums of squares
+ * of the fp16 values it stored next to them, and the consumer adds GQ_SSQ_SLOTS floats instead of exchanging per-wave sums through
+ * LDS behind a counter between the activations' arrival and the normalisation (reference rounding points unchanged:
+ * inference/model.py:281-292 -- fp32 mean of squares, rsqrt, fp16 rounding, fp16 multiply; only the fp32 summation ORDER differs,
+ * as it already did from torch's).
+ *   ssq_out  float [GQ_SSQ_SLOTS], 16-byte aligned, or NULL: the launch writes ALL slots (partial sums of squares of its fp16 outputs;
+ *            their total is the vector's sum of squares).  Plain / residual epilogue only.  Kernels without the in-epilogue form are
+ *            followed by one small launch (gq_ssq_rows) -- the result is there either way.
+ *   ssq_in   the slots written by the launch that produced x (the caller's contract), or NULL.  Used by the RMSNorm prologues that
+ *            have the hand-over form (the stream kernel, csrc/ap_stream.hip); ignored elsewhere.  GQ_SSQ_HANDOVER=0 ignores it.
+ * gq_anyprec_gemv_fused_ho = gq_anyprec_gemv_fused_ws + the two pointers; gq_anyprec_gemv_qkv_rope_ho, gq_embed_lookup_ho likewise
+ * (declared below); gq_ssq_rows: the statistics of any fp16 vector.
+ */
+#define GQ_SSQ_SLOTS 1024
+int gq_anyprec_gemv_fused_ho(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N,
+                             uint32_t K, int bits, const void *norm_weight, float eps, const void *residual,
+                             uint32_t epilogue, void *workspace, size_t workspace_bytes, const float *ssq_in, float *ssq_out,
+                             void *stream);
+int gq_ssq_rows(const void *x, uint32_t n, float *ssq_out, void *stream);
+/* Plan: which form the launch gq_anyprec_gemv_fused_ho(N, K, bits, norm_weight != NULL, epilogue) would take under the current mode /
+ * environment -- bit 0: its RMSNorm prologue reads ssq_in; bit 1: its epilogue writes ssq_out itself (no extra launch).  A decode step
+ * passes the pointers only where both ends of an edge are free (guidedquant_amd/model.py::native_layers). */
+int gq_anyprec_handover_plan(uint32_t N, uint32_t K, int bits, int has_norm, uint32_t epilogue);
+
+/*
  * The non-quantized pieces of one bs=1 decode step (inference/model.py:121-130,151-166,206-241).  Token id and
  * position are read from DEVICE memory so a captured hipGraph can be replayed per token.
  */
 /* x = tok_embeddings[token]                    table fp16 [vocab][dim], out fp16 [dim] */
 int gq_embed_lookup(const int *token, const void *table, void *out, uint32_t dim, uint32_t vocab, void *stream);
+int gq_embed_lookup_ho(const int *token, const void *table, void *out, uint32_t dim, uint32_t vocab, float *ssq_out, void *stream);
 
 /* RoPE(q,k) at *pos, KV-cache update at *pos, softmax(q k^T / sqrt(d)) v over positions 0..*pos.
  * *pos >= max_seq (decoding past the cache): nothing is written to the caches and `out` is filled with NaN, so the step's
@@ -394,6 +421,10 @@ int gq_anyprec_gemv_qkv_rope(const void *x, void *q_out, const uint32_t *qweight
                              const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
                              void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
                              void *stream);
+int gq_anyprec_gemv_qkv_rope_ho(const void *x, void *q_out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                                const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
+                                void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                                const float *ssq_in, void *stream);
 int gq_attn_decode_roped(const void *q, const int *pos, const void *k_cache, const void *v_cache, void *out, uint32_t n_head,
                          uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, float scale, uint32_t n_split, float *workspace,
                          void *stream);
@@ -409,6 +440,16 @@ int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint3
  * *pos_io is incremented, so a captured decode graph advances by itself.  top_k <= 32. */
 int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
                    float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, void *stream);
+/* Round 5: the same draw with up to 64 candidates (work_val / work_idx: 128 * 64 elements) and three optional extras for a decode
+ * step that runs without the host (guidedquant_amd/generate.py::DecodeGraph, the HF-surface route of AnyPrecisionForCausalLM.generate):
+ *   ban      device words {n <= 4, until_pos, id[0..3]} or NULL: while *pos_io < until_pos the listed tokens cannot be drawn -- what HF's
+ *            MinNewTokensLengthLogitsProcessor does to EOS (transformers generation, used by inference_example.py:57-67 min_new_tokens);
+ *   seq_out  int [seq_cap] or NULL: seq_out[*pos_io + 1] = token (positions as stored BEFORE the increment);
+ *   embed_table / x_out / dim / ssq_out: x_out = embed_table[token] (fp16 [dim]) and, with ssq_out, its hand-over statistics
+ *            (gq_embed_lookup_ho) -- the next step needs no embedding launch (inference/model.py:121-130). */
+int gq_sample_topk_ex(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
+                      float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, const int *ban, int *seq_out,
+                      uint32_t seq_cap, const void *embed_table, void *x_out, uint32_t dim, float *ssq_out, void *stream);
 
 /* Test / tuning hooks (not part of the reference's surface).  gq_reset_env_cache: drop the cached GQ_* environment
  * knobs so that a test can flip them between calls.  gq_debug_set_timing_buffer: device buffer the plane kernels write

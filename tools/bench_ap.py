@@ -22,7 +22,7 @@ if __name__ == "__main__":
     ap.add_argument("--bits", type=int, nargs="*", default=[2, 3, 4])
     ap.add_argument("--shapes", nargs="*", default=["wqkv", "wo", "w1w3", "w2"])
     ap.add_argument("--iters", type=int, default=200)
-    ap.add_argument("--launch", choices=["plain", "norm", "norm_pairs", "resid", "resid_ws", "qkv_rope"], default="plain")
+    ap.add_argument("--launch", choices=["plain", "norm", "norm_pairs", "resid", "resid_ws", "qkv_rope", "norm_ho", "norm_pairs_ho", "resid_ho", "qkv_rope_ho"], default="plain")
     a = ap.parse_args()
     for b in a.bits:
         for n in a.shapes:

@@ -20,7 +20,12 @@ for name in sys.argv[2:] or list(SH):
     for i, q in enumerate(qs):
         if i == len(qs) - 1:
             L.gq_debug_set_timing_buffer(dbg.data_ptr())
-        if FUSED:  # the decode step's own launch: RMSNorm prologue (+ gate/up pair epilogue for w1w3)
+        if os.environ.get("PT_FUSED") == "2":  # ... with the statistics hand-over (round 5)
+            ssq = torch.zeros(_lib.SSQ_SLOTS, dtype=torch.float32, device=d)
+            L.gq_ssq_rows(x.data_ptr(), K, ssq.data_ptr(), None)
+            L.gq_anyprec_gemv_fused_ho(x.data_ptr(), out.data_ptr(), q.data_ptr(), lut.data_ptr(), N, K, bits, nw.data_ptr(), 1e-5, None,
+                                       4 if name == "w1w3" else 0, None, 0, ssq.data_ptr(), None, None)
+        elif FUSED:  # the decode step's own launch: RMSNorm prologue (+ gate/up pair epilogue for w1w3)
             L.gq_anyprec_gemv_fused(x.data_ptr(), out.data_ptr(), q.data_ptr(), lut.data_ptr(), N, K, bits, nw.data_ptr(), 1e-5, None,
                                     4 if name == "w1w3" else 0, None)
         else:

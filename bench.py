@@ -93,7 +93,21 @@ def graph_time_us(launch, n_distinct, iters=200, reps=5):
     return best
 
 
-def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
+def stream_floor_us(buffers, nbytes, iters=200):
+    """what a launch that only READS nbytes once reaches on this chip (gq_debug_stream_read over the given rotating device
+    buffers, same timing method as the GEMV launches): the one-shot streaming floor, launch boundary included"""
+    import torch
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    sink = torch.zeros(16, dtype=torch.int32, device=buffers[0].device)
+    nbytes = min(int(nbytes), min(b.numel() * b.element_size() for b in buffers)) // 16 * 16
+
+    def run(i):
+        assert L.gq_debug_stream_read(buffers[i].data_ptr(), nbytes, sink.data_ptr(), _lib.current_stream_ptr()) == 0, L.gq_last_error()
+    return graph_time_us(run, len(buffers), iters)
+
+
+def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None, floor=False):
     """One AP-GEMV shape, default dispatch, rotating over > 512 MB of distinct weights (the 256 MiB Infinity Cache cannot
     serve them).  fused = None: the plain entry point (gq_anyprec_gemv); "norm": RMSNorm prologue; "norm_pairs": RMSNorm
     prologue + gate/up pair epilogue (the decode graph's w1w3 launch); "resid": residual epilogue (wo / w2 launches)."""
@@ -166,8 +180,13 @@ def bench_ap_shape(name, N, K, bits, iters=200, min_ws=512 << 20, fused=None):
 
     us = graph_time_us(run, nbuf, iters)
     gbs = b_ap(bits, N, K) / us / 1e3
-    return {"shape": name, "N": N, "K": K, "bits": bits, "launch": (fused or "plain") + ("_ho" if ho else ""), "us": round(us, 3), "GBps": round(gbs, 1),
-            "frac": round(gbs / HBM_PEAK_GBPS, 4)}
+    rec = {"shape": name, "N": N, "K": K, "bits": bits, "launch": (fused or "plain") + ("_ho" if ho else ""), "us": round(us, 3), "GBps": round(gbs, 1),
+           "frac": round(gbs / HBM_PEAK_GBPS, 4)}
+    if floor:  # the same bytes (the plane words: 99 % of the algorithmic bytes) read once by a launch that does nothing else
+        fl = stream_floor_us(qs, per, iters)
+        rec["stream_floor_us"] = round(fl, 3)
+        rec["frac_of_stream_floor"] = round(fl / us, 4)
+    return rec
 
 
 def decode_tok_s(model, dev, steps, warmup, torch_sampling=False):
@@ -277,11 +296,21 @@ def main():
     full = rank == 0 and world == 1 and not args.quick
     if full and not qtip:
         table = []
+        graph_form = {"wqkv": "norm", "wo": "resid", "w1w3": "norm_pairs", "w2": "resid"}
         for b in (2, 3, 4):
             for nm, (N, K) in SHAPES_8B.items():
                 table.append(bench_ap_shape(nm, N, K, b, iters=100))
-        extras["roofline_by_shape"] = {"note": "Llama-3-8B GEMV shapes, default dispatch, plain entry point (gq_anyprec_gemv), > 512 MB of "
-                                               "weights rotating, us per launch / algorithmic GB/s / fraction of 8 TB/s", "rows": table}
+                # the launch form of the decode graph (what the headline runs): RMSNorm (+ RoPE / cache epilogue where the library
+                # serves wqkv that way) -> wqkv, residual epilogue on wo / w2, RMSNorm + gate/up pairs on w1w3
+                form = graph_form[nm]
+                if nm == "wqkv" and L.gq_anyprec_qkv_rope_supported(N, K, b, 128):
+                    form = "qkv_rope"
+                table.append(bench_ap_shape(nm, N, K, b, iters=100, fused=form, floor=True))
+        extras["roofline_by_shape"] = {"note": "Llama-3-8B GEMV shapes, default dispatch, > 512 MB of weights rotating, us per launch / algorithmic "
+                                               "GB/s / fraction of 8 TB/s.  launch = plain: the reference's operator (gq_anyprec_gemv); the other "
+                                               "row of a shape is the launch form of the decode graph (qkv_rope / norm, resid, norm_pairs) with "
+                                               "frac_of_stream_floor = (time of a launch that only reads the same plane words once, measured "
+                                               "in this run) / (time of the launch)", "rows": table}
         if args.mode == "default":
             _lib.check(L.gq_set_ap_mode(1), "gq_set_ap_mode")
             _, run_exact = decode_tok_s(model, dev, 200, 50, args.torch_sampling)
@@ -379,6 +408,7 @@ def ap_roofline(model, bits, mode_arg):
     # by the host at ~9.6 us per launch -- the round-3 figure happened to coincide with the kernel's own time)
     t_kernel_us = graph_time_us(launch, cfg.n_layer, iters=10 * cfg.n_layer, reps=3)
     bytes_launch = b_ap(bits, 2 * I, D)
+    floor_us = stream_floor_us([b.feed_forward.w1w3.qweight for b in layers], bits * 2 * I * D // 8, iters=10 * cfg.n_layer)
     achieved = bytes_launch / t_kernel_us / 1e3  # GB/s
     exact = mode_arg == "exact" or (mode_arg == "default" and os.environ.get("GQ_AP_EXACT", "0") != "0")
     # HBM bytes per launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
@@ -394,7 +424,10 @@ def ap_roofline(model, bits, mode_arg):
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "AP-GEMV w1w3 %dx%d %d-bit, RMSNorm prologue%s (%s kernels)" % (2 * I, D, bits, " + gate/up pair epilogue" if paired else "",
                                                                                   "exact-order" if exact else "default dispatch"),
-            "avg_launch_us": round(t_kernel_us, 3), "algorithmic_bytes_per_launch": bytes_launch}
+            "avg_launch_us": round(t_kernel_us, 3), "algorithmic_bytes_per_launch": bytes_launch,
+            # next to the 8 TB/s fraction: against what a one-shot launch of this size can reach (a kernel that only reads the same
+            # plane words once, launch boundary included, measured in this run on the same tensors)
+            "stream_floor_us": round(floor_us, 3), "frac_of_stream_floor": round(floor_us / t_kernel_us, 4)}
 
 
 def qtip_roofline(cfg, R, shape=None):
@@ -533,8 +566,8 @@ def long_context_record(dev, start=4096, steps=100):
 def hf_generate_record(dev, new_tokens=100):
     """The reference's published figure (130 tokens/s on an RTX 3090, README.md:95-97) is `AnyPrecisionForCausalLM.generate(...,
     cache_implementation="static")` on the HF module tree (inference_example.py:34-77).  The same call here on a random-init
-    Llama-3.1-8B 2-bit model: (a) the HF module tree, every decoder linear one plugin::anyprec_gemv launch (unfused, eager,
-    Python between the launches); (b) `generate(..., native=True)`: the same object's fused decode model behind the same call."""
+    Llama-3.1-8B 2-bit model through its three routes (AnyPrecisionForCausalLM.generate): the default call, the module tree with a
+    captured step, transformers' own eager generate."""
     import gc
     import torch
     import transformers
@@ -562,15 +595,33 @@ def hf_generate_record(dev, new_tokens=100):
         return round(best, 2)
 
     rec = {"model": "Llama-3.1-8B-shaped, random init, 2-bit Any-Precision", "new_tokens": new_tokens,
-           "harness": "AnyPrecisionForCausalLM.generate(input_ids=[BOS], max_new_tokens=100, do_sample=False), inference_example.py:34-77"}
+           "harness": "AnyPrecisionForCausalLM.generate(input_ids=[BOS], max_new_tokens=100, do_sample=False, cache_implementation='static'), "
+                      "inference_example.py:34-77"}
+    torch.cuda.reset_peak_memory_stats(dev)
+    base_mem = torch.cuda.memory_allocated(dev)
+    # route 3 first (it needs the module tree's own planes), then route 2, then the default call (route 1 releases q/k/v/gate/up planes)
     try:
-        rec["hf_module_tree_static_cache_tok_s"] = timed(cache_implementation="static", pad_token_id=0)
+        rec["hf_module_tree_static_cache_tok_s"] = timed(cache_implementation="static", pad_token_id=0, native=False)
     except Exception as e:  # (an installed transformers without the static cache for this call: the dynamic cache then)
         rec["hf_module_tree_static_cache_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
-        rec["hf_module_tree_dynamic_cache_tok_s"] = timed(pad_token_id=0)
-    rec["native_route_tok_s"] = timed(native=True)
-    rec["note"] = ("same object, same call; native=True routes the bs=1 request to the fused decode model (hipGraph step); wall clock incl. "
-                   "the prompt token and host overhead of generate()")
+        rec["hf_module_tree_dynamic_cache_tok_s"] = timed(pad_token_id=0, native=False)
+    try:
+        rec["hf_module_tree_captured_step_tok_s"] = timed(pad_token_id=0, native=False, capture=True)
+    except Exception as e:
+        rec["hf_module_tree_captured_step_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+    m._native_cache = {}
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    rec["default_call_tok_s"] = timed(cache_implementation="static", pad_token_id=0)
+    rec["native_route_tok_s"] = rec["default_call_tok_s"]
+    rec["native_route_peak_mem_over_module_tree"] = round(torch.cuda.max_memory_allocated(dev) / max(1, base_mem), 3)
+    rec["note"] = ("same object, same call.  default_call = the unmodified reference call: routed to the fused decode model (hipGraph step, weights "
+                   "shared with the module tree by reference, q/k/v/gate/up planes held once); hf_module_tree_static_cache = native=False: "
+                   "transformers' own generate on the module tree, one plugin::anyprec_gemv launch per decoder linear (the figure of rounds 3-4); "
+                   "hf_module_tree_captured_step = capture=True: the module tree's decode step as ONE hipGraph over a transformers StaticCache "
+                   "with the fused sampler (slower than the eager route: ~1,500 small graph nodes per token; opt-in).  Wall clock incl. the "
+                   "prompt token and host overhead of generate()")
     del m
     gc.collect()
     torch.cuda.empty_cache()

@@ -72,6 +72,10 @@ class AnyPrecisionForCausalLM(nn.Module):
         self.ap_linears = []
         self._load_quantized_modules()
         self._native_cache = {}
+        self._released = None
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._restore_module_tree())
+        # new weights: the fused decode model (built from the old tensors) and every captured graph are stale
+        self.register_load_state_dict_pre_hook(lambda module, *a, **k: module._drop_native())
         if random_init_seed is not None:
             self._random_weights(random_init_seed)
         else:
@@ -80,6 +84,9 @@ class AnyPrecisionForCausalLM(nn.Module):
                                         "the reference calls snapshot_download)")
             self._load_weights(model_path)
         self.tie_weights()
+        if self.device.type == "cuda":  # before transformers' generate captures anything under inference mode (generate.py)
+            from .generate import prime_graph_rng_state
+            prime_graph_rng_state(self.device)
         if fuse_layers:
             self.fuse_layers()
         self.prune_precisions()
@@ -177,43 +184,255 @@ class AnyPrecisionForCausalLM(nn.Module):
         self.set_precision(prev_precision)
         return results
 
+    # keyword arguments of `generate` the fused routes understand (everything else -> transformers' own generate)
+    _ROUTE_KW = {"input_ids", "inputs", "max_new_tokens", "min_new_tokens", "max_length", "do_sample", "temperature", "top_k", "top_p",
+                 "pad_token_id", "eos_token_id", "attention_mask", "cache_implementation", "use_cache", "streamer", "num_beams",
+                 "num_return_sequences", "repetition_penalty", "return_dict_in_generate"}
+
+    def _route_request(self, args, kwargs):
+        """(params, None) when the request is one the fused decode routes serve -- ONE sequence, greedy or top-k (<= 64) sampling at
+        top_p = 1, no logits processors beyond min_new_tokens on EOS -- else (None, reason).  Missing sampling arguments come from
+        the model's generation_config exactly as in transformers (top_k defaults to 50 there)."""
+        if len(args) > 1 or any(k not in self._ROUTE_KW for k in kwargs):
+            return None, "arguments outside the fused routes: %s" % sorted(k for k in kwargs if k not in self._ROUTE_KW)
+        ids = args[0] if args else kwargs.get("input_ids", kwargs.get("inputs"))
+        if not torch.is_tensor(ids) or ids.dim() != 2 or ids.shape[0] != 1 or ids.shape[1] < 1 or ids.is_floating_point():
+            return None, "input_ids must be one sequence of token ids, [1, T]"
+        if self.device.type != "cuda":
+            return None, "the fused routes need the GPU"
+        gc_ = getattr(self.model, "generation_config", None)
+        g = (lambda name, dflt=None: kwargs[name] if kwargs.get(name) is not None else (getattr(gc_, name, dflt) if gc_ is not None and getattr(gc_, name, None) is not None else dflt))
+        if g("num_beams", 1) != 1 or g("num_return_sequences", 1) != 1 or g("return_dict_in_generate", False) or g("use_cache", True) is False:
+            return None, "beam search / several return sequences / dict output / use_cache=False"
+        if float(g("repetition_penalty", 1.0)) != 1.0:
+            return None, "repetition_penalty"
+        for name in ("no_repeat_ngram_size", "encoder_no_repeat_ngram_size", "bad_words_ids", "force_words_ids", "suppress_tokens", "begin_suppress_tokens",
+                     "forced_bos_token_id", "forced_eos_token_id", "sequence_bias", "typical_p", "epsilon_cutoff", "eta_cutoff", "min_p", "penalty_alpha",
+                     "min_length"):
+            v = getattr(gc_, name, None) if gc_ is not None else None
+            if v not in (None, 0, 0.0, 1.0, [], False):
+                return None, "generation_config.%s" % name
+        T = int(ids.shape[1])
+        max_new = kwargs.get("max_new_tokens")
+        if max_new is None:
+            ml = g("max_length", None)
+            max_new = (int(ml) - T) if ml is not None else None
+        if max_new is None or int(max_new) < 1:
+            return None, "max_new_tokens"
+        am = kwargs.get("attention_mask")
+        if am is not None and not (tuple(am.shape) == tuple(ids.shape) and bool((am != 0).all())):
+            return None, "attention_mask with masked positions"
+        do_sample = bool(g("do_sample", False))
+        temperature, top_k = 0.0, 1
+        if do_sample:
+            temperature = float(g("temperature", 1.0))
+            top_p, top_k = g("top_p", 1.0), g("top_k", 50)
+            if top_p is not None and float(top_p) < 1.0:
+                return None, "top_p < 1"
+            if top_k is None or int(top_k) < 1 or int(top_k) > 64 or temperature <= 0.0:
+                return None, "top_k outside 1..64 (the fused sampler's candidates)"
+        eos = g("eos_token_id", None)
+        eos = [] if eos is None else ([int(eos)] if isinstance(eos, int) else [int(e) for e in eos])
+        if len(eos) > 4:
+            return None, "more than 4 EOS ids"
+        return dict(ids=ids, T=T, max_new=int(max_new), min_new=min(int(g("min_new_tokens", 0) or 0), int(max_new)), temperature=temperature,
+                    top_k=int(top_k), eos=eos, streamer=kwargs.get("streamer")), None
+
     def generate(self, *args, **kwargs):
-        """HF `generate` on the module tree (inference_example.py:34-77) -- or, with native=True and a plain bs=1 request
-        (input_ids, max_new_tokens, do_sample / temperature / top_k), the same checkpoint's fused decode model behind the same
-        call: prompt through the HIP prompt pass, every new token one replay of the captured 5-launches-per-layer graph.  Returns
-        the [1, prompt + new] token tensor like HF does."""
+        """`generate` of the reference's HF surface (inference_example.py:34-77).  Three routes behind the one call:
+          1. the fused decode model of the same checkpoint (`native_decoder`: prompt through the HIP prompt pass, every new token one
+             replay of the captured 5-launches-per-layer graph, sampling / EOS suppression / embedding of the next token on the device)
+             -- taken AUTOMATICALLY for a request it serves (`_route_request`: one sequence, greedy or top-k <= 64 at top_p = 1 -- the
+             reference's own call); `native=False` opts out, `native=True` insists (ValueError when the request is not served);
+          2. `capture=True`: the HF module tree with its decode step captured as ONE hipGraph over a transformers StaticCache, the
+             fused sampler at its end -- opt-in: measured SLOWER than route 3 on the 8B model (172 vs 249 tokens/s: the module tree's
+             ~1,500 small launches per token cost more as graph nodes than as stream launches; the fused model is the fast form);
+          3. transformers' own generate on the module tree (anything else: beams, top_p, processors, batches; or `native=False`).
+        Returns the [1, prompt + new] token tensor like HF does; stops at EOS (checked every 32 tokens, the tail is cut); honours
+        min_new_tokens, streamer, precision=."""
         prev_precision = self.precision
         if 'precision' in kwargs:
             self.set_precision(kwargs.pop('precision'))
+        native = kwargs.pop('native', None)
+        capture = kwargs.pop('capture', None)
         try:
-            if kwargs.pop('native', False):
-                return self._generate_native(*args, **kwargs)
+            req, why = self._route_request(args, kwargs) if (native is not False or capture is True) else (None, "opted out")
+            if native is True and req is None:
+                raise ValueError("native=True: " + why)
+            if req is not None and native is not False:
+                dec = self._native_decoder_or_none(self.precision)
+                if dec is not None:
+                    return self._generate_native(dec, req)
+                if native is True:
+                    raise ValueError("native=True: this checkpoint has no fused decode form at %d bits" % self.precision)
+            if capture is True:
+                if req is None:
+                    raise ValueError("capture=True: " + why)
+                return self._generate_captured(req)
             with torch.inference_mode():
                 return self.model.generate(*args, **kwargs)
         finally:
             self.set_precision(prev_precision)
 
-    def _generate_native(self, input_ids=None, max_new_tokens=100, do_sample=False, temperature=1.0, top_k=32, **unused):
+    # -- route 1: the fused decode model ---------------------------------------------------------------------------------
+    def _native_decoder_or_none(self, bitwidth):
+        try:
+            dec = self.native_decoder(bitwidth)
+        except Exception:
+            return None
+        dec.setup_caches(1, 8) if not dec.cache_initialized else None
+        return dec if dec.native_ready() else None
+
+    def _emit(self, req, seq_host, lo, hi):
+        """tokens [lo, hi) of the host copy of the sequence: to the streamer (up to and including the first EOS that counts -- index
+        >= T + min_new_tokens); returns the index behind that EOS, or None"""
+        cut = None
+        for i in range(max(lo, req["T"] + req["min_new"]), hi if req["eos"] else 0):
+            if int(seq_host[i]) in req["eos"]:
+                cut = i + 1
+                break
+        if req["streamer"] is not None and hi > lo:
+            req["streamer"].put(seq_host[lo:(cut or hi)])
+        return cut
+
+    def _generate_native(self, dec, req, chunk=32):
         from . import generate as gen
-        ids = (input_ids if input_ids is not None else unused.pop("inputs")).to(self.device)
-        if ids.dim() != 2 or ids.shape[0] != 1:
-            raise ValueError("native=True serves one sequence (bs = 1)")
-        unsupported = [k for k in unused if k not in ("cache_implementation", "pad_token_id", "eos_token_id", "attention_mask", "use_cache")]
-        if unsupported:
-            raise ValueError(f"native=True does not take {unsupported}")
-        dec = self.native_decoder(self.precision)
-        T = ids.shape[1]
-        dec.setup_caches(1, T + max_new_tokens)
-        temp = float(temperature) if do_sample else 0.0
-        key = (self.precision, dec.max_seq_length, temp, int(top_k))
+        ids, T, max_new = req["ids"].to(self.device), req["T"], req["max_new"]
+        total = T + max_new
+        if total > dec.config.block_size:
+            raise ValueError(f"prompt + max_new_tokens = {total} exceeds the model's context ({dec.config.block_size})")
+        dec.setup_caches(1, total)
+        key = (self.precision, dec.max_seq_length, req["temperature"], req["top_k"])
         graph = self._native_cache.get(("graph",) + key)
         if graph is None:
-            graph = gen.DecodeGraph(dec, self.device, native_sampling=True, temperature=temp, top_k=int(top_k))
             self._native_cache = {k: v for k, v in self._native_cache.items() if k[0] != "graph"}
+            graph = gen.DecodeGraph(dec, self.device, native_sampling=True, fold_embed=True, seq_capacity=dec.max_seq_length + 1,
+                                    temperature=req["temperature"], top_k=req["top_k"])
             self._native_cache[("graph",) + key] = graph
+        ids32 = ids.view(-1).to(torch.int32)
         with torch.inference_mode():
-            seq = gen.generate(dec, ids.view(-1).to(torch.int32), max_new_tokens, use_graph=True, graph=graph, temperature=temp, top_k=int(top_k))
-        return seq.to(ids.dtype)
+            graph.seq[:T].copy_(ids32)
+            # EOS cannot be drawn before min_new_tokens are out: the token of the step at position p is new token number p + 2 - T
+            ban = [len(req["eos"]), T - 1 + req["min_new"]] + req["eos"] + [0] * (4 - len(req["eos"]))
+            graph.ban.copy_(torch.tensor(ban, dtype=torch.int32), non_blocking=False)
+            if T > 1:  # the prompt but for its last token fills the caches (HIP prompt pass; one eager step for a single token)
+                pre, pos = ids32[:T - 1], torch.arange(0, T - 1, device=self.device, dtype=torch.int32)
+                if dec.prefill_ready(pre):
+                    dec.prefill_native(pre, pos, start=0)
+                elif T - 1 == 1:
+                    dec.decode_native(pre.view(1), pos.view(1))
+                else:
+                    dec(pre.view(1, -1), pos)
+            graph.set_token(ids32[T - 1:T], T - 1)
+            if req["streamer"] is not None:
+                req["streamer"].put(ids.cpu())
+            done, cut = 0, None
+            host_checks = bool(req["eos"]) and req["min_new"] < max_new or req["streamer"] is not None
+            while done < max_new and cut is None:
+                n = min(chunk, max_new - done) if host_checks else max_new - done
+                for _ in range(n):
+                    graph.step()
+                if host_checks:
+                    seq_host = graph.seq[:T + done + n].cpu().long()
+                    cut = self._emit(req, seq_host, T + done, T + done + n)
+                done += n
+            end = cut if cut is not None else T + done
+            out = graph.seq[:end].to(ids.dtype).view(1, -1).clone()
+        if req["streamer"] is not None:
+            req["streamer"].end()
+        return out
+
+    # -- route 2: the module tree, decode step captured -------------------------------------------------------------------
+    def _generate_captured(self, req, chunk=32):
+        """bs = 1 decode on the HF module tree with ONE hipGraph per token: the step `logits = model(input_ids [1,1], StaticCache,
+        cache_position)` + the fused sampler (gq_sample_topk_ex: the draw, EOS suppression, the sequence store, token feedback) are
+        captured once per (precision, cache length, sampling) and replayed; the prompt runs eagerly through the same cache."""
+        from transformers import StaticCache
+        from . import _lib
+        ids, T, max_new = req["ids"].to(self.device), req["T"], req["max_new"]
+        total = T + max_new
+        V = int(self.config.vocab_size)
+        key = ("cap", self.precision, total, req["temperature"], req["top_k"])
+        st = self._native_cache.get(key)
+        # (no_grad, not inference_mode: the first graph capture of a process creates the generator's graph-safe state tensors, and
+        # inference tensors could not be updated by the captures that follow outside inference mode)
+        with torch.no_grad():
+            if st is None:
+                self._native_cache = {k: v for k, v in self._native_cache.items() if k[0] != "cap"}
+                dev = self.device
+                st = dict(cache=StaticCache(config=self.config, max_cache_len=total), tok64=torch.zeros((1, 1), dtype=torch.long, device=dev),
+                          tok=torch.zeros((1, ), dtype=torch.int32, device=dev),
+                          pos=torch.zeros((1, ), dtype=torch.int32, device=dev), nxt=torch.zeros((1, ), dtype=torch.int32, device=dev),
+                          ctr=torch.zeros((1, ), dtype=torch.int32, device=dev), wv=torch.zeros(128 * 64, dtype=torch.float32, device=dev),
+                          wi=torch.zeros(128 * 64, dtype=torch.int32, device=dev), ban=torch.zeros(6, dtype=torch.int32, device=dev),
+                          seq=torch.zeros(total + 1, dtype=torch.int32, device=dev), logits=torch.zeros(V, dtype=torch.float16, device=dev))
+
+                def step():
+                    # (positions come from the cache itself: StaticLayer.cumulative_length is a device word the layer advances in place)
+                    out = self.model(input_ids=st["tok64"], past_key_values=st["cache"], use_cache=True)
+                    st["logits"].copy_(out.logits.view(-1))
+                    _lib.check(_lib.lib().gq_sample_topk_ex(st["logits"].data_ptr(), V, req["top_k"], float(req["temperature"]), 1234,
+                                                           st["ctr"].data_ptr(), st["wv"].data_ptr(), st["wi"].data_ptr(), st["tok"].data_ptr(),
+                                                           st["pos"].data_ptr(), st["nxt"].data_ptr(), st["ban"].data_ptr(), st["seq"].data_ptr(),
+                                                           st["seq"].numel(), None, None, 0, None, _lib.current_stream_ptr()), "gq_sample_topk_ex")
+                    st["tok64"].copy_(st["tok"].view(1, 1))
+                st["step"] = step
+                st["graph"] = None
+                self._native_cache[key] = st
+            st["cache"].reset()
+            st["seq"][:T].copy_(ids.view(-1).to(torch.int32))
+            ban = [len(req["eos"]), T - 1 + req["min_new"]] + req["eos"] + [0] * (4 - len(req["eos"]))
+            st["ban"].copy_(torch.tensor(ban, dtype=torch.int32))
+            if T > 1:
+                self.model(input_ids=ids[:, :T - 1], past_key_values=st["cache"], use_cache=True)
+            st["tok64"].copy_(ids[:, T - 1:T])
+            st["tok"].copy_(ids.view(-1)[T - 1:T].to(torch.int32))
+            st["pos"].fill_(T - 1)
+
+            def set_cache_length(n):
+                for layer in st["cache"].layers:
+                    if torch.is_tensor(getattr(layer, "cumulative_length", None)):
+                        layer.cumulative_length.fill_(n)
+            if st["graph"] is None:  # capture (after two eager steps on a side stream; the cache and positions are re-set behind them)
+                keep = (st["tok64"].clone(), st["tok"].clone(), st["ctr"].clone())
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(2):
+                        st["step"]()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st["step"]()
+                torch.cuda.synchronize()
+                st["graph"] = g
+                # the warm-up steps wrote cache rows T-1 .. T+1 and moved the positions: rows past the position are overwritten before
+                # they are read (causal), the rest is restored
+                st["tok64"].copy_(keep[0])
+                st["tok"].copy_(keep[1])
+                st["ctr"].copy_(keep[2])
+                st["pos"].fill_(T - 1)
+                if T == 1:  # (no prompt pass ran: the layers allocated their tensors inside the warm-up)
+                    st["cache"].reset()
+                set_cache_length(T - 1)
+            if req["streamer"] is not None:
+                req["streamer"].put(ids.cpu())
+            done, cut = 0, None
+            host_checks = bool(req["eos"]) and req["min_new"] < max_new or req["streamer"] is not None
+            while done < max_new and cut is None:
+                n = min(chunk, max_new - done) if host_checks else max_new - done
+                for _ in range(n):
+                    st["graph"].replay()
+                if host_checks:
+                    seq_host = st["seq"][:T + done + n].cpu().long()
+                    cut = self._emit(req, seq_host, T + done, T + done + n)
+                done += n
+            end = cut if cut is not None else T + done
+            out = st["seq"][:end].to(ids.dtype).view(1, -1).clone()
+        if req["streamer"] is not None:
+            req["streamer"].end()
+        return out
 
     @staticmethod
     def _load_config(model_path, trust_remote_code=True):
@@ -253,15 +472,97 @@ class AnyPrecisionForCausalLM(nn.Module):
 
     def native_decoder(self, bitwidth: Optional[int] = None):
         """the same checkpoint as the fused gpt-fast `Transformer` (fused QKV / Up-Gate Any-Precision linears at one precision)
-        whose bs=1 decode step runs as the captured 5-launches-per-layer HIP graph"""
-        from .hf_loader import anyprec_state_dict_to_transformer, load_anyprec_hf
+        whose bs=1 decode step runs as the captured 5-launches-per-layer HIP graph.  Built from the module tree's tensors BY
+        REFERENCE: embedding, lm_head, norms, o_proj and down_proj are the same storage; q/k/v and gate/up are concatenated into the
+        fused tensors layer by layer, and -- when the checkpoint carries exactly this precision, the GuidedQuant case -- the module
+        tree's own copies are released as they go (restored from the fused tensors the first time the module tree is used again,
+        `_restore_module_tree`): one copy of every weight at any time."""
         bitwidth = bitwidth or min(self.precisions)
         dec = self._native_cache.get(("decoder", bitwidth))
         if dec is None:
-            if self.model_path is not None and os.path.exists(str(self.model_path)):
-                dec = load_anyprec_hf(self.model_path, bitwidth=bitwidth, device=self.device)
-            else:  # no checkpoint on disk (from_config_random): from the module tree's own tensors
-                cfg = self.config.to_dict() if hasattr(self.config, "to_dict") else dict(self.config)
-                dec = anyprec_state_dict_to_transformer(dict(self.model.state_dict()), cfg, bitwidth, self.device)
+            self._restore_module_tree()  # (a decoder of another precision may hold the q/k/v/gate/up planes)
+            dec = self._build_native(bitwidth)
             self._native_cache[("decoder", bitwidth)] = dec
         return dec
+
+    def _layer_linears(self, layer):
+        at, mlp = layer.self_attn, layer.mlp
+        return dict(q=at.q_proj, k=at.k_proj, v=at.v_proj, o=at.o_proj, gate=mlp.gate_proj, up=mlp.up_proj, down=mlp.down_proj)
+
+    def _build_native(self, bitwidth):
+        from .APLinear import APLinear
+        from .hf_loader import model_args_from_hf_config
+        from .model import Transformer
+        if bitwidth not in self.precisions:
+            raise ValueError(f"bitwidth {bitwidth} not among the loaded precisions {self.precisions}")
+        cfg = self.config.to_dict() if hasattr(self.config, "to_dict") else dict(self.config)
+        args = model_args_from_hf_config(cfg)
+        dev = self.device
+        with torch.device("meta"):
+            dec = Transformer(torch.float16, args, linear_class=APLinear, linear_kwargs=dict(bitwidth=bitwidth, device="meta"), fuse_linears=True)
+        inner = _get_by_path(self.model, (self.config.anyprec.get('arch_config') or {}).get('model_name', 'model'))
+        lm_head = self.model.get_output_embeddings() if hasattr(self.model, "get_output_embeddings") else self.model.lm_head
+        dec.tok_embeddings.weight = inner.embed_tokens.weight
+        dec.output.weight = lm_head.weight
+        dec.norm.weight = inner.norm.weight
+        single = all(lin.qweight.shape[0] == bitwidth for lin in self.ap_linears)  # the planes ARE this precision: nothing is lost by releasing them
+
+        def put(mod, qweight, lut):
+            mod._buffers["qweight"] = qweight
+            mod._buffers["lut"] = lut
+            mod.output = torch.zeros((1, 1, mod.out_features), dtype=torch.float16, device=dev)
+
+        released = []
+        for hf_layer, blk in zip(self.get_model_layers(), dec.layers):
+            L = self._layer_linears(hf_layer)
+            if any(m.bias is not None for m in L.values()):
+                raise NotImplementedError("fused decode model: biased linears")
+            blk.input_layernorm.weight = hf_layer.input_layernorm.weight
+            blk.post_attention_layernorm.weight = hf_layer.post_attention_layernorm.weight
+            lut = lambda m: m._buffers[f"lut{bitwidth}"].to(torch.float16)  # noqa: E731
+            put(blk.attention.wo, L["o"].qweight[:bitwidth], lut(L["o"]))           # (a prefix of the planes: contiguous view)
+            put(blk.feed_forward.w2, L["down"].qweight[:bitwidth], lut(L["down"]))
+            put(blk.attention.wqkv, torch.cat([L[n].qweight[:bitwidth] for n in "qkv"], dim=1).contiguous(),
+                torch.cat([lut(L[n]) for n in "qkv"], dim=0).contiguous())
+            put(blk.feed_forward.w1w3, torch.cat([L["gate"].qweight[:bitwidth], L["up"].qweight[:bitwidth]], dim=1).contiguous(),
+                torch.cat([lut(L["gate"]), lut(L["up"])], dim=0).contiguous())
+            if single:
+                for n in ("q", "k", "v", "gate", "up"):
+                    L[n]._buffers["qweight"] = torch.empty((0, ), dtype=torch.int32, device=dev)
+                    L[n]._gq_restore = self._restore_module_tree
+                    released.append(L[n])
+        self._released = (bitwidth, released) if released else None
+        dec = dec.eval()
+        dec._reset_native()
+        return dec
+
+    def _drop_native(self):
+        self._restore_module_tree()
+        self._native_cache = {}
+
+    def _restore_module_tree(self):
+        """give q/k/v and gate/up of the module tree their plane tensors back (slices of the fused decode model's tensors; the gate/up
+        rows un-paired), and drop the fused model and its graphs -- one copy of every weight at any time"""
+        rel = getattr(self, "_released", None)
+        if not rel:
+            return
+        from .model import _pair_perm
+        bitwidth, _ = rel
+        dec = self._native_cache.get(("decoder", bitwidth))
+        self._released = None
+        for hf_layer, blk in zip(self.get_model_layers(), dec.layers):
+            L = self._layer_linears(hf_layer)
+            qkv, gu = blk.attention.wqkv.qweight, blk.feed_forward.w1w3.qweight
+            if getattr(blk.feed_forward.w1w3, "gq_row_pairs", False):
+                gu = gu[:, torch.argsort(_pair_perm(gu.shape[1] // 2, gu.device)), :]
+            r0 = 0
+            for n in ("q", "k", "v"):
+                L[n]._buffers["qweight"] = qkv[:, r0:r0 + L[n].out_features, :].contiguous()
+                r0 += L[n].out_features
+            L["gate"]._buffers["qweight"] = gu[:, :L["gate"].out_features, :].contiguous()
+            L["up"]._buffers["qweight"] = gu[:, L["gate"].out_features:, :].contiguous()
+            for n in ("q", "k", "v", "gate", "up"):
+                L[n]._gq_restore = None
+            blk.attention.wqkv._buffers["qweight"] = blk.feed_forward.w1w3._buffers["qweight"] = None
+        self._native_cache = {}
+        gc.collect()

@@ -51,6 +51,8 @@ class AnyPrecisionLinear(nn.Module):
                 delattr(self, f'lut{bit}')
 
     def forward(self, x, **kwargs):
+        if self.qweight.numel() == 0 and getattr(self, "_gq_restore", None) is not None:
+            self._gq_restore()  # the planes live in the fused decode model (AnyPrecisionForCausalLM.native_decoder): take them back
         if 'precision' in kwargs:
             w_bits = kwargs['precision']
         else:

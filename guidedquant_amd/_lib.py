@@ -21,6 +21,7 @@ EXPORTS = [
     "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
     "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck", "gq_hop_send", "gq_hop_wait",
     "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows", "gq_anyprec_gemv_fused_ws", "gq_anyprec_gemv_fused_ws_bytes",
+    "gq_qtip_linear_out_in", "gq_debug_stream_read", "gq_hop_alloc", "gq_hop_free", "gq_hop_export", "gq_hop_import", "gq_hop_close", "gq_hop_wait_copy",
     "gq_sample_topk_ex", "gq_anyprec_gemv_fused_ho", "gq_ssq_rows", "gq_anyprec_handover_plan", "gq_embed_lookup_ho", "gq_anyprec_gemv_qkv_rope_ho",
 ]
 SSQ_SLOTS = 1024  # include/gq_hip.h GQ_SSQ_SLOTS
@@ -84,6 +85,7 @@ def lib():
         L.gq_qtip_linear_in.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), i32, ctypes.POINTER(GqQtipOut), i32, vp]
         L.gq_qtip_linear_out.argtypes = [i32, ctypes.POINTER(GqQtipOut), vp]
         L.gq_qtip_linear_out_seg.argtypes = [i32, ctypes.POINTER(GqQtipOut), vp]
+        L.gq_qtip_linear_out_in.argtypes = [ctypes.POINTER(GqQtipOut), vp, f32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
         L.gq_qtip_plan_ksplit.argtypes = [i32, ctypes.POINTER(u32), u32, i32]
         L.gq_qtip_linear.argtypes = [vp, vp, vp, f32, i32, u32, i32, i32, ctypes.POINTER(GqQtipIn), ctypes.POINTER(GqQtipOut), i32, vp, vp]
         L.gq_qtip_transform.argtypes = [i32, vp, vp, vp, f32, i32, i32, ctypes.POINTER(GqQtipXf), u32, u32, i32, vp]
@@ -119,6 +121,13 @@ def lib():
         L.gq_debug_set_qtip_timing_buffer.argtypes = [vp]
         L.gq_hop_send.argtypes = [vp, vp, u32, vp, vp, u32, vp]
         L.gq_hop_wait.argtypes = [vp, vp, u32, vp, u32, vp]
+        L.gq_debug_stream_read.argtypes = [vp, ctypes.c_size_t, vp, vp]
+        L.gq_hop_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+        L.gq_hop_free.argtypes = [vp]
+        L.gq_hop_export.argtypes = [vp, vp]
+        L.gq_hop_import.argtypes = [vp, ctypes.POINTER(vp)]
+        L.gq_hop_close.argtypes = [vp]
+        L.gq_hop_wait_copy.argtypes = [vp, vp, u32, vp, u32, vp, vp, u32, vp]
         L.gq_anyprec_qkv_rope_supported.argtypes = [u32, u32, i32, u32]
         L.gq_anyprec_gemv_qkv_rope.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, vp, vp, vp, vp, u32, u32, u32, u32, vp]
         L.gq_attn_decode_roped.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp]
@@ -131,14 +140,30 @@ def lib():
         L.gq_anyprec_gemv_fused_ws_bytes.restype = ctypes.c_size_t
         L.gq_last_error.restype = ctypes.c_char_p
         _lib = L
-        # one-time hardware self-check (LDS out-of-range reads return zero: csrc/capi.hip) -- fail loudly, never corrupt sums
-        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing() and os.environ.get("GQ_SELFCHECK", "1") != "0":
-            rc = L.gq_selfcheck()
-            if rc != 0:
-                msg = L.gq_last_error()
-                _lib = None
-                raise RuntimeError(f"gq_selfcheck: {msg.decode() if msg else rc}")
     return _lib
+
+
+_selfchecked = False
+
+
+def _ensure_selfcheck():
+    """one-time hardware self-check (LDS out-of-range reads return zero: csrc/capi.hip) -- fail loudly, never corrupt sums.  Run from
+    the first GPU entry point (every launch asks for the stream pointer), not from lib(): processes that only use the CPU entry
+    points never initialise the GPU runtime, and a first use under graph capture DEFERS the check instead of dropping it."""
+    global _selfchecked
+    if _selfchecked:
+        return
+    import torch
+    if os.environ.get("GQ_SELFCHECK", "1") == "0" or not torch.cuda.is_available():
+        _selfchecked = True
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return  # (a synchronous copy is illegal here: the next call outside a capture runs it)
+    rc = lib().gq_selfcheck()
+    if rc != 0:
+        msg = lib().gq_last_error()
+        raise RuntimeError(f"gq_selfcheck: {msg.decode() if msg else rc}")
+    _selfchecked = True
 
 
 GQ_ENOTSUP = -95  # include/gq_hip.h: valid request this build has no kernel for
@@ -152,4 +177,5 @@ def check(rc, what):
 
 def current_stream_ptr():
     import torch
+    _ensure_selfcheck()
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1158,7 +1158,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     stamp(7);
     int sb = 127;
     u32 nhot = 0;
-    if (items_w) {
+    if (items_w && !(a.xflags & 64u)) {  // (GQ_PL_XFLAGS 64: knock-out of the image build -- WRONG numerics, timing only)
         const h2v one2 = u2h2(0x3C003C00u);
         us2 mxp = {0, 0};
         float s2 = 0.f, xsum = 0.f;

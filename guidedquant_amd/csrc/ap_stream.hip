@@ -321,7 +321,10 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     constexpr int WV = st_waves<BITS>(), NH = ST_NH;
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
     constexpr u32 W = WV, T = 64u * W;
-    constexpr u32 RING = 4u;   // plane-word register slots (consumer units) per wave
+#ifndef ST_RING
+#define ST_RING 4
+#endif
+    constexpr u32 RING = ST_RING;   // plane-word register slots (consumer units) per wave
     constexpr u32 PF = ST_PF;  // consumer units requested ahead (< RING)
     constexpr u32 LPU = (u32)BITS * NH;  // plane loads per consumer unit
     constexpr u32 NCOL = PSUM ? 1u : 4u;
@@ -803,8 +806,12 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     for (u32 u0 = 0; u0 < n_units; u0 += RING) {
         if (u0 + 0u < n_units) consume(std::integral_constant<u32, 0>{}, u0);
         if (u0 + 1u < n_units) consume(std::integral_constant<u32, 1>{}, u0 + 1u);
-        if (u0 + 2u < n_units) consume(std::integral_constant<u32, 2>{}, u0 + 2u);
-        if (u0 + 3u < n_units) consume(std::integral_constant<u32, 3>{}, u0 + 3u);
+        if constexpr (RING > 2u) {
+            if (u0 + 2u < n_units) consume(std::integral_constant<u32, 2>{}, u0 + 2u);
+        }
+        if constexpr (RING > 3u) {
+            if (u0 + 3u < n_units) consume(std::integral_constant<u32, 3>{}, u0 + 3u);
+        }
     }
     stamp(3);
     __syncthreads();

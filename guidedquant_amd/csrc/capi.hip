@@ -89,3 +89,29 @@ extern "C" int gq_selfcheck(void) {
                                            "-DPL_BOOB=0 -DPL_LOOB=0 -DQT_XOOB=0 (csrc/ap_plane.hip, csrc/qtip.hip).");
     return GQ_OK;
 }
+
+// ---- measurement aid (bench.py `frac_of_stream_floor`): a kernel that only READS `bytes` once (16-byte non-temporal loads, 8 per
+// thread in flight) -- what a one-shot launch of that size can reach on this chip including its launch boundary; the GEMV launches are
+// priced against it next to the 8 TB/s roofline (tools/ubench/stream_read.hip is the stand-alone probe).
+namespace {
+typedef uint32_t gq_u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stream_read_kernel(const gq_u32x4 *p, size_t n16, uint32_t *sink) {
+    const size_t i = (size_t)blockIdx.x * 256u * 8u + threadIdx.x;
+    gq_u32x4 v[8], acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const size_t j = i + (size_t)u * 256u;
+        v[u] = j < n16 ? __builtin_nontemporal_load(p + j) : (gq_u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc ^= v[u];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1u;
+}
+}  // namespace
+extern "C" int gq_debug_stream_read(const void *buf, size_t bytes, uint32_t *sink, void *stream) {
+    if (!buf || !sink || bytes < 16 || ((uintptr_t)buf & 15u)) return gq_fail(GQ_EINVAL, "gq_debug_stream_read: 16-byte aligned buffer of >= 16 bytes.");
+    const size_t n16 = bytes / 16u;
+    hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)((n16 + 2047u) / 2048u)), dim3(256), 0, (hipStream_t)stream, (const gq_u32x4 *)buf, n16, sink);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}

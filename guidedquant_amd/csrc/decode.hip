@@ -347,6 +347,9 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint1
     constexpr u32 NW = ATTN_WAVES;
     constexpr int LPP = HD / 8, PPW = 64 / LPP, U = 4;
     constexpr u32 NS = NW * PPW, PASS = NW * PPW * U;
+    // (the merge and the NaN poisoning below index the block's QH * HD outputs by thread id: a build with fewer waves would silently
+    // leave the upper heads of a group unwritten)
+    static_assert(64 * ATTN_WAVES >= QH * HD, "attn_roped_kernel: the block must have a thread per output of its QH heads (GQ_ATTN_WAVES)");
     float *sc = reinterpret_cast<float *>(smem);  // [QH][2 * NS] running max / sum of the position streams
     float *red2 = sc + (size_t)QH * 2u * NS;      // [QH][NS][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;

@@ -10,6 +10,7 @@
 // No RCCL call, no host round trip per hop (the isend / irecv pair of the default transport costs two host synchronisations).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "gq_internal.h"
 
@@ -32,16 +33,60 @@ __global__ void __launch_bounds__(256) hop_send_kernel(const uint4 *src, uint4 *
     }
 }
 
-__global__ void __launch_bounds__(64) hop_wait_kernel(const u32 *seq_local, const u32 *tick, u32 add, u32 *err, u32 max_spins) {
-    if (threadIdx.x != 0) return;
-    const u32 want = tick[0] + add;
-    for (u32 i = 0; i < max_spins; i++) {
-        if (__hip_atomic_load(seq_local, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return;
-        __builtin_amdgcn_s_sleep(32);
+__global__ void __launch_bounds__(64) hop_wait_kernel(const u32 *seq_local, const u32 *tick, u32 add, u32 *err, u32 max_spins, const u32 *land,
+                                                      u32 *dst, u32 n4) {
+    // one wave: lane 0 polls, then all 64 lanes copy the landed payload (system-scope loads out of the fine-grained landing slot)
+    // into the buffer the stage's kernels read with ordinary cached loads -- they never touch memory a peer writes
+    u32 ok = 0;
+    if (threadIdx.x == 0) {
+        const u32 want = tick[0] + add;
+        for (u32 i = 0; i < max_spins && !ok; i++) {
+            ok = __hip_atomic_load(seq_local, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want;
+            if (!ok) __builtin_amdgcn_s_sleep(32);
+        }
+        if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ok = __shfl(ok, 0, 64);
+    if (!ok || !land) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the payload loads stay behind the word)
+    for (u32 i = threadIdx.x; i < n4; i += 64u) dst[i] = __hip_atomic_load(land + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
+
+// Memory a PEER writes (landing slots, sequence words) must be fine-grained: ordinary hipMalloc memory is coarse-grained -- writes of
+// a peer GPU are not guaranteed visible to (or coherent with the L2s of) kernels running here.  These are allocated
+// with hipDeviceMallocFinegrained and shared through hipIpc handles; only gq_hop_send (peer side) and gq_hop_wait (this side, which
+// copies the payload out) ever touch them.
+extern "C" int gq_hop_alloc(size_t bytes, void **ptr) {
+    if (!ptr || bytes == 0) return gq_fail(GQ_EINVAL, "gq_hop_alloc: null pointer / zero size.");
+    void *p = nullptr;
+    GQ_HIP_CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    GQ_HIP_CHECK(hipMemset(p, 0, bytes));
+    GQ_HIP_CHECK(hipDeviceSynchronize());
+    *ptr = p;
+    return GQ_OK;
+}
+extern "C" int gq_hop_free(void *ptr) {
+    if (ptr) GQ_HIP_CHECK(hipFree(ptr));
+    return GQ_OK;
+}
+extern "C" int gq_hop_export(void *ptr, void *handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    if (!ptr || !handle64) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    GQ_HIP_CHECK(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle64), ptr));
+    return GQ_OK;
+}
+extern "C" int gq_hop_import(const void *handle64, void **ptr) {
+    if (!ptr || !handle64) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    GQ_HIP_CHECK(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return GQ_OK;
+}
+extern "C" int gq_hop_close(void *ptr) {
+    if (ptr) GQ_HIP_CHECK(hipIpcCloseMemHandle(ptr));
+    return GQ_OK;
+}
 
 extern "C" int gq_hop_send(const void *src, void *dst_remote, uint32_t nbytes, uint32_t *seq_remote, const uint32_t *tick, uint32_t add,
                            void *stream) {
@@ -54,8 +99,14 @@ extern "C" int gq_hop_send(const void *src, void *dst_remote, uint32_t nbytes, u
 }
 
 extern "C" int gq_hop_wait(const uint32_t *seq_local, const uint32_t *tick, uint32_t add, uint32_t *err, uint32_t max_spins, void *stream) {
+    return gq_hop_wait_copy(seq_local, tick, add, err, max_spins, nullptr, nullptr, 0, stream);
+}
+extern "C" int gq_hop_wait_copy(const uint32_t *seq_local, const uint32_t *tick, uint32_t add, uint32_t *err, uint32_t max_spins, const void *landed,
+                                void *dst, uint32_t nbytes, void *stream) {
     if (!seq_local || !tick || !err) return gq_fail(GQ_EINVAL, "null pointer argument.");
-    hipLaunchKernelGGL(hop_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seq_local, tick, add, err, max_spins ? max_spins : (1u << 21));
+    if (landed && (!dst || nbytes % 4u || (((uintptr_t)landed | (uintptr_t)dst) & 3u))) return gq_fail(GQ_EINVAL, "gq_hop_wait_copy: 4-byte units.");
+    hipLaunchKernelGGL(hop_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seq_local, tick, add, err, max_spins ? max_spins : (1u << 21),
+                       (const u32 *)landed, (u32 *)dst, landed ? nbytes / 4u : 0u);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

@@ -613,6 +613,7 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     // every block (same arithmetic, same order) and stored once, by block 0, for the kernels that need it later
     // (the residual stream).  One launch and one global round trip less per linear.
     const uint16_t *xg = a.x, *x2g = a.x2;
+    if (PRO == QPRO_PRE && !a.x) xg = reinterpret_cast<const uint16_t *>(L.SU);  // (one pre-transformed vector per linear: gq_qtip_linear_out_in)
     if (a.nprev) {
         uint16_t *xp = reinterpret_cast<uint16_t *>(smem + a.xp_off);  // [nprev][K] fp16
         for (u32 r = 0; r < a.nprev; r++) {
@@ -819,6 +820,97 @@ struct QtipOutArgs {
 __global__ void __launch_bounds__(1024) qtip_linear_out_kernel(QtipOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     qtip_transform_out(a.lin[blockIdx.x], reinterpret_cast<float *>(smem));
+}
+
+// Round 5: transform-out of ONE linear (o or down, residual added) followed by the transform-IN of the linears that consume its
+// output (gate / up, or the next layer's q / k / v) -- block j of the launch repeats the transform-out (only block 0 stores the hidden
+// state) and then runs RMSNorm -> * SU_j -> Hadamard -> * K^-1/2 / 32 -> fp16 for consumer j, leaving that linear's PRE-TRANSFORMED
+// input in memory.  The matvec launch that follows takes it as is (GQ_QPRO_PRETRANSFORMED with one vector per linear): its 256
+// blocks no longer repeat RMSNorm . SU . H each (~5 us of a 15 us launch, profiles/r04_qtip_decode_kernel_trace.txt).  Same
+// element-wise operations, the same butterfly network and the same summation order of the mean of squares (1024 threads, the
+// per-thread unit order of qtip_linear_in_kernel's prologue): the pre-transformed vectors are what that prologue builds.
+struct QtipOutInArgs {
+    QtipOut prev;
+    const uint16_t *normw;
+    float eps, kscale;
+    const float *SU[3];
+    uint16_t *xt[3];
+};
+__global__ void __launch_bounds__(1024) qtip_out_in_kernel(QtipOutInArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float redf[17];
+    const u32 K = a.prev.M, T = blockDim.x, tid = threadIdx.x, j = blockIdx.x;
+    float *v = reinterpret_cast<float *>(smem);                       // [K] fp32 transform buffer
+    uint16_t *hs = reinterpret_cast<uint16_t *>(smem + (size_t)K * 4u);  // [K] fp16: the hidden state this launch produces
+    // the consumer's vectors are requested with the sums (one block: nothing else hides their latency)
+    constexpr u32 NU = 2;  // 8-element units per thread (K <= 16384)
+    float4 su0[NU], su1[NU];
+    uint4 nwq[NU];
+#pragma unroll
+    for (u32 k = 0; k < NU; k++) {
+        const u32 u = tid + k * T;
+        const bool ok = u < K / 8u;
+        su0[k] = ok ? reinterpret_cast<const float4 *>(a.SU[j])[2u * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        su1[k] = ok ? reinterpret_cast<const float4 *>(a.SU[j])[2u * u + 1u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        nwq[k] = ok ? reinterpret_cast<const uint4 *>(a.normw)[u] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    {   // transform-out into LDS (qtip_transform_out's arithmetic; the global store only by block 0)
+        QtipOut P = a.prev;
+        P.out = hs;
+        qtip_transform_out(P, v);
+        __syncthreads();
+        if (j == 0u && a.prev.out)
+            for (u32 u = tid; u < K / 4u; u += T) reinterpret_cast<uint2 *>(a.prev.out)[u] = reinterpret_cast<const uint2 *>(hs)[u];
+    }
+    // transform-in of consumer j: the prologue of qtip_linear_in_kernel<QPRO_RMSNORM>, unit by unit
+    float ss = 0.f;
+    for (u32 u = tid; u < K / 8u; u += T)
+#pragma unroll
+        for (u32 e = 0; e < 8; e++) {
+            const float f = (float)__builtin_bit_cast(h16, hs[8u * u + e]);
+            ss += f * f;
+        }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((tid & 63u) == 0) redf[tid >> 6] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
+    const float nscale = 1.0f / sqrtf(t / (float)K + a.eps);
+#pragma unroll
+    for (u32 k = 0; k < NU; k++) {
+        const u32 u = tid + k * T;
+        if (u < K / 8u) {
+            const uint4 xq = reinterpret_cast<const uint4 *>(hs)[u];
+            const u32 xw[4] = {xq.x, xq.y, xq.z, xq.w}, nw[4] = {nwq[k].x, nwq[k].y, nwq[k].z, nwq[k].w};
+            const float su[8] = {su0[k].x, su0[k].y, su0[k].z, su0[k].w, su1[k].x, su1[k].y, su1[k].z, su1[k].w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                h16 xh = __builtin_bit_cast(h16, (uint16_t)(xw[e >> 1] >> (16 * (e & 1))));
+                xh = (h16)gq_pin_f32((float)xh * nscale) * __builtin_bit_cast(h16, (uint16_t)(nw[e >> 1] >> (16 * (e & 1))));
+                o[e] = (float)xh * su[e];
+            }
+            reinterpret_cast<float4 *>(v)[2u * u] = make_float4(o[0], o[1], o[2], o[3]);
+            reinterpret_cast<float4 *>(v)[2u * u + 1u] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+    __syncthreads();
+    fwht_lds(v, K);
+    const float sc = a.kscale;
+#pragma unroll
+    for (u32 k = 0; k < NU; k++) {
+        const u32 u = tid + k * T;
+        if (u < K / 8u) {
+            const float4 f0 = reinterpret_cast<const float4 *>(v)[2u * u], f1 = reinterpret_cast<const float4 *>(v)[2u * u + 1u];
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            u32 o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = (u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e] * sc) / 32.0f)) |
+                       ((u32)__builtin_bit_cast(uint16_t, (h16)((f[2 * e + 1] * sc) / 32.0f)) << 16);
+            reinterpret_cast<uint4 *>(a.xt[j])[u] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
 }
 
 // The same transform-out spread over M / 128 blocks per linear (gq_qtip_linear_out_seg).  H_M = H_(M / 128) (x) H_128: block `seg`
@@ -1346,7 +1438,7 @@ int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, 
     if (ksplit < 1 || ksplit > 4) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: ksplit must be 1..4.");
     if (!lin || n < 1 || n > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 1..3 linears.");
     if (n_prev < 0 || n_prev > 2 || (n_prev && !prev)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: 0..2 producing linears.");
-    if (n_prev == 0 && !x) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: x is null.");
+    if (n_prev == 0 && !x && prologue != GQ_QPRO_PRETRANSFORMED) return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: x is null.");
     if (n_prev && n_prev != (prologue == GQ_QPRO_SILU_MUL ? 2 : 1))
         return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: one producing linear per input vector (two for SILU_MUL).");
     if (R < 2 || R > 4) return gq_fail(GQ_ENOTSUP, "R (bits per weight) must be 2, 3 or 4 (kernel_check.py:1-14).");
@@ -1373,6 +1465,8 @@ int qtip_linear_in_impl(const void *x, const void *x2, const void *norm_weight, 
     for (int i = 0; i < n; i++) {
         if (!lin[i].trellis || (!lin[i].SU && prologue != GQ_QPRO_PRETRANSFORMED && prologue != 4) || !lin[i].tlut || !lin[i].y32 || lin[i].M == 0 || lin[i].M % 32u)
             return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: null pointer or M not a multiple of 32.");
+        if (prologue == GQ_QPRO_PRETRANSFORMED && !x && (!lin[i].SU || ((uintptr_t)lin[i].SU & 15u)))
+            return gq_fail(GQ_EINVAL, "gq_qtip_linear_in: pre-transformed input without x: every linear's SU field must point to ITS fp16 vector (16-byte aligned).");
         if (((uintptr_t)lin[i].trellis | (uintptr_t)lin[i].tlut) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
         bands[i] = lin[i].M / 32u;
     }
@@ -1527,6 +1621,29 @@ extern "C" int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream) {
     static GqPerDeviceOnce once;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(qtip_linear_out_kernel), 160 * 1024));
     hipLaunchKernelGGL(qtip_linear_out_kernel, dim3((u32)n), dim3(1024), smem, (hipStream_t)stream, a);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+
+extern "C" int gq_qtip_linear_out_in(const GqQtipOut *prev, const void *norm_weight, float eps, int n_next, const float *const *SU_next,
+                                     void *const *xt_next, void *stream) {
+    if (!prev || !norm_weight || !SU_next || !xt_next || n_next < 1 || n_next > 3) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_in: 1..3 consumers, no null pointers.");
+    const u32 K = prev->M;
+    if (!pow2(K) || K < 256u || K > 8192u) return gq_fail(GQ_ENOTSUP, "gq_qtip_linear_out_in: width must be a power of two in 256..8192.");
+    if (!prev->y32 || !prev->SV32 || prev->parts > 4u) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_in: producing linear (y32, SV32, parts <= 4).");
+    if (((uintptr_t)prev->y32 | (uintptr_t)prev->SV32 | (uintptr_t)norm_weight) & 15u || ((uintptr_t)prev->resid | (uintptr_t)prev->out) & 7u)
+        return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_in: buffers must be 16-byte (fp16 vectors: 8-byte) aligned.");
+    QtipOutInArgs a{};
+    a.prev = QtipOut{prev->y32, prev->SV32, (const uint16_t *)prev->resid, (uint16_t *)prev->out, K, (float)pow((double)K, -0.5), prev->parts ? prev->parts : 1u};
+    a.normw = (const uint16_t *)norm_weight;
+    a.eps = eps;
+    a.kscale = (float)pow((double)K, -0.5);
+    for (int i = 0; i < n_next; i++) {
+        if (!SU_next[i] || !xt_next[i] || (((uintptr_t)SU_next[i] | (uintptr_t)xt_next[i]) & 15u)) return gq_fail(GQ_EINVAL, "gq_qtip_linear_out_in: consumer vectors (16-byte aligned).");
+        a.SU[i] = SU_next[i];
+        a.xt[i] = (uint16_t *)xt_next[i];
+    }
+    hipLaunchKernelGGL(qtip_out_in_kernel, dim3((unsigned)n_next), dim3(1024), (size_t)K * 6u, (hipStream_t)stream, a);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

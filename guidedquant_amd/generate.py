@@ -64,6 +64,35 @@ def decode_one_token(model: Transformer, x: torch.Tensor, input_pos: torch.Tenso
     return sample(logits, **sampling_kwargs)
 
 
+_graph_rng_primed = False
+_prime_graph = None
+
+
+def prime_graph_rng_state(device=None):
+    """The FIRST graph capture of a process creates the default generator's graph-safe state tensors; created under
+    torch.inference_mode() (transformers' generate captures there) they are inference tensors, and every later capture outside
+    inference mode fails ("Inplace update to inference tensor outside InferenceMode").  One tiny capture outside inference mode, before
+    anybody else captures, makes them ordinary tensors, which both kinds of capture may update."""
+    global _graph_rng_primed
+    if _graph_rng_primed or not torch.cuda.is_available() or torch.is_inference_mode_enabled() or torch.cuda.is_current_stream_capturing():
+        return
+    _graph_rng_primed = True
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        t = torch.zeros(1, device="cuda")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                t.add_(1.0)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        # the graph is KEPT: the state tensors live as long as a graph is registered with the generator -- with none left, the next
+        # capture (possibly under inference mode) would create them anew
+        global _prime_graph
+        _prime_graph = (g, t)
+
+
 class DecodeGraph:
     """One captured hipGraph of `decode_one_token` with static token / position / output tensors
     (the manual-graph path of generate.py:95-113)."""
@@ -78,6 +107,7 @@ class DecodeGraph:
         writing `self.tok` directly is only valid without the fold.
         seq_capacity > 0: the sampler also stores every token at `self.seq[pos + 1]` (int32 [seq_capacity]); `self.ban` (int32
         {n, until_pos, id0..id3}) lists tokens that cannot be drawn while pos < until_pos (HF's min_new_tokens on EOS)."""
+        prime_graph_rng_state(device)
         self.model = model
         self.native_sampling = bool(native_sampling) and model.native_ready() and (sampling_kwargs.get("top_k") or 0) <= 64 \
             and sampling_kwargs.get("top_k") is not None

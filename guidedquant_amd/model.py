@@ -667,6 +667,43 @@ class Transformer(nn.Module):
                 d["d"] = [("gq_qtip_mlp_mid", (ctypes.pointer(mid), ks_gu, n_mlp, Kf)),
                           ("gq_qtip_linear_in_rows", (st["z32"].data_ptr(), n_mlp, 64, a_in[6], 1, a_in[8], a_in[11]))] + d["d"][2:]
             layers.append(d)
+        # Round 5 (GQ_QTIP_PRE=1; default OFF -- measured 421 vs 427 tokens/s on Llama-2-7b, profiles/r05_qtip_pre.txt: the one-block
+        # launch grows by more than the 256-block launch shrinks, whose prologue ran under its first tile requests anyway): the
+        # transform-out launch of wo / down ALSO runs the transform-in of the linears that read
+        # its output through an RMSNorm -- gate / up, the next layer's q / k / v -- one block per consumer (gq_qtip_linear_out_in), and
+        # their matvec launch takes the pre-transformed vectors as they are: its 256 blocks no longer repeat RMSNorm . SU . Hadamard.
+        # Needs power-of-two widths on that edge and the plain launch forms (no folding, no one-launch form).
+        st["xt"] = torch.zeros(3, c.dim, dtype=torch.float16, device=dev)
+        pre_on = os.environ.get("GQ_QTIP_PRE", "0") != "0" and not fold and not one_launch and 256 <= c.dim <= 8192 and (c.dim & (c.dim - 1)) == 0
+
+        def with_pre(plan_out, plan_in, normw, mods):
+            """(plan of the producer with its last launch -- the transform-out -- replaced, plan of the consumers' matvec launch on the
+            pre-transformed vectors), or None when the launches are not of the plain form"""
+            if not (pre_on and plan_out and plan_in and plan_out[-1][0] in ("gq_qtip_linear_out", "gq_qtip_linear_out_seg") and plan_out[-1][1][0] == 1
+                    and plan_in[0][0] == "gq_qtip_linear_in" and plan_in[0][1][4] == 1 and plan_in[0][1][9] == 0
+                    and all(m.K_left == 1 and m.in_features == c.dim for m in mods)):
+                return None
+            desc = plan_out[-1][1][1]  # GqQtipOut array of one element
+            n = len(mods)
+            su = (ctypes.c_void_p * n)(*[f32(m.SU) for m in mods])
+            xt = (ctypes.c_void_p * n)(*[st["xt"][i].data_ptr() for i in range(n)])
+            a_in = plan_in[0][1]  # (xp, x2p, normw, eps, pro, K, R, n, arr, 0, None, ks)
+            arr = (_lib.GqQtipIn * n)(*[_lib.GqQtipIn(a_in[8][i].trellis, st["xt"][i].data_ptr(), a_in[8][i].tlut, a_in[8][i].y32, a_in[8][i].M) for i in range(n)])
+            keep.extend([su, xt, arr])
+            return (plan_out[:-1] + [("gq_qtip_linear_out_in", (desc, normw, c.norm_eps, n, su, xt))],
+                    [("gq_qtip_linear_in", (None, None, None, 0.0, 3, a_in[5], a_in[6], n, arr, 0, None, a_in[11]))] + plan_in[1:])
+
+        for li, (d, b) in enumerate(zip(layers, self.layers)):
+            at, ff = b.attention, b.feed_forward
+            r = with_pre(d["o"], d["gu"], b.post_attention_layernorm.weight.data_ptr(), [ff.w1, ff.w3])
+            if r is not None:
+                d["o"], d["gu"] = r
+            d["d_pre"] = d["qkv_pre"] = None
+        for li in range(len(layers) - 1):
+            nb = self.layers[li + 1]
+            r = with_pre(layers[li]["d"], layers[li + 1]["qkv"], nb.input_layernorm.weight.data_ptr(), [nb.attention.wq, nb.attention.wk, nb.attention.wv])
+            if r is not None and layers[li]["d_out"] is None:
+                layers[li]["d_pre"], layers[li + 1]["qkv_pre"] = r
         st["qtip_layers"] = layers
         st["qtip_keep"] = keep
 
@@ -690,9 +727,12 @@ class Transformer(nn.Module):
                 ck(getattr(L, name)(*args, sp), name)
 
         pending = None  # transform-out of the previous layer's down projection, not yet run
+        pre_in = False  # the previous layer's down launch left this layer's q / k / v inputs pre-transformed
         for li in range(l0, l1):
             d, at = b["qtip_layers"][li], self.layers[li].attention
-            if pending is not None and d["qkv_f"] is not None:
+            if pre_in:
+                run(d["qkv_pre"])
+            elif pending is not None and d["qkv_f"] is not None:
                 run(d["qkv_f"])  # (rebuilds and stores the hidden state itself)
             else:
                 if pending is not None:
@@ -710,7 +750,8 @@ class Transformer(nn.Module):
                                           b["attn_ws"].data_ptr() if b["attn_ws"] is not None else None, sp), "attn")
             run(d["o"])
             run(d["gu"])
-            run(d["d"])
+            pre_in = li + 1 < l1 and d["d_pre"] is not None
+            run(d["d_pre"] if pre_in else d["d"])
             pending = d["d_out"]
         if pending is not None:
             run(pending)

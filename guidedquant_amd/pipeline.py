@@ -140,51 +140,93 @@ class PipelinedDecoder:
 
     # -- device-to-device hops (hop="ipc") ------------------------------------------------------------------------
     def _setup_ipc(self, max_new_tokens):
-        """sequence words, tick counters, and the peers' buffers mapped into this process"""
-        from torch.multiprocessing.reductions import reduce_tensor
-        S, dev = self.n_seq, self.dev
-        self.seq_h = torch.zeros(S, dtype=torch.int32, device=dev)     # incoming hidden state of slot s carries tick number seq_h[s]
-        self.seq_tok = torch.ones(S, dtype=torch.int32, device=dev)    # (stage 0) incoming token ...; 1 = the BOS token of tick 1
+        """sequence words, tick counters, and the peers' landing slots mapped into this process.  Everything a PEER writes -- the
+        landing slots of the hidden states / tokens and the sequence words -- is FINE-GRAINED memory of this stage's device
+        (gq_hop_alloc: ordinary allocations are coarse-grained, a peer GPU's writes to them are not guaranteed visible to the kernels
+        running here), shared through hipIpc handles; gq_hop_wait_copy moves a landed payload into the ordinary buffers the stage's
+        kernels read (`self.h`, `self._tok4`)."""
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        S, dev, c = self.n_seq, self.dev, self.model.config
+        self.max_new_tokens = max_new_tokens
         self.tick = torch.zeros(S, dtype=torch.int32, device=dev)      # ticks of slot s completed on this stage
         self.tick64 = torch.zeros(S, dtype=torch.int64, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         self.out_buf = torch.zeros(S, max_new_tokens + 1, dtype=torch.int32, device=dev)
         self.spins = int(os.environ.get("GQ_HOP_SPINS", str(1 << 21)))
+        # one fine-grained block: [landing slots of h: S x dim fp16][landing slots of tokens: S x 16 B][seq_h: S words][seq_tok: S words]
+        hb, tb = S * c.dim * 2, S * 16
+        self._fg_layout = dict(h=0, tok=hb, seq_h=hb + tb, seq_tok=hb + tb + 4 * S)
+        nbytes = hb + tb + 8 * S
+        with torch.cuda.device(dev):
+            p = ctypes.c_void_p()
+            _lib.check(L.gq_hop_alloc(nbytes, ctypes.byref(p)), "gq_hop_alloc")
+            self._fg = int(p.value)
+            handle = (ctypes.c_ubyte * 64)()
+            _lib.check(L.gq_hop_export(self._fg, handle), "gq_hop_export")
+
+        class _Raw:  # a torch view of raw device memory (CUDA array interface): reset() writes the words with tensor ops
+            def __init__(r, ptr, n):
+                r.__cuda_array_interface__ = dict(shape=(n, ), typestr="<i4", data=(ptr, False), version=2)
+        self.seq_h = torch.as_tensor(_Raw(self._fg + self._fg_layout["seq_h"], S), device=dev)      # incoming hidden state of slot s carries tick seq_h[s]
+        self.seq_tok = torch.as_tensor(_Raw(self._fg + self._fg_layout["seq_tok"], S), device=dev)  # (stage 0) incoming token ...
+        self.seq_tok.fill_(1)                                                                        # 1 = the BOS token of tick 1
         torch.cuda.synchronize()
-        mine = {k: reduce_tensor(t) for k, t in (("h", self.h), ("seq_h", self.seq_h), ("tok", self._tok4), ("seq_tok", self.seq_tok))}
         allh = [None] * self.world
-        dist.all_gather_object(allh, mine, group=self.group)
-
-        def open_(rank_, key):
-            fn, args = allh[rank_][key]
-            return fn(*args)
-
-        self._peer = {}
-        if not self.last:
-            self._peer["h"], self._peer["seq_h"] = open_(self.rank + 1, "h"), open_(self.rank + 1, "seq_h")
+        dist.all_gather_object(allh, dict(handle=bytes(handle), pid=os.getpid(), dev=torch.cuda.get_device_properties(dev).name), group=self.group)
+        self._peer_map = None
+        peer = self.rank + 1 if not self.last else 0
+        if allh[peer]["pid"] == os.getpid():
+            base = self._fg  # (a one-stage pipeline sends to itself)
         else:
-            self._peer["tok"], self._peer["seq_tok"] = open_(0, "tok"), open_(0, "seq_tok")
+            with torch.cuda.device(dev):
+                q = ctypes.c_void_p()
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(allh[peer]["handle"])
+                _lib.check(L.gq_hop_import(buf, ctypes.byref(q)), "gq_hop_import")
+            base = self._peer_map = int(q.value)
+        self._peer = dict(h=base + self._fg_layout["h"], tok=base + self._fg_layout["tok"], seq_h=base + self._fg_layout["seq_h"],
+                          seq_tok=base + self._fg_layout["seq_tok"])
         dist.barrier(group=self.group)  # every mapping is open before anybody may free or reuse
+
+    def close_ipc(self):
+        """unmap the peer's slots and free this stage's (after a barrier of the caller's: nobody may still be sending)"""
+        from . import _lib
+        if getattr(self, "_peer_map", None):
+            _lib.lib().gq_hop_close(self._peer_map)
+            self._peer_map = None
+        if getattr(self, "_fg", None):
+            self.seq_h = self.seq_tok = None
+            _lib.lib().gq_hop_free(self._fg)
+            self._fg = None
 
     def _tick_ipc(self, slot: int):
         from . import _lib
         L, st = _lib.lib(), _lib.current_stream_ptr()
         tick = self.tick[slot:slot + 1]
-        seq = self.seq_tok if self.first else self.seq_h
-        _lib.check(L.gq_hop_wait(seq[slot:slot + 1].data_ptr(), tick.data_ptr(), 1, self.err.data_ptr(), self.spins, st), "gq_hop_wait")
-        self._tick_native(slot)
         c = self.model.config
+        lay, hb = self._fg_layout, c.dim * 2
+        if self.first:  # the token of the tick lands in the token slot; copied into the row the embedding lookup reads
+            _lib.check(L.gq_hop_wait_copy(self._fg + lay["seq_tok"] + 4 * slot, tick.data_ptr(), 1, self.err.data_ptr(), self.spins,
+                                          self._fg + lay["tok"] + 16 * slot, self._tok4[slot].data_ptr(), 16, st), "gq_hop_wait")
+        else:
+            _lib.check(L.gq_hop_wait_copy(self._fg + lay["seq_h"] + 4 * slot, tick.data_ptr(), 1, self.err.data_ptr(), self.spins,
+                                          self._fg + lay["h"] + hb * slot, self.h[slot].data_ptr(), hb, st), "gq_hop_wait")
+        self._tick_native(slot)
         if not self.last:
-            _lib.check(L.gq_hop_send(self.h[slot].data_ptr(), self._peer["h"][slot].data_ptr(), c.dim * 2, self._peer["seq_h"][slot:slot + 1].data_ptr(),
+            _lib.check(L.gq_hop_send(self.h[slot].data_ptr(), self._peer["h"] + hb * slot, hb, self._peer["seq_h"] + 4 * slot,
                                      tick.data_ptr(), 1, st), "gq_hop_send")
         else:
             self.out_buf[slot].index_copy_(0, self.tick64[slot:slot + 1], self.tok_out[slot:slot + 1])
-            _lib.check(L.gq_hop_send(self._tok_out4[slot].data_ptr(), self._peer["tok"][slot].data_ptr(), 16, self._peer["seq_tok"][slot:slot + 1].data_ptr(),
+            _lib.check(L.gq_hop_send(self._tok_out4[slot].data_ptr(), self._peer["tok"] + 16 * slot, 16, self._peer["seq_tok"] + 4 * slot,
                                      tick.data_ptr(), 2, st), "gq_hop_send")
         tick.add_(1)
         self.tick64[slot:slot + 1].add_(1)
 
     def _run_ipc(self, n_tokens: int) -> torch.Tensor:
+        if n_tokens > self.max_new_tokens:
+            raise ValueError(f"run({n_tokens}): the pipeline was built for max_new_tokens = {self.max_new_tokens}")
+        self.reset()  # ticks, sequence words and the output index start over: a run never continues the previous one's counters
         torch.cuda.synchronize()
         dist.barrier(group=self.group)  # every stage has reset its sequence words
         for _ in range(n_tokens):
@@ -287,6 +329,13 @@ class PipelinedDecoder:
             self.seq_tok.fill_(1)
             self._tok4.zero_()
             self._tok4[:, 0] = self.bos_id
+            if self.first:  # the landing slot of the token of tick 1 (its word already says "arrived"): BOS
+                class _Raw:
+                    def __init__(r, ptr, n):
+                        r.__cuda_array_interface__ = dict(shape=(n, ), typestr="<i4", data=(ptr, False), version=2)
+                land = torch.as_tensor(_Raw(self._fg + self._fg_layout["tok"], 4 * self.n_seq), device=self.dev).view(self.n_seq, 4)
+                land.zero_()
+                land[:, 0] = self.bos_id
 
     def _tick(self, slot: int):
         if self.graphs is not None:

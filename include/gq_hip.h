@@ -232,6 +232,14 @@ int gq_qtip_linear_out(int n, const GqQtipOut *lin, void *stream);
  * fp32 rounding (the additions of the full transform in another order), 2.9 instead of 4.6 us per launch in the decode step.
  * M a power of two in 128..8192, sums 16-byte aligned (GQ_ENOTSUP / GQ_EINVAL else). */
 int gq_qtip_linear_out_seg(int n, const GqQtipOut *lin, void *stream);
+/* Round 5: gq_qtip_linear_out of ONE linear (o or down; residual added, prev->out written once) FOLLOWED IN THE SAME LAUNCH by the
+ * transform-in of the n_next <= 3 linears that read its output through an RMSNorm (gate / up; the next layer's q / k / v): block j
+ * leaves xt_next[j] = half(H(RMSNorm(out) * SU_next[j]) * K^-1/2 / 32), fp16 [K] -- the vector gq_qtip_linear_in's RMSNorm prologue
+ * would build in every one of its blocks (BitshiftLinear.forward, inference/lib/codebook/bitshift.py:441-447; RMSNorm of
+ * inference/model.py:281-292).  The matvec launch then runs with GQ_QPRO_PRETRANSFORMED and x == NULL: every GqQtipIn.SU field
+ * points to ITS pre-transformed vector.  K = prev->M a power of two in 256..8192. */
+int gq_qtip_linear_out_in(const GqQtipOut *prev, const void *norm_weight, float eps, int n_next, const float *const *SU_next,
+                          void *const *xt_next, void *stream);
 int gq_qtip_plan_ksplit(int n, const uint32_t *M, uint32_t K, int max_ksplit); /* host-side helper, launches nothing */
 /*
  * gq_qtip_linear_in + gq_qtip_linear_out in ONE launch: the block that finishes a linear LAST (a device-scope counter per
@@ -397,11 +405,26 @@ int gq_attn_decode_split(const void *qkv, const int *pos, const void *cos_table,
  */
 int gq_hop_send(const void *src, void *dst_remote, uint32_t nbytes, uint32_t *seq_remote, const uint32_t *tick, uint32_t add, void *stream);
 int gq_hop_wait(const uint32_t *seq_local, const uint32_t *tick, uint32_t add, uint32_t *err, uint32_t max_spins, void *stream);
+/* Round 5: what a PEER writes -- landing slots and sequence words -- lives in FINE-GRAINED device memory (ordinary
+ * allocations are coarse-grained: a peer GPU's writes are not guaranteed visible to kernels running here).  gq_hop_alloc: zeroed
+ * fine-grained memory of the current device; gq_hop_export / gq_hop_import: a 64-byte hipIpc handle of it / the mapping in another
+ * process; gq_hop_close, gq_hop_free.  gq_hop_wait_copy = gq_hop_wait, then the payload is copied out of the landing slot with
+ * system-scope loads into `dst`, the ordinary buffer the stage's kernels read: no kernel but these two touches peer-written memory. */
+int gq_hop_alloc(size_t bytes, void **ptr);
+int gq_hop_free(void *ptr);
+int gq_hop_export(void *ptr, void *handle64);
+int gq_hop_import(const void *handle64, void **ptr);
+int gq_hop_close(void *ptr);
+int gq_hop_wait_copy(const uint32_t *seq_local, const uint32_t *tick, uint32_t add, uint32_t *err, uint32_t max_spins, const void *landed,
+                     void *dst, uint32_t nbytes, void *stream);
 
 /* One-time device self-check of a hardware behaviour the plane / QTIP kernels rest on (an LDS read beyond the workgroup's
  * allocation returns zeros: the idle MFMA columns take their zeros from there).  GQ_OK, or GQ_ENOTSUP with the rebuild flags in
  * gq_last_error().  The Python binding calls it once per process on a GPU box. */
 int gq_selfcheck(void);
+/* Measurement aid: one launch that only reads `bytes` of `buf` once (the one-shot streaming floor bench.py prices the GEMV launches
+ * against: `frac_of_stream_floor`).  sink: one device word (never written in practice). */
+int gq_debug_stream_read(const void *buf, size_t bytes, uint32_t *sink, void *stream);
 
 /*
  * Round 4: RoPE and the KV-cache write in the EPILOGUE of the fused q / k / v projection, attention without them.

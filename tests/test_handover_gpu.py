@@ -148,8 +148,8 @@ def test_decode_step_with_and_without_the_handover():
     from guidedquant_amd.generate import random_init_
     from guidedquant_amd.model import ModelArgs, Transformer
     dev = torch.device("cuda:0")
-    args = ModelArgs(block_size=256, vocab_size=4096, n_layer=3, n_head=32, dim=4096, intermediate_size=14336, n_local_heads=8, rope_base=500000.0)
-    model = Transformer(torch.float16, args, linear_class=APLinear, linear_kwargs=dict(bitwidth=2, device=dev), fuse_linears=True).to(dev).eval()
+    args = ModelArgs(block_size=256, vocab_size=4096, n_layer=3, n_head=32, dim=4096, intermediate_size=14336, n_local_heads=8, rope_base=500000.0, model_name="llama-test")
+    model = Transformer(torch.float16, args, linear_class=APLinear, linear_kwargs=dict(bitwidth=2, device=dev), fuse_linears=True).to(device=dev, dtype=torch.float16).eval()
     random_init_(model, seed=3)
     model.setup_caches(1, 64)
     assert model._handover_plan(model.layers[0]) == dict(qkv_in=False, w13=False, w2_out=True)  # off by default (measured slower)

@@ -257,6 +257,56 @@ def test_folded_transform_out_is_bit_identical():
             assert torch.equal(stored[i].view(torch.int16), outs[i].view(torch.int16))
 
 
+@pytest.mark.parametrize("K,parts", [(4096, 1), (4096, 2), (1024, 1), (8192, 1)])
+def test_transform_out_with_the_consumers_transform_in_is_bit_identical(K, parts):
+    """gq_qtip_linear_out_in (round 5): the transform-out of a producer (+ residual) and, in the same launch, the RMSNorm -> SU -> Hadamard
+    prologue of the three linears that read it; their matvec launch on the pre-transformed vectors (GQ_QPRO_PRETRANSFORMED, one vector
+    per linear) gives the SAME sums, bit for bit, as gq_qtip_linear_out followed by gq_qtip_linear_in with the RMSNorm prologue, and
+    the stored hidden state is the same"""
+    import ctypes
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    R = 2
+    prod = _rand_qlinear(2048, K, R, seed=31 + K)
+    cons = [_rand_qlinear(K, m, R, seed=40 + i) for i, m in enumerate((K, 1024, 1024))]
+    g = torch.Generator(device="cpu").manual_seed(5 + parts)
+    xin = torch.randn(2048, generator=g).half().to(d)
+    resid = torch.randn(K, generator=g).half().to(d)
+    normw = (1 + 0.2 * torch.randn(K, generator=g)).half().to(d)
+    st = _lib.current_stream_ptr()
+    su_p, sv_p = prod.SU.float().contiguous(), (prod.SV.float() * 32).contiguous()
+    y32 = torch.zeros(parts * K, dtype=torch.float32, device=d)
+    pin = (_lib.GqQtipIn * 1)(_lib.GqQtipIn(prod.trellis.data_ptr(), su_p.data_ptr(), prod.tlut.data_ptr(), y32.data_ptr(), K))
+    _lib.check(L.gq_qtip_linear_in(xin.data_ptr(), None, None, 0.0, 0, 2048, R, 1, pin, 0, None, parts, st), "producer")
+    su_c = [m.SU.float().contiguous() for m in cons]
+    # two launches: transform-out, then the consumers with their RMSNorm prologue
+    h_ref = torch.zeros(K, dtype=torch.float16, device=d)
+    pout = (_lib.GqQtipOut * 1)(_lib.GqQtipOut(y32.data_ptr(), sv_p.data_ptr(), resid.data_ptr(), h_ref.data_ptr(), K, parts))
+    _lib.check(L.gq_qtip_linear_out(1, pout, st), "out")
+    y_ref = [torch.full((m.out_features,), float("nan"), dtype=torch.float32, device=d) for m in cons]
+    cin = (_lib.GqQtipIn * 3)(*[_lib.GqQtipIn(m.trellis.data_ptr(), su_c[i].data_ptr(), m.tlut.data_ptr(), y_ref[i].data_ptr(), m.out_features)
+                                for i, m in enumerate(cons)])
+    _lib.check(L.gq_qtip_linear_in(h_ref.data_ptr(), None, normw.data_ptr(), 1e-5, 1, K, R, 3, cin, 0, None, 1, st), "consumers")
+    # one launch for transform-out + the three transform-ins, then the bare matvecs
+    h = torch.full((K,), float("nan"), dtype=torch.float16, device=d)
+    xt = [torch.full((K,), float("nan"), dtype=torch.float16, device=d) for _ in cons]
+    pout2 = (_lib.GqQtipOut * 1)(_lib.GqQtipOut(y32.data_ptr(), sv_p.data_ptr(), resid.data_ptr(), h.data_ptr(), K, parts))
+    sup = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in su_c])
+    xtp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in xt])
+    _lib.check(L.gq_qtip_linear_out_in(pout2, normw.data_ptr(), 1e-5, 3, sup, xtp, st), "out_in")
+    y_new = [torch.full((m.out_features,), float("nan"), dtype=torch.float32, device=d) for m in cons]
+    cpre = (_lib.GqQtipIn * 3)(*[_lib.GqQtipIn(m.trellis.data_ptr(), xt[i].data_ptr(), m.tlut.data_ptr(), y_new[i].data_ptr(), m.out_features)
+                                 for i, m in enumerate(cons)])
+    _lib.check(L.gq_qtip_linear_in(None, None, None, 0.0, 3, K, R, 3, cpre, 0, None, 1, st), "pre-transformed")
+    torch.cuda.synchronize()
+    assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16))
+    for a, b in zip(y_new, y_ref):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    assert L.gq_qtip_linear_out_in(pout2, normw.data_ptr(), 1e-5, 4, sup, xtp, st) != 0   # at most 3 consumers
+    assert L.gq_qtip_linear_in(None, None, None, 0.0, 1, K, R, 3, cpre, 0, None, 1, st) != 0  # x == NULL only with the pre-transformed form
+
+
 @pytest.mark.parametrize("M,K", [(4096, 4096), (2048, 8192), (1024, 1024)])
 def test_split_k_and_pretransformed_input(M, K):
     """ksplit = 2 (two blocks per band, partial sums added by gq_qtip_linear_out with parts = 2) agrees with ksplit = 1 to

@@ -1601,6 +1601,7 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
     // epilogue (out[n] = out[n] + y2[n], every element read and written by the same lane).  Two fp16 roundings instead
     // of one; plain and residual epilogues only.
     if (K > 32768u || K % 256u || pro != PRO_NONE || pairs) return GQ_ENOTSUP;
+    if (ho && ho->dry) return GQ_OK;  // (plan only: the chained / K-split forms have no hand-over form, and nothing may be launched)
     if (ws && M == 1u) {  // with a workspace: K split over blocks, one fp16 rounding (ap_stream.hip)
         const int rc = gq_stream_gemv_ksplit(x, out, qweight, lut, N, K, bits, resid, ws, ws_bytes, stream);
         if (rc != GQ_ENOTSUP) return rc;

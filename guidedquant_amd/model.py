@@ -774,6 +774,8 @@ class Transformer(nn.Module):
         L = _lib.lib()
         c, at, ff = self.config, blk.attention, blk.feed_forward
         on = os.environ.get("GQ_SSQ_HANDOVER", "0") != "0"
+        if not on:
+            return dict(qkv_in=False, w13=False, w2_out=False)
         qkv_in = on and bool(L.gq_anyprec_handover_plan(at.wqkv.out_features, c.dim, at.wqkv.bitwidth, 1, 0) & 1)
         w13_in = on and bool(L.gq_anyprec_handover_plan(2 * c.intermediate_size, c.dim, ff.w1w3.bitwidth, 1, 4) & 1)
         wo_out = bool(L.gq_anyprec_handover_plan(c.dim, c.dim, at.wo.bitwidth, 0, 1) & 2)

@@ -414,12 +414,13 @@ def ap_roofline(model, bits, mode_arg):
     # HBM bytes per launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
     # tools/prof_bench.sh) for one kernel template, launch form and shape -- reported only when this run launches the same
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r04_w1w3_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            t = json.load(f)
-        if (not exact and t.get("bits") == bits and t.get("N") == 2 * I and t.get("K") == D and t.get("launch") == ("norm_pairs" if paired else "norm")):
-            traffic, traffic_src = t.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/r04_w1w3_traffic.json)" % t.get("kernel")
+    for tname in ("r05_w1w3_traffic.json", "r04_w1w3_traffic.json"):  # (the newest committed passes of this kernel template)
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if traffic is None and os.path.exists(tpath):
+            with open(tpath) as f:
+                t = json.load(f)
+            if (not exact and t.get("bits") == bits and t.get("N") == 2 * I and t.get("K") == D and t.get("launch") == ("norm_pairs" if paired else "norm")):
+                traffic, traffic_src = t.get("hbm_bytes_per_launch"), "offline PMC passes of %s (profiles/%s)" % (t.get("kernel"), tname)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "AP-GEMV w1w3 %dx%d %d-bit, RMSNorm prologue%s (%s kernels)" % (2 * I, D, bits, " + gate/up pair epilogue" if paired else "",

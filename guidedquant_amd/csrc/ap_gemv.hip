@@ -73,16 +73,32 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
                                         uint16_t *xlds, float *red /* >= 16 floats of LDS */, bool stager, u32 T) {
     const u32 tid = threadIdx.x;
     float scale = 0.f;
+    // RMSNorm (round 5): ONE memory round trip.  A stager thread requests the activations AND the norm weights of its first item (32
+    // activations: 4 + 4 sixteen-byte loads) up front, takes the sum of squares from those registers, and normalises from them behind
+    // the barrier.  The first version read x, reduced, and only then requested x again together with the norm weights -- a layer
+    // weight that comes from HBM: two extra round trips, +2.1 us (3 bits) / +3.3 us (4 bits) on the 8B wqkv launch against the plain one
+    // (bench.py roofline_by_shape, round 5).  Items beyond the first (K > 16 T) are re-read as before.
+    u32 in0[4][4], nw0[4][4];
+    const u32 idx0 = stager ? tid : 4u * G.Q;
     if constexpr (PRO == PRO_RMSNORM) {
         float ss = 0.f;
-        for (u32 g = stager ? tid : G.K; g < G.K / 8u; g += T) {
-            uint4 v = ld16(x + 8u * g);
-            const u32 w[4] = {v.x, v.y, v.z, v.w};
+        for (u32 idx = idx0; idx < 4u * G.Q; idx += T) {
+            const u32 e0 = G.xindex(idx >> 2, 0u, idx & 3u, 0u);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float a = h2f(w[i] & 0xFFFF), b = h2f(w[i] >> 16);
-                ss += a * a;
-                ss += b * b;
+            for (int v = 0; v < 4; v++) {
+                const uint4 t4 = ld16(x + e0 + 8 * v);
+                const u32 w[4] = {t4.x, t4.y, t4.z, t4.w};
+                if (idx == idx0) {
+                    const uint4 n4 = ld16(normw + e0 + 8 * v);
+                    in0[v][0] = t4.x, in0[v][1] = t4.y, in0[v][2] = t4.z, in0[v][3] = t4.w;
+                    nw0[v][0] = n4.x, nw0[v][1] = n4.y, nw0[v][2] = n4.z, nw0[v][3] = n4.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float a = h2f(w[i] & 0xFFFF), b = h2f(w[i] >> 16);
+                    ss += a * a;
+                    ss += b * b;
+                }
             }
         }
 #pragma unroll
@@ -93,20 +109,22 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
         for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
         scale = 1.0f / sqrtf(tot / (float)G.K + eps);
     }
-    for (u32 idx = stager ? tid : 4u * G.Q; idx < 4u * G.Q; idx += T) {
+    for (u32 idx = idx0; idx < 4u * G.Q; idx += T) {
         const u32 q = idx >> 2, c = idx & 3u;
         const u32 e0 = G.xindex(q, 0u, c, 0u);  // 32 consecutive activations: v = 0..3, j = 0..7
         u32 in[4][4];
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            uint4 t4 = ld16(x + e0 + 8 * v);
-            in[v][0] = t4.x;
-            in[v][1] = t4.y;
-            in[v][2] = t4.z;
-            in[v][3] = t4.w;
             if constexpr (PRO == PRO_RMSNORM) {
-                uint4 n4 = ld16(normw + e0 + 8 * v);
-                const u32 nw[4] = {n4.x, n4.y, n4.z, n4.w};
+                u32 nw[4];
+                if (idx == idx0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) in[v][i] = in0[v][i], nw[i] = nw0[v][i];
+                } else {
+                    const uint4 t4 = ld16(x + e0 + 8 * v), n4 = ld16(normw + e0 + 8 * v);
+                    in[v][0] = t4.x, in[v][1] = t4.y, in[v][2] = t4.z, in[v][3] = t4.w;
+                    nw[0] = n4.x, nw[1] = n4.y, nw[2] = n4.z, nw[3] = n4.w;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     uint16_t a = f2h(gq_pin_f32(h2f(in[v][i] & 0xFFFF) * scale)), b = f2h(gq_pin_f32(h2f(in[v][i] >> 16) * scale));
@@ -114,11 +132,18 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
                     _Float16 rb = __builtin_bit_cast(_Float16, b) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] >> 16));
                     in[v][i] = (u32)__builtin_bit_cast(uint16_t, ra) | ((u32)__builtin_bit_cast(uint16_t, rb) << 16);
                 }
-            } else if constexpr (PRO == PRO_SILUMUL) {
-                uint4 u4 = ld16(x + G.K + e0 + 8 * v);
-                const u32 uw[4] = {u4.x, u4.y, u4.z, u4.w};
+            } else {
+                uint4 t4 = ld16(x + e0 + 8 * v);
+                in[v][0] = t4.x;
+                in[v][1] = t4.y;
+                in[v][2] = t4.z;
+                in[v][3] = t4.w;
+                if constexpr (PRO == PRO_SILUMUL) {
+                    uint4 u4 = ld16(x + G.K + e0 + 8 * v);
+                    const u32 uw[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
-                for (int i = 0; i < 4; i++) in[v][i] = silu_mul_pk(in[v][i], uw[i]);
+                    for (int i = 0; i < 4; i++) in[v][i] = silu_mul_pk(in[v][i], uw[i]);
+                }
             }
         }
 #pragma unroll

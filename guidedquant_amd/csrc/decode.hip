@@ -648,6 +648,34 @@ struct SampleEx {
     float *ssq_out;
 };
 
+// what both draw kernels do with the token: outputs, token / position feedback, the sequence store
+__device__ __forceinline__ void sample_publish(int tokc, u32 ctr, int *counter, int *tok_io, int *pos_io, int *next_tok, const SampleEx &ex) {
+    next_tok[0] = tokc;
+    counter[0] = (int)(ctr + 1u);
+    if (tok_io) tok_io[0] = tokc;
+    const int p = pos_io ? pos_io[0] : 0;
+    if (ex.seq_out && (u32)(p + 1) < ex.seq_cap) ex.seq_out[p + 1] = tokc;
+    if (pos_io) pos_io[0] = p + 1;
+}
+// the next step's hidden state: tok_embeddings[token] (+ the statistics hand-over for layer 0's RMSNorm); 1024 threads
+__device__ __forceinline__ void sample_embed(int chosen, u32 tid, const SampleEx &ex) {
+    u32 tk = (u32)chosen;
+    if (tk >= ex.vocab) tk = 0;
+    float acc = 0.f;
+    for (u32 i = tid; i < ex.dim / 8u; i += 1024u) {
+        const uint4 v = reinterpret_cast<const uint4 *>(ex.emb_table + (size_t)tk * ex.dim)[i];
+        gq_store_wt(reinterpret_cast<uint4 *>(ex.x_out) + i, v);
+        const u32 wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float a = (float)__builtin_bit_cast(_Float16, (uint16_t)(wd[k] & 0xFFFFu)), b = (float)__builtin_bit_cast(_Float16, (uint16_t)(wd[k] >> 16));
+            acc += a * a;
+            acc += b * b;
+        }
+    }
+    if (ex.ssq_out) gq_store_wt(ex.ssq_out + tid, acc);  // (1024 threads = GQ_SSQ_SLOTS)
+}
+
 // stage 1: each of the 128 blocks selects the top KM of its slice (<= 1024 logits, 4 per thread in registers); KM = 32 or 64
 template <int KM>
 __global__ void __launch_bounds__(256) sample_stage1(const uint16_t *logits, u32 V, float *cand_val, int *cand_idx, const int *ban, const int *pos_io) {
@@ -752,32 +780,77 @@ __global__ void __launch_bounds__(1024) sample_stage2(const float *cand_val, con
             if (os > score || (os == score && ot < tokc)) { score = os; tokc = ot; }
         }
         if (l == 0) {
-            next_tok[0] = tokc;
-            counter[0] = (int)(ctr + 1u);
-            if (tok_io) tok_io[0] = tokc;
-            const int p = pos_io ? pos_io[0] : 0;
-            if (ex.seq_out && (u32)(p + 1) < ex.seq_cap) ex.seq_out[p + 1] = tokc;
-            if (pos_io) pos_io[0] = p + 1;
+            sample_publish(tokc, ctr, counter, tok_io, pos_io, next_tok, ex);
             chosen = tokc;
         }
     }
-    if (ex.x_out) {  // the next step's hidden state: tok_embeddings[token] (+ the statistics hand-over for layer 0's RMSNorm)
+    if (ex.x_out) {
         __syncthreads();
-        u32 tk = (u32)chosen;
-        if (tk >= ex.vocab) tk = 0;
-        float acc = 0.f;
-        for (u32 i = tid; i < ex.dim / 8u; i += 1024u) {
-            const uint4 v = reinterpret_cast<const uint4 *>(ex.emb_table + (size_t)tk * ex.dim)[i];
-            gq_store_wt(reinterpret_cast<uint4 *>(ex.x_out) + i, v);
-            const u32 wd[4] = {v.x, v.y, v.z, v.w};
+        sample_embed(chosen, tid, ex);
+    }
+}
+
+// Greedy draw (temperature <= 0: the arg-max logit, ties to the lowest index -- torch.argmax / HF do_sample=False; the race above
+// also picks the arg-max at T -> 0 and differs only on EXACT ties) in ONE launch of one block: every thread keeps the largest key
+// of its 16-byte units of the logits (250 KiB at a 128 K vocabulary: ~1.8 us through one CU), DPP-free wave maxima by shuffles,
+// 16 wave results through LDS.  Replaces the two selection launches (5.0 + 11.5 us in the round-4 trace) for the benchmark's and
+// the HF greedy route's sampling settings.
+__global__ void __launch_bounds__(1024) sample_greedy_kernel(const uint16_t *logits, u32 V, int *counter, int *tok_io, int *pos_io, int *next_tok,
+                                                             SampleEx ex) {
+    __shared__ unsigned long long wmax[16];
+    __shared__ int chosen;
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    int nban = 0, bid[4] = {-1, -1, -1, -1};
+    if (ex.ban) {
+        nban = ex.ban[0];
+        if (pos_io && pos_io[0] >= ex.ban[1]) nban = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float a = (float)__builtin_bit_cast(_Float16, (uint16_t)(wd[k] & 0xFFFFu)), b = (float)__builtin_bit_cast(_Float16, (uint16_t)(wd[k] >> 16));
-                acc += a * a;
-                acc += b * b;
-            }
+        for (int i = 0; i < 4; i++) bid[i] = i < nban ? ex.ban[2 + i] : -1;
+    }
+    unsigned long long best = 0ull;
+    auto take = [&](uint16_t h, u32 gi) {
+        const bool banned = (int)gi == bid[0] || (int)gi == bid[1] || (int)gi == bid[2] || (int)gi == bid[3];
+        const unsigned long long k = ((unsigned long long)ordered_key16(h) << 17) | (unsigned long long)(131071u - gi);
+        if (!banned && k > best) best = k;
+    };
+    const u32 n8 = V / 8u;
+    // all of a thread's 16-byte units are requested before the first is looked at (vocab <= 131072: at most 16 per thread) -- a
+    // loop that waits for each load pays the memory latency 16 times (measured: 21 us for the launch)
+    uint4 v[16];
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+        const u32 u = tid + 1024u * k;
+        v[k] = u < n8 ? reinterpret_cast<const uint4 *>(logits)[u] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+        const u32 u = tid + 1024u * k;
+        if (u < n8) {
+            const u32 wd[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (u32 e = 0; e < 8; e++) take((uint16_t)(wd[e >> 1] >> (16u * (e & 1u))), 8u * u + e);
         }
-        if (ex.ssq_out) gq_store_wt(ex.ssq_out + tid, acc);  // (1024 threads = GQ_SSQ_SLOTS)
+    }
+    for (u32 gi = 8u * n8 + tid; gi < V; gi += 1024u) take(logits[gi], gi);
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const u32 lo = (u32)__shfl_xor((int)(u32)best, sh, 64), hi = (u32)__shfl_xor((int)(u32)(best >> 32), sh, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        if (o > best) best = o;
+    }
+    if (l == 0) wmax[w] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = wmax[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) b = wmax[i] > b ? wmax[i] : b;
+        const int tokc = b ? (int)(131071u - (u32)(b & 131071ull)) : 0;
+        sample_publish(tokc, (u32)counter[0], counter, tok_io, pos_io, next_tok, ex);
+        chosen = tokc;
+    }
+    if (ex.x_out) {
+        __syncthreads();
+        sample_embed(chosen, tid, ex);
     }
 }
 
@@ -793,38 +866,54 @@ __global__ void __launch_bounds__(256) dense_gemv_kernel(const uint16_t *x, cons
     float *red = reinterpret_cast<float *>(xs + K);
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
     float nscale = 1.f;
+    // (round 5: x and the norm weights of a thread's first two units are requested together and kept -- the weights are a layer
+    // tensor that comes from HBM; requested only behind the sum of squares they cost the launch a second memory round trip)
+    constexpr u32 NPRE = 2;
+    uint4 xpre[NPRE], npre[NPRE];
+    auto sq8 = [&](const uint4 &v, float &ss) {
+        const u32 ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float a = h2f(ww[i] & 0xFFFF), b = h2f(ww[i] >> 16);
+            ss += a * a;
+            ss += b * b;
+        }
+    };
+    auto norm8 = [&](uint4 v, const uint4 &nv) {
+        u32 ww[4] = {v.x, v.y, v.z, v.w};
+        const u32 nw[4] = {nv.x, nv.y, nv.z, nv.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const h16 a = (h16)gq_pin_f32(h2f(ww[i] & 0xFFFF) * nscale) * u2h((uint16_t)(nw[i] & 0xFFFF));
+            const h16 b = (h16)gq_pin_f32(h2f(ww[i] >> 16) * nscale) * u2h((uint16_t)(nw[i] >> 16));
+            ww[i] = (u32)h2u(a) | ((u32)h2u(b) << 16);
+        }
+        return make_uint4(ww[0], ww[1], ww[2], ww[3]);
+    };
     if (normw) {
         float ss = 0.f;
-        for (u32 g = tid; g < K / 8u; g += 256) {
-            const uint4 v = reinterpret_cast<const uint4 *>(x)[g];
-            const u32 ww[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float a = h2f(ww[i] & 0xFFFF), b = h2f(ww[i] >> 16);
-                ss += a * a;
-                ss += b * b;
-            }
+        for (u32 k = 0; k < NPRE; k++) {
+            const u32 g = tid + 256u * k;
+            xpre[k] = g < K / 8u ? reinterpret_cast<const uint4 *>(x)[g] : make_uint4(0u, 0u, 0u, 0u);
+            npre[k] = g < K / 8u ? reinterpret_cast<const uint4 *>(normw)[g] : make_uint4(0u, 0u, 0u, 0u);
         }
+#pragma unroll
+        for (u32 k = 0; k < NPRE; k++) sq8(xpre[k], ss);  // (units beyond K are zero)
+        for (u32 g = tid + 256u * NPRE; g < K / 8u; g += 256) sq8(reinterpret_cast<const uint4 *>(x)[g], ss);
         ss = wave_reduce<false>(ss);
         if (l == 0) red[w] = ss;
         __syncthreads();
         nscale = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
-    }
-    for (u32 g = tid; g < K / 8u; g += 256) {
-        uint4 v = reinterpret_cast<const uint4 *>(x)[g];
-        if (normw) {
-            const uint4 nv = reinterpret_cast<const uint4 *>(normw)[g];
-            u32 ww[4] = {v.x, v.y, v.z, v.w};
-            const u32 nw[4] = {nv.x, nv.y, nv.z, nv.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const h16 a = (h16)gq_pin_f32(h2f(ww[i] & 0xFFFF) * nscale) * u2h((uint16_t)(nw[i] & 0xFFFF));
-                const h16 b = (h16)gq_pin_f32(h2f(ww[i] >> 16) * nscale) * u2h((uint16_t)(nw[i] >> 16));
-                ww[i] = (u32)h2u(a) | ((u32)h2u(b) << 16);
-            }
-            v = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        for (u32 k = 0; k < NPRE; k++) {
+            const u32 g = tid + 256u * k;
+            if (g < K / 8u) reinterpret_cast<uint4 *>(xs)[g] = norm8(xpre[k], npre[k]);
         }
-        reinterpret_cast<uint4 *>(xs)[g] = v;
+        for (u32 g = tid + 256u * NPRE; g < K / 8u; g += 256)
+            reinterpret_cast<uint4 *>(xs)[g] = norm8(reinterpret_cast<const uint4 *>(x)[g], reinterpret_cast<const uint4 *>(normw)[g]);
+    } else {
+        for (u32 g = tid; g < K / 8u; g += 256) reinterpret_cast<uint4 *>(xs)[g] = reinterpret_cast<const uint4 *>(x)[g];
     }
     __syncthreads();
     const u32 row_begin = blockIdx.x * rows_per_block;
@@ -1023,6 +1112,11 @@ int sample_launch(const void *logits, uint32_t vocab, int top_k, float temperatu
     const u32 per = (vocab + SAMP_BLOCKS - 1) / SAMP_BLOCKS;
     if (per > 1024u || vocab > 131072u) return gq_fail(GQ_ENOTSUP, "vocab too large for the fused sampler (<= 131072).");
     hipStream_t s = (hipStream_t)stream;
+    if (temperature <= 0.f && ((uintptr_t)logits & 15u) == 0 && gq_env_int("GQ_SAMPLE_GREEDY", 1)) {  // greedy: one launch (sample_greedy_kernel)
+        hipLaunchKernelGGL(sample_greedy_kernel, dim3(1), dim3(1024), 0, s, (const uint16_t *)logits, vocab, counter, tok_io, pos_io, next_tok, ex);
+        GQ_HIP_CHECK(hipGetLastError());
+        return GQ_OK;
+    }
     if (top_k <= 32) {
         hipLaunchKernelGGL(sample_stage1<32>, dim3(SAMP_BLOCKS), dim3(256), 0, s, (const uint16_t *)logits, vocab, work_val, work_idx, ex.ban, pos_io);
         hipLaunchKernelGGL(sample_stage2<32>, dim3(1), dim3(1024), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok, ex);

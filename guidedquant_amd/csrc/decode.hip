@@ -790,69 +790,9 @@ __global__ void __launch_bounds__(1024) sample_stage2(const float *cand_val, con
     }
 }
 
-// Greedy draw (temperature <= 0: the arg-max logit, ties to the lowest index -- torch.argmax / HF do_sample=False; the race above
-// also picks the arg-max at T -> 0 and differs only on EXACT ties) in ONE launch of one block: every thread keeps the largest key
-// of its 16-byte units of the logits (250 KiB at a 128 K vocabulary: ~1.8 us through one CU), DPP-free wave maxima by shuffles,
-// 16 wave results through LDS.  Replaces the two selection launches (5.0 + 11.5 us in the round-4 trace) for the benchmark's and
-// the HF greedy route's sampling settings.
-__global__ void __launch_bounds__(1024) sample_greedy_kernel(const uint16_t *logits, u32 V, int *counter, int *tok_io, int *pos_io, int *next_tok,
-                                                             SampleEx ex) {
-    __shared__ unsigned long long wmax[16];
-    __shared__ int chosen;
-    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
-    int nban = 0, bid[4] = {-1, -1, -1, -1};
-    if (ex.ban) {
-        nban = ex.ban[0];
-        if (pos_io && pos_io[0] >= ex.ban[1]) nban = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) bid[i] = i < nban ? ex.ban[2 + i] : -1;
-    }
-    unsigned long long best = 0ull;
-    auto take = [&](uint16_t h, u32 gi) {
-        const bool banned = (int)gi == bid[0] || (int)gi == bid[1] || (int)gi == bid[2] || (int)gi == bid[3];
-        const unsigned long long k = ((unsigned long long)ordered_key16(h) << 17) | (unsigned long long)(131071u - gi);
-        if (!banned && k > best) best = k;
-    };
-    const u32 n8 = V / 8u;
-    // all of a thread's 16-byte units are requested before the first is looked at (vocab <= 131072: at most 16 per thread) -- a
-    // loop that waits for each load pays the memory latency 16 times (measured: 21 us for the launch)
-    uint4 v[16];
-#pragma unroll
-    for (u32 k = 0; k < 16; k++) {
-        const u32 u = tid + 1024u * k;
-        v[k] = u < n8 ? reinterpret_cast<const uint4 *>(logits)[u] : make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (u32 k = 0; k < 16; k++) {
-        const u32 u = tid + 1024u * k;
-        if (u < n8) {
-            const u32 wd[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-            for (u32 e = 0; e < 8; e++) take((uint16_t)(wd[e >> 1] >> (16u * (e & 1u))), 8u * u + e);
-        }
-    }
-    for (u32 gi = 8u * n8 + tid; gi < V; gi += 1024u) take(logits[gi], gi);
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-        const u32 lo = (u32)__shfl_xor((int)(u32)best, sh, 64), hi = (u32)__shfl_xor((int)(u32)(best >> 32), sh, 64);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        if (o > best) best = o;
-    }
-    if (l == 0) wmax[w] = best;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long b = wmax[0];
-#pragma unroll
-        for (int i = 1; i < 16; i++) b = wmax[i] > b ? wmax[i] : b;
-        const int tokc = b ? (int)(131071u - (u32)(b & 131071ull)) : 0;
-        sample_publish(tokc, (u32)counter[0], counter, tok_io, pos_io, next_tok, ex);
-        chosen = tokc;
-    }
-    if (ex.x_out) {
-        __syncthreads();
-        sample_embed(chosen, tid, ex);
-    }
-}
+// (Round 5, measured and removed: a ONE-launch greedy draw -- one 1024-thread block keeps the largest key of its 16-byte units of the
+// logits -- for temperature 0.  21 us with a load loop, no better than the two launches above with all 16 loads of a thread in flight
+// (865.6 / 864.1 against 867.9 / 868.3 tokens/s): one CU takes the 250 KiB of logits slower than 128 blocks + one do.)
 
 // ------------------------------------------------------------------------------------------------ dense fp16 GEMV
 // out[n] = sum_k x[k] * W[n][k], fp32 accumulation (v_dot2_f32_f16), fp16 output -- what nn.Linear(fp16) gives at M = 1.
@@ -1112,11 +1052,6 @@ int sample_launch(const void *logits, uint32_t vocab, int top_k, float temperatu
     const u32 per = (vocab + SAMP_BLOCKS - 1) / SAMP_BLOCKS;
     if (per > 1024u || vocab > 131072u) return gq_fail(GQ_ENOTSUP, "vocab too large for the fused sampler (<= 131072).");
     hipStream_t s = (hipStream_t)stream;
-    if (temperature <= 0.f && ((uintptr_t)logits & 15u) == 0 && gq_env_int("GQ_SAMPLE_GREEDY", 1)) {  // greedy: one launch (sample_greedy_kernel)
-        hipLaunchKernelGGL(sample_greedy_kernel, dim3(1), dim3(1024), 0, s, (const uint16_t *)logits, vocab, counter, tok_io, pos_io, next_tok, ex);
-        GQ_HIP_CHECK(hipGetLastError());
-        return GQ_OK;
-    }
     if (top_k <= 32) {
         hipLaunchKernelGGL(sample_stage1<32>, dim3(SAMP_BLOCKS), dim3(256), 0, s, (const uint16_t *)logits, vocab, work_val, work_idx, ex.ban, pos_io);
         hipLaunchKernelGGL(sample_stage2<32>, dim3(1), dim3(1024), 0, s, work_val, work_idx, top_k, temperature, seed, counter, tok_io, pos_io, next_tok, ex);

@@ -438,7 +438,7 @@ struct QuadCfg {
 
 int num_cus() { return gq_cu_count(); }
 
-bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
+bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c, int pro = PRO_NONE) {
     if (K % 128u) return false;
     const u32 Q = K / 128u;
     if (Q > 512u) return false;
@@ -468,7 +468,12 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c) {
     if (bits == 4 && d > 3) d = 3;
     // persistent-style grid: about `bpc` blocks per CU (what the kernel's occupancy allows), every block the same number of steps
     const u32 cus = (u32)num_cus();
-    u32 bpc = (u32)gq_env_int("GQ_AP_BPC", bits <= 3 && d == 1 ? 3 : 2);
+    u32 bpc_def = bits <= 3 && d == 1 ? 3u : 2u;
+    // a block of an RMSNorm launch normalises the whole vector before its first step: with ONE step per block (few rows: wqkv) the
+    // 2-3 resident blocks of a CU repeat that side by side -- one block per CU then (measured, 8B wqkv: 3-bit 8.8 -> 8.4 us, 4-bit
+    // 11.9 -> 11.0; the large matrices keep the deeper grid: w1w3 exact 2-bit 17.2 vs 21.9 us with one block per CU)
+    if (pro == PRO_RMSNORM && steps <= cus * bpc_def) bpc_def = 1u;
+    u32 bpc = (u32)gq_env_int("GQ_AP_BPC", (int)bpc_def);
     if (bpc < 1) bpc = 1;
     u32 target = cus * bpc;
     u32 spb = (steps + target - 1) / target;
@@ -597,7 +602,7 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
     }
     if (ho && ho->dry) return GQ_OK;  // (the exact-mode kernels have no hand-over form)
     const uint64_t qbytes = (uint64_t)bits * a.N * (a.K / 8u);
-    if (!force_generic && bits <= 4 && qbytes < 0x7FFFFFFFull && pick_quad_cfg(a.N, a.K, bits, c) &&
+    if (!force_generic && bits <= 4 && qbytes < 0x7FFFFFFFull && pick_quad_cfg(a.N, a.K, bits, c, pro) &&
         (((uintptr_t)a.qw | (uintptr_t)a.x | (uintptr_t)a.normw) & 15u) == 0 && ((uintptr_t)a.lut & 15u) == 0 &&
         !((a.epilogue & GQ_EPI_SILU_PAIRS) && ((c.SPB * c.RS) & 1u))) {
         a.RS = c.RS;

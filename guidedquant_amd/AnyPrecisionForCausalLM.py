@@ -198,8 +198,6 @@ class AnyPrecisionForCausalLM(nn.Module):
         ids = args[0] if args else kwargs.get("input_ids", kwargs.get("inputs"))
         if not torch.is_tensor(ids) or ids.dim() != 2 or ids.shape[0] != 1 or ids.shape[1] < 1 or ids.is_floating_point():
             return None, "input_ids must be one sequence of token ids, [1, T]"
-        if self.device.type != "cuda":
-            return None, "the fused routes need the GPU"
         gc_ = getattr(self.model, "generation_config", None)
         g = (lambda name, dflt=None: kwargs[name] if kwargs.get(name) is not None else (getattr(gc_, name, dflt) if gc_ is not None and getattr(gc_, name, None) is not None else dflt))
         if g("num_beams", 1) != 1 or g("num_return_sequences", 1) != 1 or g("return_dict_in_generate", False) or g("use_cache", True) is False:
@@ -257,6 +255,8 @@ class AnyPrecisionForCausalLM(nn.Module):
         capture = kwargs.pop('capture', None)
         try:
             req, why = self._route_request(args, kwargs) if (native is not False or capture is True) else (None, "opted out")
+            if req is not None and self.device.type != "cuda":
+                req, why = None, "the fused routes need the GPU"
             if native is True and req is None:
                 raise ValueError("native=True: " + why)
             if req is not None and native is not False:
@@ -306,8 +306,10 @@ class AnyPrecisionForCausalLM(nn.Module):
         graph = self._native_cache.get(("graph",) + key)
         if graph is None:
             self._native_cache = {k: v for k, v in self._native_cache.items() if k[0] != "graph"}
+            # (the sampler's counter-based generator is seeded from torch's: torch.manual_seed() makes a run reproducible; the counter
+            # runs on across calls, so two sampled calls differ)
             graph = gen.DecodeGraph(dec, self.device, native_sampling=True, fold_embed=True, seq_capacity=dec.max_seq_length + 1,
-                                    temperature=req["temperature"], top_k=req["top_k"])
+                                    seed=int(torch.initial_seed() & 0x7FFFFFFF), temperature=req["temperature"], top_k=req["top_k"])
             self._native_cache[("graph",) + key] = graph
         ids32 = ids.view(-1).to(torch.int32)
         with torch.inference_mode():
@@ -365,13 +367,14 @@ class AnyPrecisionForCausalLM(nn.Module):
                           pos=torch.zeros((1, ), dtype=torch.int32, device=dev), nxt=torch.zeros((1, ), dtype=torch.int32, device=dev),
                           ctr=torch.zeros((1, ), dtype=torch.int32, device=dev), wv=torch.zeros(128 * 64, dtype=torch.float32, device=dev),
                           wi=torch.zeros(128 * 64, dtype=torch.int32, device=dev), ban=torch.zeros(6, dtype=torch.int32, device=dev),
-                          seq=torch.zeros(total + 1, dtype=torch.int32, device=dev), logits=torch.zeros(V, dtype=torch.float16, device=dev))
+                          seq=torch.zeros(total + 1, dtype=torch.int32, device=dev), logits=torch.zeros(V, dtype=torch.float16, device=dev),
+                          seed=int(torch.initial_seed() & 0x7FFFFFFF))
 
                 def step():
                     # (positions come from the cache itself: StaticLayer.cumulative_length is a device word the layer advances in place)
                     out = self.model(input_ids=st["tok64"], past_key_values=st["cache"], use_cache=True)
                     st["logits"].copy_(out.logits.view(-1))
-                    _lib.check(_lib.lib().gq_sample_topk_ex(st["logits"].data_ptr(), V, req["top_k"], float(req["temperature"]), 1234,
+                    _lib.check(_lib.lib().gq_sample_topk_ex(st["logits"].data_ptr(), V, req["top_k"], float(req["temperature"]), st["seed"],
                                                            st["ctr"].data_ptr(), st["wv"].data_ptr(), st["wi"].data_ptr(), st["tok"].data_ptr(),
                                                            st["pos"].data_ptr(), st["nxt"].data_ptr(), st["ban"].data_ptr(), st["seq"].data_ptr(),
                                                            st["seq"].numel(), None, None, 0, None, _lib.current_stream_ptr()), "gq_sample_topk_ex")

@@ -18,8 +18,8 @@ from .model import ModelArgs, Transformer
 
 def model_args_from_hf_config(cfg: dict) -> ModelArgs:
     """Llama `config.json` -> ModelArgs (inference/model.py:27-51 field meanings)."""
-    name = cfg.get("_name_or_path") or cfg.get("model_type", "llama")
-    if "llama" not in name.lower():
+    name = os.path.basename(str(cfg.get("_name_or_path") or cfg.get("model_type", "llama")).rstrip("/")) or "llama"
+    if "llama" not in name.lower():  # (the block layout is Llama's whatever the checkpoint directory is called)
         name = "llama-" + name
     return ModelArgs(block_size=int(cfg.get("max_position_embeddings", 8192)), vocab_size=int(cfg["vocab_size"]),
                      n_layer=int(cfg["num_hidden_layers"]), n_head=int(cfg["num_attention_heads"]), dim=int(cfg["hidden_size"]),

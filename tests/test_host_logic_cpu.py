@@ -350,3 +350,35 @@ def test_anyprecision_for_causal_lm_from_quantized_on_cpu(tmp_path):
     assert m2.ap_linears[0].qweight.shape[0] == 2 and not hasattr(m2.ap_linears[0], "lut3")
     nat = m2.native_decoder()
     assert nat.layers[0].attention.wqkv.bitwidth == 2 and nat.layers[0].attention.wqkv.qweight.shape == (2, D + 2 * KV * hd, D // 32)
+
+
+def test_generate_routes_the_reference_call_and_declines_the_rest(tmp_path):
+    """AnyPrecisionForCausalLM._route_request (host logic of the HF surface, round 5): the reference's own generate call
+    (inference_example.py:44-67: do_sample, temperature 1, top_p 1, pad_token_id, attention_mask of ones, static cache, streamer; top_k
+    left to the generation config = 50) is one the fused decode route serves; beams, top_p < 1, batches, masked positions, processors
+    and unknown keywords go to transformers' generate"""
+    pytest.importorskip("transformers")
+    import torch
+    from ap_helpers import tiny_hf_anyprec_checkpoint
+    from guidedquant_amd.AnyPrecisionForCausalLM import AnyPrecisionForCausalLM
+    tiny_hf_anyprec_checkpoint(tmp_path)
+    m = AnyPrecisionForCausalLM.from_quantized(str(tmp_path), device="cpu")
+    ids = torch.tensor([[3, 17, 5]])
+    req, why = m._route_request((ids, ), dict(max_new_tokens=20, min_new_tokens=20, do_sample=True, temperature=1.0, top_p=1.0, pad_token_id=0,
+                                              attention_mask=torch.ones_like(ids), cache_implementation="static", streamer=object()))
+    assert why is None and req["T"] == 3 and req["max_new"] == 20 and req["min_new"] == 20 and req["top_k"] == 50 and req["temperature"] == 1.0
+    req, _ = m._route_request((), dict(input_ids=ids, max_new_tokens=4, do_sample=False, eos_token_id=[7, 9]))
+    assert req["top_k"] == 1 and req["temperature"] == 0.0 and req["eos"] == [7, 9] and req["min_new"] == 0
+    req, _ = m._route_request((ids, ), dict(max_length=10))
+    assert req["max_new"] == 7
+    for kw in (dict(max_new_tokens=4, do_sample=True, top_p=0.9), dict(max_new_tokens=4, num_beams=2), dict(max_new_tokens=4, do_sample=True, top_k=100),
+               dict(max_new_tokens=4, repetition_penalty=1.2), dict(max_new_tokens=4, logits_processor=[]), dict(max_new_tokens=4, eos_token_id=[1, 2, 3, 4, 5]),
+               dict(max_new_tokens=4, attention_mask=torch.tensor([[0, 1, 1]])), dict(), dict(max_new_tokens=0)):
+        req, why = m._route_request((ids, ), kw)
+        assert req is None and why, kw
+    assert m._route_request((torch.tensor([[1, 2], [3, 4]]), ), dict(max_new_tokens=4))[0] is None   # a batch
+    # on a host model the request is declined at the device check and transformers' generate runs
+    out = m.generate(ids, max_new_tokens=3, do_sample=False, pad_token_id=0)
+    assert out.shape == (1, 6)
+    with pytest.raises(ValueError):
+        m.generate(ids, max_new_tokens=3, do_sample=False, native=True)

@@ -542,13 +542,13 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     float *part = red + 64u * MBA + 2u * hot_cap;     // [item][batch row][subset][16 rows]
     const u32 rg0 = blockIdx.x * a.RGB;
     auto stamp = [&](int i) {
-        if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
+        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
     };
     stamp(0);
     if (a.xflags & 32u) return;
     const bool early = w < E;
     auto stamp2 = [&](int i) {  // finer stamps of the prologue (second table of tools/phase_timing.py)
-        if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[128u + w * 16u + (u32)i] = __builtin_readcyclecounter();
+        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[128u + w * 16u + (u32)i] = __builtin_readcyclecounter();
     };
 
     // ---------------------------------------------------------------- 0. activation loads, then the first tiles
@@ -1059,7 +1059,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     const u32 my_steps = items_w * cpi;
     const u32 chunk0 = (w & (CS - 1u)) * cpi;
     auto stamp = [&](int i) {
-        if (a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
+        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
     };
     stamp(0);
     // A wave that is still building its image shares its SIMD with older waves already in their main loops; instruction issue is

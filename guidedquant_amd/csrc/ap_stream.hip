@@ -305,7 +305,7 @@ constexpr u32 META_W = 16u;
 #define ST_PF 2
 #endif
 #ifndef ST_KO
-#define ST_KO 0   // build-time knock-outs, WRONG numerics, timing only (bit mask): 1 no sum-of-squares exchange, 8 no image reads
+#define ST_KO 0   // build-time knock-outs, WRONG numerics, timing only (bit mask): 1 no sum-of-squares exchange, 8 no image reads, 16 the activations arrive as 4 fp32 partial vectors (loads only)
 #endif
 #ifndef ST_TAU_SCALE
 #define ST_TAU_SCALE 1  // a unit's power of two from its extraction threshold (what stays in the image is <= tau) instead of its maximum:
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // phase stamps (tools/phase_timing.py): kept in LDS and written out at the very end -- a global store per stamp sits in
     // vmcnt and turns the next wait for a load into a wait for the store's acknowledgement (~1,000 cycles each)
     unsigned long long *dbgl = reinterpret_cast<unsigned long long *>(smem + a.dbg_off) + w * 24u;
-    const bool dbg_on = a.dbg && blockIdx.x == gridDim.x / 2;
+    const bool dbg_on = GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2;
     auto stamp = [&](int i) {
         if (dbg_on && l == 0) dbgl[i] = __builtin_readcyclecounter();
     };
@@ -425,6 +425,16 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
             if constexpr (PRO == PRO_RMSNORM) nv[n] = bload128<0>(rsn, voff, xs0);
             if constexpr (PRO == PRO_SILUMUL) nv[n] = bload128<0>(rsx, voff, xs0 + 2u * a.Kx);
         }
+#if ST_KO & 16  // probe: the activations as 4 fp32 partial vectors (8 more 16-byte loads per lane, the same 64 KiB for every block)
+        {
+            const rsrc_t rsp = make_rsrc(a.qw, 65536u);
+            u32x4 pv[8];
+#pragma unroll
+            for (u32 i = 0; i < 8u; i++) pv[i] = bload128<0>(rsp, (w * 64u + l) * 32u + 16u * (i & 1u), 16384u * (i >> 1));
+#pragma unroll
+            for (u32 i = 0; i < 8u; i++) asm volatile("" ::"v"(pv[i]));
+        }
+#endif
     }
     stamp2(0);
     // the LUT rows of the block: thread T - 1 - i takes row i (the waves that start last and have the least to do); the

@@ -353,7 +353,11 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint1
     float *sc = reinterpret_cast<float *>(smem);  // [QH][2 * NS] running max / sum of the position streams
     float *red2 = sc + (size_t)QH * 2u * NS;      // [QH][NS][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+#ifdef GQ_ATTN_PROBE  // timing probe (tools/r5): blockIdx.y = identical copies of the whole-group form, every copy writes the same outputs
+    const u32 h0 = blockIdx.x * QH, g = h0 / (H / Hkv), sp = 0u;
+#else
     const u32 h0 = blockIdx.x * QH, g = h0 / (H / Hkv), sp = blockIdx.y;
+#endif
     const u32 sub = l / LPP, ld = l % LPP;
     const uint16_t *kcg = kc + (size_t)g * max_seq * HD, *vcg = vc + (size_t)g * max_seq * HD;
     // requests that do not depend on the position: q, and (blocks that may start at row 0) the first batch of cached rows
@@ -988,9 +992,25 @@ extern "C" int gq_attn_decode_roped(const void *q, const int *pos, const void *k
     hipStream_t s = (hipStream_t)stream;
     // grouped-query models with a split cache: the 4 query heads of a KV group in one block (every cached row loaded once)
     const bool gqa = n_split >= 4u && (n_head / n_kv_head) % 4u == 0u && gq_env_int("GQ_ATTN_GQA", 1);  // (8 heads per group: two blocks of 4)
+#ifdef GQ_ATTN_PROBE
+    const u32 copies = (u32)gq_env_int("GQ_ATTN_PROBE_COPIES", 0);
+    const bool gqa_p = copies > 0u;
+    const u32 qh = gqa_p || gqa ? 4u : 1u;
+    const size_t smem = (size_t)qh * ((size_t)2u * nstreams + (size_t)nstreams * head_dim + nstreams + 1u) * 4u;
+    const dim3 grid(n_head / qh, gqa_p ? copies : n_split);
+    if (gqa_p) {
+        static GqPerDeviceOnce once;
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(attn_roped_kernel<128, 4>), 160 * 1024));
+        hipLaunchKernelGGL((attn_roped_kernel<128, 4>), grid, dim3(64 * ATTN_WAVES), smem, s, (const uint16_t *)q, pos, (const uint16_t *)k_cache,
+                           (const uint16_t *)v_cache, (uint16_t *)out, n_head, n_kv_head, max_seq, scale, 1u, workspace);
+        GQ_HIP_CHECK(hipGetLastError());
+        return GQ_OK;
+    }
+#else
     const u32 qh = gqa ? 4u : 1u;
     const size_t smem = (size_t)qh * ((size_t)2u * nstreams + (size_t)nstreams * head_dim + nstreams + 1u) * 4u;
     const dim3 grid(n_head / qh, n_split);
+#endif
 #define GQ_LAUNCH_ROPED(HD_, QH_)                                                                                                    \
     do {                                                                                                                             \
         static GqPerDeviceOnce once;                                                                                                 \

@@ -39,6 +39,14 @@ struct GqPerDeviceOnce {
     }
 };
 
+// Phase stamps (tools/phase_timing.py, qtip_phase_timing.py, qtip_mid_timing.py: per-wave shader-clock timestamps into a debug buffer)
+// are compiled OUT of the shipped library: even switched off at run time every stamp site costs a wave two or three scalar
+// instructions and a branch on its critical path (the stream kernel's prologue alone had ~20 sites).  A library with the sites:
+//   tools/build_variant.sh stamps ap_stream.hip -DGQ_STAMPS=1   (one translation unit per variant; select with GQ_LIB_PATH)
+#ifndef GQ_STAMPS
+#define GQ_STAMPS 0
+#endif
+
 #if defined(__HIPCC__)
 // `(half)(a * b)` on floats: the compiler folds the conversion into v_fma_mixlo_f16, which rounds the EXACT product once.
 // The reference's torch ops round the fp32 product first and convert then (two roundings; they differ on fp16 ties of the

@@ -206,7 +206,7 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     u32 dq[PF][LD];
     u32 nstamp = 0;
     auto stamp = [&]() {
-        if (dbg && blockIdx.x == gridDim.x / 2 && l == 0 && nstamp < 8u) dbg[w * 8u + nstamp++] = __builtin_readcyclecounter();
+        if (GQ_STAMPS && dbg && blockIdx.x == gridDim.x / 2 && l == 0 && nstamp < 8u) dbg[w * 8u + nstamp++] = __builtin_readcyclecounter();
     };
     stamp();
     u32 j = blockIdx.x;
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     }
     u32 pst = 0;
     auto pstamp = [&]() {
-        if (a.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63u) == 0 && pst < 8u) a.dbg[128u + (tid >> 6) * 8u + pst++] = __builtin_readcyclecounter();
+        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63u) == 0 && pst < 8u) a.dbg[128u + (tid >> 6) * 8u + pst++] = __builtin_readcyclecounter();
     };
     auto prologue = [&]() {
         pstamp();
@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(MID_T) qtip_mlp_mid_kernel(QtipMidArgs a) {
     const u32 w = __builtin_amdgcn_readfirstlane(tid >> 6), r0 = 4u * (tid & 63u);
     u32 nst = 0;
     auto stamp = [&]() {
-        if (a.dbg && blockIdx.x == 32u && (tid & 63u) == 0u && nst < 8u) a.dbg[w * 8u + nst++] = __builtin_readcyclecounter();
+        if (GQ_STAMPS && a.dbg && blockIdx.x == 32u && (tid & 63u) == 0u && nst < 8u) a.dbg[w * 8u + nst++] = __builtin_readcyclecounter();
     };
     stamp();
     // ---- requests.  First what stage 1 needs (the sums of the previous launch: the long latency), then the constants.

@@ -1,4 +1,6 @@
-"""Per-wave phase timestamps (shader clock) of the middle block of the plane-MFMA kernel."""
+"""(Needs a library built WITH the stamp sites -- they are compiled out of the shipped one: csrc/gq_internal.h GQ_STAMPS; e.g.
+tools/build_variant.sh stamps ap_stream.hip -DGQ_STAMPS=1 and GQ_LIB_PATH=guidedquant_amd/abl_stamps/libgq_hip.so.)
+Per-wave phase timestamps (shader clock) of the middle block of the plane-MFMA kernel."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

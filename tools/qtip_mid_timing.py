@@ -1,4 +1,6 @@
-"""Phase stamps (shader clock, lane 0 of every wave of block 32) of gq_qtip_mlp_mid at Llama-2-7b's MLP width, the sums written
+"""(Needs a library built WITH the stamp sites -- they are compiled out of the shipped one: csrc/gq_internal.h GQ_STAMPS; e.g.
+tools/build_variant.sh stamps ap_stream.hip -DGQ_STAMPS=1 and GQ_LIB_PATH=guidedquant_amd/abl_stamps/libgq_hip.so.)
+Phase stamps (shader clock, lane 0 of every wave of block 32) of gq_qtip_mlp_mid at Llama-2-7b's MLP width, the sums written
 by a launch right in front of it: [start, rows done (sums landed + column sums), tables in LDS, out product, middle, in product, end]"""
 import ctypes, os, sys
 import numpy as np

@@ -1,4 +1,6 @@
-"""Per-wave phase stamps (shader clock) of the middle block of gq_qtip_matvec:
+"""(Needs a library built WITH the stamp sites -- they are compiled out of the shipped one: csrc/gq_internal.h GQ_STAMPS; e.g.
+tools/build_variant.sh stamps ap_stream.hip -DGQ_STAMPS=1 and GQ_LIB_PATH=guidedquant_amd/abl_stamps/libgq_hip.so.)
+Per-wave phase stamps (shader clock) of the middle block of gq_qtip_matvec:
 [start, first tile blocks requested, prologue done (codebook + activations in LDS), item 0 main loop done, item 0 flushed, item 1 ...]"""
 import ctypes, os, sys
 import torch

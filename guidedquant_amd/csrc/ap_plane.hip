@@ -59,6 +59,12 @@ struct PlaneArgs {
     float *ssq_out;           // statistics hand-over (gq_hip.h GQ_SSQ_SLOTS): block b leaves the sum of squares of its fp16 outputs in slot b
 };
 
+// The ablation switches of GQ_PL_XFLAGS (a.xflags) are compiled in only with -DGQ_ABLATION=1: in the shipped library every test of
+// them would be a scalar compare and a branch on the prologue's critical path (like the phase stamps, gq_internal.h GQ_STAMPS).
+#ifndef GQ_ABLATION
+#define GQ_ABLATION 0
+#endif
+#define PL_XF(bit) (GQ_ABLATION && (a.xflags & (bit)))
 #ifndef PL_SSQ_MODE
 #define PL_SSQ_MODE 2  // statistics hand-over slots: plain stores, slots grouped by XCD (see plane_epilogue)
 #endif
@@ -371,10 +377,13 @@ __device__ __forceinline__ void store_out16(uint16_t *p, uint16_t v) { gq_store_
 
 // coefficients x plane sums.  lane = (output row, Moebius index c): term c = coef[c] * (c == 0 ? sum(x) : T[c]); the NP
 // terms of a row sit in NP adjacent lanes and are added by a fixed DPP tree (deterministic order)
-template <int BITS>
+// SPEC: the decode step's form compiled in (plain / residual epilogue, no statistics hand-over) -- see ap_plane_local_kernel
+template <int BITS, bool SPEC = false>
 __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lutl, const float *part, float X, u32 rg0, u32 m, u32 tid,
                                                u32 T, u32 PS /* floats between the K-split items of a row group */) {
     constexpr int NP = 1 << BITS;
+    const bool f_pairs = !SPEC && a.pairs;
+    float *const f_ssq = SPEC ? nullptr : a.ssq_out;
     const u32 CS = 1u << a.log2CS;
     for (u32 e = tid; e < a.RGB * 16u * (u32)NP; e += T) {
         const u32 i = e / (u32)NP, c = e % (u32)NP;
@@ -421,7 +430,7 @@ __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lu
         _Float16 yh = (_Float16)y;
         // hand-off stores: write-through, one 2-byte store per output (gq_internal.h; two neighbouring outputs per 4-byte store
         // measured slower: 831 vs 839 tokens/s, plain stores 825)
-        if (a.pairs) {
+        if (f_pairs) {
             // the partner row of the pair sits NP lanes away: F.silu(gate) * up on fp16 values -- inference/model.py:266
             const _Float16 yo = __builtin_bit_cast(_Float16, (uint16_t)__shfl_xor((int)__builtin_bit_cast(uint16_t, yh), NP));
             if (c == 0u && !(rr & 1u) && row + 1u < a.N) {
@@ -434,7 +443,7 @@ __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lu
             if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[(size_t)m * a.N + row]) + yh;
             store_out16(a.out + (size_t)m * a.N + row, __builtin_bit_cast(uint16_t, yh));
         }
-        if (a.ssq_out) {
+        if (f_ssq) {
             // hand-over to the RMSNorm prologue of the NEXT launch (include/gq_hip.h, GQ_SSQ_SLOTS): the sum of squares of the fp16
             // values just stored, one slot per epilogue wave (whole waves: 16 RGB 2^b is a multiple of 64; host: one pass of this
             // loop, M = 1, plain / residual epilogue).  Fixed DPP tree: deterministic.
@@ -456,7 +465,7 @@ __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lu
         }
     }
     // (the consumer adds all GQ_SSQ_SLOTS: block 0 clears the slots no wave of the grid writes)
-    if (a.ssq_out && blockIdx.x == 0u)
+    if (f_ssq && blockIdx.x == 0u)
         for (u32 i = gridDim.x * ((a.RGB * 16u * (u32)NP) >> 6) + tid; i < (u32)GQ_SSQ_SLOTS; i += T) {
 #if PL_SSQ_MODE == 1 || PL_SSQ_MODE == 2
             a.ssq_out[(i & 7u) * ((u32)GQ_SSQ_SLOTS / 8u) + (i >> 3)] = 0.f;
@@ -545,7 +554,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
         if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
     };
     stamp(0);
-    if (a.xflags & 32u) return;
+    if PL_XF(32u) return;
     const bool early = w < E;
     auto stamp2 = [&](int i) {  // finer stamps of the prologue (second table of tools/phase_timing.py)
         if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[128u + w * 16u + (u32)i] = __builtin_readcyclecounter();
@@ -572,7 +581,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
 #pragma unroll
                 for (u32 n = 0; n < (u32)NI; n++) {
                     const u32 idx = tid + n * (E * 64u);  // 16-byte unit of the vector
-                    const u32 voff = (idx < G.K / 8u && !(a.xflags & 8u)) ? 16u * idx : OOB;
+                    const u32 voff = (idx < G.K / 8u && !PL_XF(8u)) ? 16u * idx : OOB;
                     rawv[mm][n] = bload128(rsm, voff, 0u);
                     if constexpr (PRO == PRO_RMSNORM) rawa[n] = bload128(rsa, voff, 0u);
                     if constexpr (PRO == PRO_SILUMUL) rawa[n] = bload128(rsx, voff, 2u * G.K);
@@ -583,7 +592,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             for (u32 n = 0; n < (u32)NI; n++) {
                 const u32 chunk = (w >> 1) + n * (E / 2u);  // wave-uniform
                 const u32 tp = G.tpw(chunk);
-                const bool ok = chunk < G.nchunks && pt < tp && !(a.xflags & 8u);
+                const bool ok = chunk < G.nchunks && pt < tp && !PL_XF(8u);
                 const u32 vlo = ok ? 16u * pt + 2u * (7u - pb) : OOB, vhi = ok ? 16u * pt + 2u * (3u - pb) : OOB;
 #pragma unroll
                 for (u32 c = 0; c < 4; c++) {
@@ -620,7 +629,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // plane stream of this wave: its items in order (late wave: item w - E first), cpi steps each, ring slot = step % S
     const u32 first_late = (!early && w - E < nIt) ? 1u : 0u;
     const u32 items_w = first_late + (nIt > L + w ? (nIt - L - w + W - 1u) / W : 0u);
-    const u32 my_steps = (a.xflags & 2u) ? 0u : items_w * cpi;
+    const u32 my_steps = PL_XF(2u) ? 0u : items_w * cpi;
     auto item_after = [&](u32 item) { return item < L ? L + w : item + W; };  // the wave's next item
     const u32 item0 = first_late ? w - E : L + w;
     const u32 plane_bytes = a.N * a.wpr_ld * 4u;
@@ -640,7 +649,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     }
     u32 iq_item = item0, iq_c = 0, iq_slot = 0, iq_n = 0;  // next step to request
     auto issue = [&]() {
-        if (a.xflags & 1024u) {  // experiment: no plane loads at all (the MFMA phase runs on whatever is in LDS)
+        if PL_XF(1024u) {  // experiment: no plane loads at all (the MFMA phase runs on whatever is in LDS)
             iq_n++;
             return;
         }
@@ -662,11 +671,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // The LUT rows of the block ride in the queue of the last wave as nlut pseudo steps of exactly LPS loads each
     // (padded with out-of-range loads), behind its first item: loads return in order, so its vmcnt bookkeeping stays in
     // units of steps, and the LUT is in LDS once it has seen its last tile.
-    const u32 nlut = (w == W - 1u && !(a.xflags & 16u)) ? lut_bytes / (LPS * 1024u) : 0u;
+    const u32 nlut = (w == W - 1u && !PL_XF(16u)) ? lut_bytes / (LPS * 1024u) : 0u;
     u32 lut_after = 0;  // pseudo steps queued behind the steps issued so far
     if (!early) {
         // late wave: first item now (this may block in the issue queue: nothing else to do before the image is built)
-        while (iq_n < my_steps && iq_n < S && (!(a.xflags & 256u) || iq_n < cpi * first_late)) issue();
+        while (iq_n < my_steps && iq_n < S && (!PL_XF(256u) || iq_n < cpi * first_late)) issue();
         if (nlut) {
             const u32x4 rl = make_rsrc(a.lut, a.N * (u32)NP * 2u);
             const u32 want = a.RGB * 16u * (u32)NP * 2u;
@@ -980,7 +989,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             issue();
         }
         if (++cq_slot == S) cq_slot = 0;
-        if (chunk < G.nchunks && !(a.xflags & 1u)) {
+        if (chunk < G.nchunks && !PL_XF(1u)) {
             // MFMA columns without a piece (col >= 4 MB) must read zeros (measured: with real data in them -- the same addresses as
             // columns 0..3, an LDS broadcast -- w1w3 runs 10.7 instead of 9.8 us: the matrix cores draw more power on non-zero
             // operands and the chip clocks down).  PL_BOOB: their base address lies outside the workgroup's LDS allocation (192 KiB
@@ -996,7 +1005,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             mfma_chunk<BITS>(acc, Wd, bbase, bcol ? 512u : 0u, bcol ? 64u : 0u, sb);
 #endif
             if (!(HOT_ABL & 4) && __builtin_expect(nhot != 0u, 0)) hot_step<BITS>(acc, Wd, hotl, nhot, chunk, sb, col, kb);
-        } else if (a.xflags & 1u) {
+        } else if PL_XF(1u) {
             acc[0][0] += __builtin_bit_cast(float, Wd[0][0] ^ Wd[BITS - 1][7]);
         }
         if (++cq_c == cpi) {
@@ -1028,7 +1037,10 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
 //   items: wave w takes items w, w + W, ...; CS divides W, so all of them cover the same chunks cs * cpi .. + cpi - 1,
 //   cs = w mod CS, of different row groups.  Waves with the same cs build the same image redundantly (RGB > 1).
 //   LDS: [A rings: W x S slots][LUT rows][images: W x NC x 4096][red: 64 floats][hot lists: W x 16 NC x 8 B][part]
-template <int BITS, int PRO, int NC>
+// SPEC: the instance of the decode step's wo / w2 launches -- K a multiple of 1024 (no short tail chunk), plain or residual
+// epilogue, no statistics hand-over: the tests of those launch properties (wave-uniform compares and branches, most of them on the
+// prologue's critical path) are compiled out.  The host picks it when the launch qualifies (launch_local_inst); same arithmetic.
+template <int BITS, int PRO, int NC, bool SPEC = false>
 __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(PlaneArgs a) {
     static_assert(PRO != PRO_RMSNORM, "the RMSNorm scale needs the whole vector");
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
@@ -1086,7 +1098,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
 #pragma unroll
         for (u32 n = 0; n < (u32)NC; n++) {
             const u32 chunk = chunk0 + n;
-            const u32 tp = G.tpw(chunk);
+            const u32 tp = SPEC ? 32u : G.tpw(chunk);
 #pragma unroll
             for (u32 k = 0; k < 2; k++) {
                 const u32 u = l + 64u * k;
@@ -1158,7 +1170,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     stamp(7);
     int sb = 127;
     u32 nhot = 0;
-    if (items_w && !(a.xflags & 64u)) {  // (GQ_PL_XFLAGS 64: knock-out of the image build -- WRONG numerics, timing only)
+    if (items_w && !PL_XF(64u)) {  // (GQ_PL_XFLAGS 64: knock-out of the image build -- WRONG numerics, timing only)
         const h2v one2 = u2h2(0x3C003C00u);
         us2 mxp = {0, 0};
         float s2 = 0.f, xsum = 0.f;
@@ -1196,7 +1208,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
             for (u32 n = 0; n < (u32)NC; n++) {
                 const u32 chunk = chunk0 + n;
                 if (n >= cpi || chunk >= G.nchunks) continue;
-                const u32 tp = G.tpw(chunk);
+                const u32 tp = SPEC ? 32u : G.tpw(chunk);
 #pragma unroll
                 for (u32 k = 0; k < 2; k++) {
                     const u32 u = l + 64u * k;
@@ -1223,7 +1235,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
         for (u32 n = 0; n < (u32)NC; n++) {
             const u32 chunk = chunk0 + n;
             if (n >= cpi || chunk >= G.nchunks) continue;
-            const u32 tp = G.tpw(chunk);
+            const u32 tp = SPEC ? 32u : G.tpw(chunk);
 #pragma unroll
             for (u32 k = 0; k < 2; k++) {
                 // unit u = the 8 activations j = 0..7 of (byte c, virtual lane t): word q holds j = 2q (low half), 2q + 1
@@ -1263,8 +1275,8 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
 #pragma unroll
         for (u32 n = 0; n < (u32)NC; n++) {
             const u32 chunk = chunk0 + n;
-            if (n >= cpi || chunk >= G.nchunks || G.tpw(chunk) == 32u) continue;
-            const u32 tp = G.tpw(chunk);
+            if (SPEC || n >= cpi || chunk >= G.nchunks || G.tpw(chunk) == 32u) continue;
+            const u32 tp = SPEC ? 32u : G.tpw(chunk);
             for (u32 o = l; o < 1024u; o += 64u) {  // dword o of the chunk image: block o / 32, k = 4 (o % 32) -> t = 8 (k/32) + 4 h + (k%32)/8
                 const u32 blk = o >> 5, k4 = ((o & 31u) * 4u) ^ bimg_swz(blk & 3u), hh = (blk >> 2) & 1u;  // (logical k of the stored position)
                 const u32 t = 8u * (k4 >> 5) + 4u * hh + ((k4 & 31u) >> 3);
@@ -1328,7 +1340,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     float X = 0.f;
 #pragma unroll
     for (u32 i = 0; i < W; i++) X += red[32 + i];
-    plane_epilogue<BITS>(a, lutl, part, X, rg0, m, tid, T, NP1 * 16u);
+    plane_epilogue<BITS, SPEC>(a, lutl, part, X, rg0, m, tid, T, NP1 * 16u);
     stamp(5);
 }
 
@@ -1419,10 +1431,10 @@ bool pick_local_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
     return true;
 }
 
-template <int BITS, int PRO, int NC>
+template <int BITS, int PRO, int NC, bool SPEC = false>
 int launch_local_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     static GqPerDeviceOnce once;
-    auto kern = ap_plane_local_kernel<BITS, PRO, NC>;
+    auto kern = ap_plane_local_kernel<BITS, PRO, NC, SPEC>;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     dim3 grid(c.grid, M), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
@@ -1436,6 +1448,13 @@ int launch_local(const PlaneArgs &a, const PlaneCfg &c, u32 M, int pro, hipStrea
         if (c.NI == 1) return launch_local_inst<BITS, PRO_SILUMUL, 1>(a, c, M, s);
         if (c.NI == 2) return launch_local_inst<BITS, PRO_SILUMUL, 2>(a, c, M, s);
         return launch_local_inst<BITS, PRO_SILUMUL, 4>(a, c, M, s);
+    }
+    if constexpr (BITS <= 3) {  // the decode step's wo / w2 launches: see SPEC at the kernel (GQ_PL_SPEC=0: the general instances)
+        if (a.K % 1024u == 0u && !a.pairs && !a.ssq_out && !PL_XF(~0u) && gq_env_int("GQ_PL_SPEC", 1)) {
+            if (c.NI == 1) return launch_local_inst<BITS, PRO_NONE, 1, true>(a, c, M, s);
+            if (c.NI == 2) return launch_local_inst<BITS, PRO_NONE, 2, true>(a, c, M, s);
+            return launch_local_inst<BITS, PRO_NONE, 4, true>(a, c, M, s);
+        }
     }
     if (c.NI == 1) return launch_local_inst<BITS, PRO_NONE, 1>(a, c, M, s);
     if (c.NI == 2) return launch_local_inst<BITS, PRO_NONE, 2>(a, c, M, s);

@@ -316,9 +316,19 @@ constexpr u32 META_W = 16u;
 #endif
 template <int BITS>
 constexpr int st_waves() { return BITS == 2 ? ST_W2 : ST_W34; }
-template <int BITS, int PRO, int NPU, bool PSUM>
+// EPI: the epilogue compiled in -- EPI_ANY reads the launch's flags (a.rope / a.pairs / a.part_out / a.resid / a.ssq_in) at run time;
+// the decode step's wqkv launch (EPI_ROPE) has an instance of its own: every wave-uniform flag test is a scalar compare and a branch
+// that no wave overlaps with anything in the prologue (the phase stamps alone, ~20 such sites, were 2 % of the decode step:
+// profiles/r05_stamps_compiled_out.txt); 51 -> 33 conditional branches in front of the first MFMA, wqkv 5.77 -> 5.61 us
+enum { EPI_ANY = -1, EPI_ROPE = 1, EPI_PAIRS = 2 };
+template <int BITS, int PRO, int NPU, bool PSUM, int EPI = EPI_ANY>
 __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(StreamArgs a) {
     constexpr int WV = st_waves<BITS>(), NH = ST_NH;
+    static_assert(EPI != EPI_ROPE || !PSUM, "the RoPE epilogue rotates raw-parked pairs");
+    const bool f_rope = EPI == EPI_ANY ? a.rope != 0u : EPI == EPI_ROPE;
+    const bool f_pairs = EPI == EPI_ANY ? a.pairs != 0u : EPI == EPI_PAIRS;
+    const bool f_part = EPI == EPI_ANY && a.part_out != nullptr;
+    const bool f_resid = EPI == EPI_ANY && a.resid != nullptr;
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
     constexpr u32 W = WV, T = 64u * W;
 #ifndef ST_RING
@@ -364,7 +374,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // wave and is looked at only behind the image build -- reading it where the cos / sin addresses are formed would park the wave
     // for a memory round trip in front of its prologue: measured, 1 us per launch)
     u32 posv = 0;
-    if (a.rope) posv = (u32)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.pos, 4u), 0, 0, 0);
+    if (f_rope) posv = (u32)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.pos, 4u), 0, 0, 0);
     unsigned char *img = smem + a.img_off;
     HotEnt *hotl = reinterpret_cast<HotEnt *>(img + (size_t)NC2 * 2048u);
     float *xpart = reinterpret_cast<float *>(hotl + (size_t)NC2 * HOTCAP);  // [NC2][4][16]
@@ -375,8 +385,8 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // MFMA row i of group rg is row  head * hd + 8 (rg % (hd / 16)) + i / 2 + (hd / 2) (i % 2),  head = rg / (hd / 16): rows (2 m,
     // 2 m + 1) of a group are the rotation partners (d, d + hd / 2) of one head (rotate_half, inference/model.py:330-341), so the
     // epilogue lane that owns 4 consecutive MFMA rows owns two whole pairs -- the stored tensor keeps the reference's row order.
-    auto grp_base = [&](u32 rg) -> u32 { return a.rope ? ((rg >> (a.lhd - 4u)) << a.lhd) + 8u * (rg & ((1u << (a.lhd - 4u)) - 1u)) : rg * 16u; };
-    auto grp_row = [&](u32 i) -> u32 { return a.rope ? (i >> 1) + ((i & 1u) << (a.lhd - 1u)) : i; };
+    auto grp_base = [&](u32 rg) -> u32 { return f_rope ? ((rg >> (a.lhd - 4u)) << a.lhd) + 8u * (rg & ((1u << (a.lhd - 4u)) - 1u)) : rg * 16u; };
+    auto grp_row = [&](u32 i) -> u32 { return f_rope ? (i >> 1) + ((i & 1u) << (a.lhd - 1u)) : i; };
 
     // ---------------------------------------------------------------- 0. requests: activations first, then one unit of planes
     const u32 xg = l >> 4, xc = l & 3u, xtt = 4u * xg + ((l >> 2) & 3u);
@@ -386,7 +396,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // LDS in front of the launch barrier; the builders read it back behind the barrier while their activations are still in
     // flight.  No exchange of per-wave sums (an LDS counter, a spin, a read-back) between the activations' arrival and the
     // normalisation: measured upper bound 0.4 us of the wqkv launch (profiles/r05_stream_knockouts.txt).
-    const bool ho = PRO == PRO_RMSNORM && a.ssq_in != nullptr;
+    const bool ho = PRO == PRO_RMSNORM && EPI == EPI_ANY && a.ssq_in != nullptr;
     if (PRO == PRO_RMSNORM && ho && w == (npw < W ? npw : W - 1u)) {
         // Requests, wait and sum inside ONE branch, from inline asm: left to the compiler, the wait for these loads lands at the
         // join behind the branch as vmcnt(0) for EVERY wave -- the builders then drain their activation loads, the last waves
@@ -515,7 +525,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // epilogue lane = (piece column, Moebius index c, row quad, row group): its residual elements now
     const u32 e_col = tid & (NCOL - 1u), e_c = (tid / NCOL) & (u32)NP1, e_rq = (tid / (NCOL * NP)) & 3u, e_rgl = tid / (NCOL * NP * 4u);
     u32x2 rres = {0u, 0u};
-    if (a.resid && !a.pairs && e_rgl < a.RGB && e_c == 0u && e_col == 0u)
+    if (f_resid && !f_pairs && e_rgl < a.RGB && e_c == 0u && e_col == 0u)
         rres = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.resid, a.N * 2u), (int)(2u * ((rg0 + e_rgl) * 16u + 4u * e_rq)), 0, 0));
 
     // ---------------------------------------------------------------- 1. images of this wave's units
@@ -685,7 +695,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     // RoPE epilogue: lane (c = 0, col = k < 2) of a row quad rotates the pair (rows 2 k, 2 k + 1 of the quad): its cos / sin now
     u32 rp_row = 0, rp_cs[4] = {0u, 0u, 0u, 0u};
     u32 rp_pos = 0;
-    if (a.rope) {
+    if (f_rope) {
         rp_pos = __builtin_amdgcn_readfirstlane(posv);
         rp_row = grp_base(rg0 + e_rgl) + 2u * e_rq + e_col;  // the pair's first row (d < hd / 2), partner at + hd / 2
         if (e_rgl < a.RGB) {  // (the epilogue's waves)
@@ -881,7 +891,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
         stamp2(9);
         // every lane of the row quad holds the 4 sums
         const u32 row = (rg0 + e_rgl) * 16u + 4u * e_rq;
-        if (a.rope) {
+        if (f_rope) {
             // apply_rotary_pos_emb on fp16 values (inference/model.py:336-341): q_embed = (q * cos) + (rotate_half(q) * sin), three
             // fp16-rounded operations on the GEMV's fp16 outputs; rotated q -> out (reference row order), rotated k and plain v ->
             // the caches at *pos (KVCache.update, model.py:69-79).  A position past the cache writes nothing to the caches.
@@ -908,7 +918,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
                     }
                 }
             }
-        } else if (a.pairs) {
+        } else if (f_pairs) {
             // rows (2 i, 2 i + 1) = (gate, up): F.silu(gate) * up on fp16 values -- inference/model.py:266.  Lane (c = 0, col = k)
             // takes pair k of the quad (one silu per lane instead of two on the tail)
             const u32 k = PSUM ? e_c : e_col;  // (PSUM: lanes c = 0, 1 of the quad)
@@ -916,7 +926,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
             const float gv = (float)yg;
             const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * yu;
             if ((PSUM ? true : e_c == 0u) && k < 2u && row + 2u * k + 1u < a.N) gq_store_wt(a.out + (row >> 1) + k, __builtin_bit_cast(uint16_t, o));
-        } else if (a.part_out) {
+        } else if (f_part) {
             // K split over blocks: the fp32 sums of this slice (coefficient terms included: they are linear in x) for the reduce launch
             if (e_c == 0u && e_col == 0u) {
                 float *po = a.part_out + (size_t)ksl * a.N + row;
@@ -934,7 +944,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 _Float16 yh = (_Float16)y[r];
-                if (a.resid) yh = __builtin_bit_cast(_Float16, (uint16_t)(rres[r >> 1] >> (16 * (r & 1)))) + yh;
+                if (f_resid) yh = __builtin_bit_cast(_Float16, (uint16_t)(rres[r >> 1] >> (16 * (r & 1)))) + yh;
                 o[r] = __builtin_bit_cast(uint16_t, yh);
             }
             if (row + 3u < a.N) {
@@ -987,10 +997,10 @@ bool pick_stream_cfg(u32 N, u32 K, int bits, StreamCfg &c, u32 rgb_force = 0) {
     return c.smem <= lds;
 }
 
-template <int BITS, int PRO, int NPU, bool PSUM>
+template <int BITS, int PRO, int NPU, bool PSUM, int EPI = EPI_ANY>
 int launch_inst(const StreamArgs &a, const StreamCfg &c, hipStream_t s) {
     static GqPerDeviceOnce once;
-    auto kern = ap_stream_kernel<BITS, PRO, NPU, PSUM>;
+    auto kern = ap_stream_kernel<BITS, PRO, NPU, PSUM, EPI>;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     hipLaunchKernelGGL(kern, dim3(c.grid, c.gy), dim3(64u * c.W), c.smem, s, a);
     GQ_HIP_CHECK(hipGetLastError());
@@ -1002,6 +1012,16 @@ int launch_npu(const StreamArgs &a, const StreamCfg &c, hipStream_t s) {
         if (c.NPU == 4u) {  // K > 16384 (the 70B down projection in one launch): summed parking only, no RMSNorm in front of it
             if constexpr (PRO != PRO_RMSNORM) return c.psum ? launch_inst<BITS, PRO, 4, true>(a, c, s) : GQ_ENOTSUP;
             return GQ_ENOTSUP;
+        }
+        if constexpr (PRO == PRO_RMSNORM) {
+            // the decode step's wqkv launch: the instance with the RoPE epilogue compiled in (GQ_ST_EPI=0: the run-time form; =2: also
+            // the pair-epilogue instance for w1w3, which measured SLOWER than the run-time form, 8.85 vs 8.65 us, with a main loop
+            // that is instruction for instruction the same -- profiles/r05_compiled_in_epilogues.txt)
+            const int epi = gq_env_int("GQ_ST_EPI", 1);
+            if (!c.psum && c.NPU == 1u && !a.ssq_in && !a.part_out && !a.resid && epi) {
+                if (a.rope && !a.pairs) return launch_inst<BITS, PRO, 1, false, EPI_ROPE>(a, c, s);
+                if (a.pairs && !a.rope && epi >= 2) return launch_inst<BITS, PRO, 1, false, EPI_PAIRS>(a, c, s);
+            }
         }
         if (!c.psum) return c.NPU == 1u ? launch_inst<BITS, PRO, 1, false>(a, c, s) : launch_inst<BITS, PRO, 2, false>(a, c, s);
     }

@@ -194,8 +194,12 @@ def decode_tok_s(model, dev, steps, warmup, torch_sampling=False):
     import torch
     from guidedquant_amd.generate import DecodeGraph
     # (round 5: the embedding lookup of the NEXT token rides in the sampler's last block -- GQ_FOLD_EMBED=0 restores the launch)
+    # round 5: ten consecutive token steps per graph replay (token / position / RNG counter feed back on the device): the boundary
+    # between two graph launches, ~8 us, is paid once per ten tokens (profiles/r05_steps_per_replay.txt: 898 -> 906 tokens/s)
+    spr = 1 if torch_sampling else int(os.environ.get("GQ_STEPS_PER_REPLAY", "10"))
+    assert SEQ_NEW_TOKENS % spr == 0
     graph = DecodeGraph(model, dev, native_sampling=not torch_sampling, temperature=0.0, top_k=32,
-                        fold_embed=os.environ.get("GQ_FOLD_EMBED", "1") != "0")
+                        fold_embed=os.environ.get("GQ_FOLD_EMBED", "1") != "0", steps_per_replay=spr)
     bos = torch.tensor([[(128000 if model.config.vocab_size > 100000 else 1)]], dtype=torch.int32, device=dev)
     zero = torch.zeros((1, ), dtype=torch.int32, device=dev)
 
@@ -203,9 +207,12 @@ def decode_tok_s(model, dev, steps, warmup, torch_sampling=False):
         done = 0
         while done < n:
             graph.set_token(bos, zero)
-            for _ in range(min(SEQ_NEW_TOKENS, n - done)):
+            k = min(SEQ_NEW_TOKENS, n - done)
+            for _ in range(k // spr):  # (a replay decodes `spr` tokens)
                 graph.step()
-            done += min(SEQ_NEW_TOKENS, n - done)
+            for _ in range(k % spr):   # (what is left of the K steps asked for: single-step replays -- exactly K token steps are timed)
+                graph.step_one()
+            done += k
 
     return graph, run_steps
 
@@ -348,6 +355,7 @@ def main():
                    "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
                    "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1),
                    "kv_positions_timed": "0..%d" % (min(args.steps, SEQ_NEW_TOKENS) - 1),
+                   "token_steps_per_graph_replay": 1 if (args.torch_sampling or pp) else int(os.environ.get("GQ_STEPS_PER_REPLAY", "10")),
                    "note": "sequences of %d new tokens: --steps < %d times only the first positions of one sequence (the reference metric "
                            "averages over 100 new tokens; 400-step runs of the same build agree within 1 %%)" % (SEQ_NEW_TOKENS, SEQ_NEW_TOKENS)},
         "roofline": roofline, "cpu_baseline": cpu_baseline,

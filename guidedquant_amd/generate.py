@@ -97,7 +97,8 @@ class DecodeGraph:
     """One captured hipGraph of `decode_one_token` with static token / position / output tensors
     (the manual-graph path of generate.py:95-113)."""
 
-    def __init__(self, model: Transformer, device, native_sampling=False, seed=1234, fold_embed=False, seq_capacity=0, **sampling_kwargs):
+    def __init__(self, model: Transformer, device, native_sampling=False, seed=1234, fold_embed=False, seq_capacity=0, steps_per_replay=1,
+                 **sampling_kwargs):
         """native_sampling: draw the token with the fused HIP sampler (gq_sample_topk_ex: same distribution as `sample`,
         own counter-based RNG, top_k <= 64) and feed token / position back inside the graph; `next_prob` is then
         not produced.  Default False = the reference's torch sampling ops, captured in the graph.
@@ -106,12 +107,17 @@ class DecodeGraph:
         launch less per token.  The token of the first step must then be set through `set_token` (which runs the lookup once);
         writing `self.tok` directly is only valid without the fold.
         seq_capacity > 0: the sampler also stores every token at `self.seq[pos + 1]` (int32 [seq_capacity]); `self.ban` (int32
-        {n, until_pos, id0..id3}) lists tokens that cannot be drawn while pos < until_pos (HF's min_new_tokens on EOS)."""
+        {n, until_pos, id0..id3}) lists tokens that cannot be drawn while pos < until_pos (HF's min_new_tokens on EOS).
+        steps_per_replay > 1 (native sampling only): the graph holds that many consecutive token steps -- token, position and RNG
+        counter are fed back on the device, so step i + 1 needs nothing from the host; one replay then decodes `steps_per_replay`
+        tokens (`next_tok` = the last of them, all of them in `self.seq` when seq_capacity > 0) and the boundary between two graph
+        launches is paid once per replay instead of once per token."""
         prime_graph_rng_state(device)
         self.model = model
         self.native_sampling = bool(native_sampling) and model.native_ready() and (sampling_kwargs.get("top_k") or 0) <= 64 \
             and sampling_kwargs.get("top_k") is not None
         self.fold_embed = bool(fold_embed) and self.native_sampling
+        self.steps_per_replay = max(1, int(steps_per_replay)) if self.native_sampling else 1
         self.seed = seed
         self.rng_counter = torch.zeros((1, ), dtype=torch.int32, device=device)
         self.work_val = torch.zeros((128 * 64, ), dtype=torch.float32, device=device)
@@ -133,8 +139,16 @@ class DecodeGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self._step()
+            for _ in range(self.steps_per_replay):
+                self._step()
         torch.cuda.synchronize()
+        # (a single-step graph over the same state tensors for what is left of a sequence: `step_one`)
+        self.graph1 = self.graph
+        if self.steps_per_replay > 1:
+            self.graph1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph1):
+                self._step()
+            torch.cuda.synchronize()
         self._bound = self._signature()
         self._gen = getattr(model, "_alloc_gen", 0)
 
@@ -217,6 +231,16 @@ class DecodeGraph:
         if advance and not self.native_sampling:
             self.tok.copy_(self.next_tok)
             self.pos.add_(1)
+
+    def step_one(self):
+        """one token step whatever `steps_per_replay` is (the tail of a sequence whose length is not a multiple of it)"""
+        if self.steps_per_replay == 1:
+            return self.step()
+        gen = getattr(self.model, "_alloc_gen", 0)
+        if gen != self._gen:
+            self.check_bound()
+            self._gen = gen
+        self.graph1.replay()
 
 
 def decode_n_tokens(model: Transformer, cur_token: torch.Tensor, input_pos: torch.Tensor, num_new_tokens: int,

@@ -213,6 +213,30 @@ def test_native_sampling_graph_advances_by_itself():
     assert seq == seq2
 
 
+@pytest.mark.parametrize("fold", [False, True])
+def test_several_token_steps_per_graph_replay_decode_the_same_tokens(fold):
+    """DecodeGraph(steps_per_replay=k): token, position and RNG counter feed back on the device, so k captured steps per replay
+    give the tokens of k single-step replays (greedy and sampled), all of them in the sequence store"""
+    from guidedquant_amd.generate import DecodeGraph
+    d = _dev()
+    m = _tiny_model(2)
+    m.setup_caches(1, 32)
+    for temp in (0.0, 0.8):
+        seqs = []
+        for k in (1, 4):
+            g = DecodeGraph(m, d, native_sampling=True, temperature=temp, top_k=32, seed=7, fold_embed=fold, seq_capacity=32, steps_per_replay=k)
+            assert g.steps_per_replay == k
+            g.set_token(1, 0)
+            for _ in range(12 // k):
+                g.step()
+            g.step_one()  # (the tail of a sequence: one step)
+            torch.cuda.synchronize()
+            assert int(g.pos.item()) == 13
+            seqs.append(g.seq[1:14].tolist())
+            assert seqs[-1][-1] == int(g.next_tok.item())
+        assert seqs[0] == seqs[1], (temp, seqs)
+
+
 def test_pipelined_decoder_native_single_rank():
     """the layer-pipeline driver on one rank (native fused kernels, 2 sequences with their own KV slots) reproduces the
     plain greedy decode of the same model"""

@@ -593,7 +593,10 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
     // (matrices of <= 16 rows per CU without the RMSNorm prologue run the local-image variant, which needs no block-wide
     // activation pass: >= 16 M weights at 2 and 3 bits -- wo)
     const bool local = pro != PRO_RMSNORM && bits <= 3 && gq_plane_local_shape(a.N, a.K, bits);
-    const int def_min = local ? 16 : (bits == 2 ? 20 : 32);
+    // (round 5: behind the RMSNorm prologue the plane kernel wins from 20 M weights at 3 and 4 bits too -- 8B wqkv, 25 M: 7.2 vs 8.4 us
+    // at 3 bits, 10.2 vs 12.0 at 4 -- the exact kernel normalises the whole vector in every block in front of its first row step;
+    // without the prologue the 32 M threshold stands: wo at 4 bits 6.6 exact vs 7.6 plane.  profiles/r05_dispatch_3_4_bits.txt)
+    const int def_min = local ? 16 : ((bits == 2 || pro == PRO_RMSNORM) ? 20 : 32);
     const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : def_min) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {

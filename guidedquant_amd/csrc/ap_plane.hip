@@ -378,12 +378,12 @@ __device__ __forceinline__ void store_out16(uint16_t *p, uint16_t v) { gq_store_
 // coefficients x plane sums.  lane = (output row, Moebius index c): term c = coef[c] * (c == 0 ? sum(x) : T[c]); the NP
 // terms of a row sit in NP adjacent lanes and are added by a fixed DPP tree (deterministic order)
 // SPEC: the decode step's form compiled in (plain / residual epilogue, no statistics hand-over) -- see ap_plane_local_kernel
-template <int BITS, bool SPEC = false>
+template <int BITS, bool SPEC = false, bool NOSSQ = false>
 __device__ __forceinline__ void plane_epilogue(const PlaneArgs &a, const u32 *lutl, const float *part, float X, u32 rg0, u32 m, u32 tid,
                                                u32 T, u32 PS /* floats between the K-split items of a row group */) {
     constexpr int NP = 1 << BITS;
     const bool f_pairs = !SPEC && a.pairs;
-    float *const f_ssq = SPEC ? nullptr : a.ssq_out;
+    float *const f_ssq = (SPEC || NOSSQ) ? nullptr : a.ssq_out;  // (NOSSQ: pairs stay a run-time flag)
     const u32 CS = 1u << a.log2CS;
     for (u32 e = tid; e < a.RGB * 16u * (u32)NP; e += T) {
         const u32 i = e / (u32)NP, c = e % (u32)NP;
@@ -514,8 +514,12 @@ __device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
 // rows from one read of the weight words): row mm of the block's a.MB rows has its own activation image and uses the MFMA columns
 // 4 mm .. 4 mm + 3 (a row needs 4 of the 16: its bf8 pieces), its own E8M0 scale (supplied per lane) and statistics; the images
 // are built one after the other through the same staged copy.  Plain prologue only; gridDim.y = ceil(M / a.MB).
-template <int BITS, int PRO, int NI, int MBT = 1>
+// SPEC: the instances of the decode step's launches (like SPEC of the local-image kernel below): the activations come through the
+// staged copy (a.rawx: true for every model shape -- the item-layout loads are the fallback of rings too small for the vector), K is
+// a multiple of 1024, no statistics hand-over; the pair epilogue stays a run-time flag (w1w3 has it, w2 has not).
+template <int BITS, int PRO, int NI, int MBT = 1, bool SPEC = false>
 __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2) ap_plane_kernel(PlaneArgs a) {
+    const bool rawx = SPEC || a.rawx != 0u;
     static_assert(MBT == 1 || PRO == PRO_NONE, "several rows per pass: plain prologue only");
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
     constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u, E = W / 2u, L = W - E;  // early / late waves
@@ -574,7 +578,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     if (early) {
         const u32x4 rsx = make_rsrc(a.x + (size_t)m * a.x_ld, (PRO == PRO_SILUMUL ? 4u : 2u) * G.K);
         const u32x4 rsa = make_rsrc(PRO == PRO_RMSNORM ? a.normw : a.x, 2u * G.K);
-        if (a.rawx) {
+        if (rawx) {
 #pragma unroll
             for (u32 mm = 0; mm < (u32)MBT; mm++) {  // (every row's loads are in flight before the first one is used)
                 const u32x4 rsm = MBT == 1 ? rsx : make_rsrc(a.x + (size_t)(m + mm) * a.x_ld, mm < MB ? 2u * G.K : 0u);
@@ -591,7 +595,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
 #pragma unroll
             for (u32 n = 0; n < (u32)NI; n++) {
                 const u32 chunk = (w >> 1) + n * (E / 2u);  // wave-uniform
-                const u32 tp = G.tpw(chunk);
+                const u32 tp = SPEC ? 32u : G.tpw(chunk);
                 const bool ok = chunk < G.nchunks && pt < tp && !PL_XF(8u);
                 const u32 vlo = ok ? 16u * pt + 2u * (7u - pb) : OOB, vhi = ok ? 16u * pt + 2u * (3u - pb) : OOB;
 #pragma unroll
@@ -695,7 +699,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // waves' serial chain, where every instruction costs 5-8 cycles; they also take the mean magnitude the threshold needs --;
     // otherwise the early waves, from their own maxima and one more sum in the statistics pass.
     constexpr u32 NSC = L >= 2u ? L / 2u : 1u;
-    const bool scan_late = a.rawx && !a.himg && !(HOT_ABL & 2) && !(HOT_ABL & 32);
+    const bool scan_late = rawx && !a.himg && !(HOT_ABL & 2) && !(HOT_ABL & 32);
     // image passes: early wave w takes passes [0, NIe), with a.himg late wave w the passes [NIe, NI) of early wave w - E
     constexpr u32 NIe = (NI + 1) / 2;
     const bool helper = !early && a.himg;
@@ -798,7 +802,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
                 mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(us2, xw & 0x7FFF7FFFu));
             }
         };
-        if (a.rawx) {
+        if (rawx) {
             unsigned char *raw = smem;  // the early waves' ring slots
 #pragma unroll
             for (u32 n = 0; n < (u32)NI; n++) {
@@ -863,15 +867,15 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
             xmax = xmax * nscale * 1.002f;  // covers the two fp16 roundings of the transform
         }
         stamp2(4);
-        if (!(HOT_ABL & 2) && !scan_late && a.rawx && early) detect();
-        if (a.rawx) {
+        if (!(HOT_ABL & 2) && !scan_late && rawx && early) detect();
+        if (rawx) {
             // the staged copy is complete: gather this thread's items (for SiLU the staged vector is already the product)
             const uint16_t *rx = reinterpret_cast<const uint16_t *>(smem), *ra = rx + G.K;
 #pragma unroll
             for (u32 n = 0; n < (u32)NI; n++) {
                 if (n < n0 || n >= n1) continue;
                 const u32 chunk = (vw >> 1) + n * (E / 2u);
-                const u32 tp = G.tpw(chunk);
+                const u32 tp = SPEC ? 32u : G.tpw(chunk);
                 const bool ok = chunk < G.nchunks && pt < tp;
 #pragma unroll
                 for (u32 c = 0; c < 4; c++) {  // low half = weight 7 - b, high half = weight 3 - b
@@ -1022,7 +1026,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2
     // ---------------------------------------------------------------- 4. epilogue: coefficients x plane sums
 #pragma unroll
     for (u32 mm = 0; mm < (u32)MBT; mm++)
-        if (mm < MB) plane_epilogue<BITS>(a, lutl, part + (size_t)mm * NP1 * 16u, Xr[mm], rg0, m + mm, tid, T, MB * NP1 * 16u);
+        if (mm < MB) plane_epilogue<BITS, false, SPEC>(a, lutl, part + (size_t)mm * NP1 * 16u, Xr[mm], rg0, m + mm, tid, T, MB * NP1 * 16u);
     (void)X;
     stamp(5);
 }
@@ -1461,10 +1465,10 @@ int launch_local(const PlaneArgs &a, const PlaneCfg &c, u32 M, int pro, hipStrea
     return launch_local_inst<BITS, PRO_NONE, 4>(a, c, M, s);
 }
 
-template <int BITS, int PRO, int NI, int MBT = 1>
+template <int BITS, int PRO, int NI, int MBT = 1, bool SPEC = false>
 int launch_plane_inst(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     static GqPerDeviceOnce once;
-    auto kern = ap_plane_kernel<BITS, PRO, NI, MBT>;
+    auto kern = ap_plane_kernel<BITS, PRO, NI, MBT, SPEC>;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     dim3 grid(c.grid, MBT == 1 ? M : (M + a.MB - 1u) / a.MB), block(c.T);
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
@@ -1483,6 +1487,14 @@ int launch_plane_rows(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t 
 template <int BITS, int PRO>
 int launch_plane_ni(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     // K <= 16384 -> at most 2048 items over 512 / 256 lanes
+    if constexpr (BITS >= 3 && PRO != PRO_SILUMUL) {  // the 3- / 4-bit decode launches (wqkv, w1w3 behind RMSNorm; w2 plain): see SPEC at the kernel
+        if (a.rawx && a.K % 1024u == 0u && !a.ssq_out && !PL_XF(~0u) && gq_env_int("GQ_PL_SPEC", 1)) {
+            if (c.NI <= 1) return launch_plane_inst<BITS, PRO, 1, 1, true>(a, c, M, s);
+            if (c.NI == 2) return launch_plane_inst<BITS, PRO, 2, 1, true>(a, c, M, s);
+            if (c.NI <= 4) return launch_plane_inst<BITS, PRO, 4, 1, true>(a, c, M, s);
+            if (c.NI <= 8) return launch_plane_inst<BITS, PRO, 8, 1, true>(a, c, M, s);
+        }
+    }
     if (c.NI <= 1) return launch_plane_inst<BITS, PRO, 1>(a, c, M, s);
     if (c.NI == 2) return launch_plane_inst<BITS, PRO, 2>(a, c, M, s);
     if (c.NI <= 4) return launch_plane_inst<BITS, PRO, 4>(a, c, M, s);

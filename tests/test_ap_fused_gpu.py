@@ -82,20 +82,25 @@ def test_rmsnorm_prologue_default_dispatch_equals_unfused_chain(oracle, bits, N,
     xn = ((xt * torch.rsqrt((xt * xt).mean() + EPS)).half() * torch.from_numpy(nw).cuda()).cpu().numpy()
     assert (xn.view(np.uint16) != rmsnorm_ref(x, nw, EPS).view(np.uint16)).sum() <= 4  # torch on the GPU vs the numpy restatement
     plain = run_fused(xn, q, lut, bits)
-    diff = fused.view(np.uint16) != plain.view(np.uint16)
-    assert diff.mean() <= 0.02, diff.mean()
-    ulp = np.abs(np.spacing(plain)).astype(np.float64)
-    # (round 4: the RMSNorm launches of the 2-bit 8B shapes run the stream kernel, the plain launch the round-3 kernels: two fp32
-    # summation orders, so an output that nearly cancels may move by more than its own ulps -- by fp32 noise of sum|w||x|)
-    slack = 2e-6 * (np.abs(lut.astype(np.float64)).max(axis=1) * np.abs(xn.astype(np.float64)).sum())
-    assert (np.abs(fused.astype(np.float64) - plain.astype(np.float64)) <= 2 * ulp + slack).all()
     rows = _rows(rng, N, 32)
-    if N * K >= (20 if bits == 2 else 32) * 1000000:  # the default dispatch sends this shape to the plane-MFMA kernel
+    # which kernel family the default dispatch picks (ap_gemv.hip): behind the RMSNorm prologue the plane-MFMA kernel from 20 M weights
+    # at every width (round 5); the plain launch from 20 M at 2 bits, 32 M at 3 / 4 bits -- below that the exact kernel
+    fused_fast, plain_fast = N * K >= 20 * 1000000, N * K >= (20 if bits == 2 else 32) * 1000000
+    if fused_fast == plain_fast:
+        diff = fused.view(np.uint16) != plain.view(np.uint16)
+        assert diff.mean() <= 0.02, diff.mean()
+        ulp = np.abs(np.spacing(plain)).astype(np.float64)
+        # (round 4: the RMSNorm launches of the 2-bit 8B shapes run the stream kernel, the plain launch the round-3 kernels: two fp32
+        # summation orders, so an output that nearly cancels may move by more than its own ulps -- by fp32 noise of sum|w||x|)
+        slack = 2e-6 * (np.abs(lut.astype(np.float64)).max(axis=1) * np.abs(xn.astype(np.float64)).sum())
+        assert (np.abs(fused.astype(np.float64) - plain.astype(np.float64)) <= 2 * ulp + slack).all()
+    if fused_fast:
         _check_fast(fused, rmsnorm_ref(x, nw, EPS), q, lut, bits, oracle, rows=rows)
-    else:  # below the threshold the exact kernel runs: the reference's fp16 order on the normalised vector, bit for bit
+    if not plain_fast:  # the exact kernel: the reference's fp16 order on the normalised vector, bit for bit
         want = oracle.ap_gemv_f16(xn, np.ascontiguousarray(q[:, rows, :]), lut[rows], bits)[0]
         assert np.array_equal(plain[rows].view(np.uint16), want.view(np.uint16))
-        assert (fused[rows].view(np.uint16) != want.view(np.uint16)).mean() <= 0.1
+        if not fused_fast:
+            assert (fused[rows].view(np.uint16) != want.view(np.uint16)).mean() <= 0.1
 
 
 # wo / w2: residual epilogue, on the local-image kernel (2/3-bit default) and on the shared-image kernel

@@ -12,8 +12,9 @@ def test_plan_follows_the_dispatch():
         assert L.gq_anyprec_handover_plan(28672, 4096, 2, 1, 4) == 1      # gate/up pair epilogue: nothing to write
         assert L.gq_anyprec_handover_plan(4096, 4096, 2, 0, 1) == 2
         assert L.gq_anyprec_handover_plan(4096, 14336, 2, 0, 1) == 2
-        # 3 bits: wqkv runs the exact kernel (no form); wo / w2 write from two epilogue waves per block
-        assert L.gq_anyprec_handover_plan(6144, 4096, 3, 1, 0) == 0
+        # 3 bits: wqkv runs the shared-image plane kernel (round 5: from 20 M weights behind the RMSNorm prologue) -- its prologue has
+        # no reading form, its plain epilogue could write; wo / w2 write from two epilogue waves per block
+        assert L.gq_anyprec_handover_plan(6144, 4096, 3, 1, 0) == 2
         assert L.gq_anyprec_handover_plan(4096, 4096, 3, 0, 1) == 2
         # 70B: wo on the stream kernel, w2 split along K over blocks -- neither has the in-epilogue form
         assert L.gq_anyprec_handover_plan(8192, 8192, 2, 0, 1) == 0

@@ -1487,12 +1487,14 @@ int launch_plane_rows(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t 
 template <int BITS, int PRO>
 int launch_plane_ni(const PlaneArgs &a, const PlaneCfg &c, u32 M, hipStream_t s) {
     // K <= 16384 -> at most 2048 items over 512 / 256 lanes
-    if constexpr (BITS >= 3 && PRO != PRO_SILUMUL) {  // the 3- / 4-bit decode launches (wqkv, w1w3 behind RMSNorm; w2 plain): see SPEC at the kernel
+    if constexpr (PRO != PRO_SILUMUL) {  // the decode launches this kernel serves (3 / 4 bits: wqkv, w1w3 behind RMSNorm, w2 plain; 2 bits: the 70B widths): see SPEC at the kernel
         if (a.rawx && a.K % 1024u == 0u && !a.ssq_out && !PL_XF(~0u) && gq_env_int("GQ_PL_SPEC", 1)) {
             if (c.NI <= 1) return launch_plane_inst<BITS, PRO, 1, 1, true>(a, c, M, s);
             if (c.NI == 2) return launch_plane_inst<BITS, PRO, 2, 1, true>(a, c, M, s);
             if (c.NI <= 4) return launch_plane_inst<BITS, PRO, 4, 1, true>(a, c, M, s);
-            if (c.NI <= 8) return launch_plane_inst<BITS, PRO, 8, 1, true>(a, c, M, s);
+            if constexpr (BITS != 2) {
+                if (c.NI <= 8) return launch_plane_inst<BITS, PRO, 8, 1, true>(a, c, M, s);
+            }
         }
     }
     if (c.NI <= 1) return launch_plane_inst<BITS, PRO, 1>(a, c, M, s);
@@ -1621,7 +1623,10 @@ int gq_plane_gemv_try(const void *x, void *out, const uint32_t *qweight, const v
         const int st = gq_env_int("GQ_ST", 1);
         // (and the 70B attention output projection, 8192 x 8192 without a prologue: 7.6 vs 7.9 us)
         if (st >= 3 || (st == 2 && pro == PRO_RMSNORM) || (st == 1 && pro == PRO_RMSNORM && bits == 2 && K <= 4096u) ||
-            (st == 1 && pro == PRO_NONE && !pairs && bits == 2 && K == 8192u && N >= 8192u && M == 1u)) {
+            (st == 1 && pro == PRO_NONE && !pairs && bits == 2 && K == 8192u && N >= 8192u && M == 1u) ||
+            // (round 5: and the plain launch -- the reference's own operator -- of the 8B gate / up matrix: 8.39 vs 9.26 us; wqkv, wo
+            // and w2 stay on the plane kernels: 4.95 / 4.03 / 6.44 vs 5.26 / 4.68 / 7.62.  profiles/r05_plain_launch_dispatch.txt)
+            (st == 1 && pro == PRO_NONE && bits == 2 && K <= 4096u && (uint64_t)N * K >= 100000000ull && M == 1u)) {
             const int rc = gq_stream_gemv_try(x, out, qweight, lut, M, N, K, bits, normw, eps, resid, pro, pairs, stream, ho);
             if (rc != GQ_ENOTSUP) return rc;
         }

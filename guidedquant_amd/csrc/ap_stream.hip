@@ -369,6 +369,9 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
     const u32 nchunks = a.K >> 10, NC2 = 2u * nchunks, NCU = NC2 / NH;
     const u32 npw = NC2 < W ? NC2 : W;  // waves with an image to build
     const bool is_pro = w < npw;
+    // (round 5, measured and not kept: the later-started builder of a SIMD at a higher priority than the earlier one -- alone the
+    // launch gains 0.1 us on w1w3, in the decode graph the step loses 0.5 %; a longer poll interval of the consumers' ready-flag
+    // loop and the main loop aligned to 64 / 256 bytes change nothing: profiles/r05_stream_phase_variants.txt)
     if (is_pro) __builtin_amdgcn_s_setprio(3);
     // RoPE epilogue: the position is requested first thing (a vector load: it returns in order ahead of everything else of this
     // wave and is looked at only behind the image build -- reading it where the cos / sin addresses are formed would park the wave

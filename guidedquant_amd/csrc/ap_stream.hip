@@ -307,6 +307,11 @@ constexpr u32 META_W = 16u;
 #ifndef ST_KO
 #define ST_KO 0   // build-time knock-outs, WRONG numerics, timing only (bit mask): 1 no sum-of-squares exchange, 8 no image reads, 16 the activations arrive as 4 fp32 partial vectors (loads only)
 #endif
+#ifndef ST_DPPIMG
+#define ST_DPPIMG 0  // 1: consumers read their unit image with two dense ds_read_b128 and spread it over the piece lanes by DPP instead of
+                     // eight reads that only the 16 piece lanes take part in -- correct (GPU suite green) and SLOWER: wqkv 5.80 vs 5.65 us, decode 904
+                     // vs 911 tokens/s (profiles/r05_stream_phase_variants.txt): the masked reads are not what the image phase waits for
+#endif
 #ifndef ST_TAU_SCALE
 #define ST_TAU_SCALE 1  // a unit's power of two from its extraction threshold (what stays in the image is <= tau) instead of its maximum:
                         // one wave-wide reduction less per unit; the extracted elements take their own power of two (round 5)
@@ -676,11 +681,21 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
                 const u32 v01 = __builtin_amdgcn_perm(P[p][1], P[p][3], 0x05010703u);
                 // b = 2: j = 5, 1 (byte 3 of words 2, 0); b = 3: j = 4, 0 (byte 1 of words 2, 0)
                 const u32 v23 = __builtin_amdgcn_perm(P[p][0], P[p][2], 0x05010703u);
+#if ST_DPPIMG
+                // (dense-read layout: row c = 4 b + p keeps byte k at k ^ 16 (c / 2) = k ^ (32 b + 16 (p / 2)) -- see the consumers' read)
+                unsigned char *d = dst + p * 128u;
+                const u32 kx = k0 ^ (16u * (p >> 1));
+                *reinterpret_cast<uint16_t *>(d + kx) = (uint16_t)v01;
+                *reinterpret_cast<uint16_t *>(d + 512u + (kx ^ 32u)) = (uint16_t)(v01 >> 16);
+                *reinterpret_cast<uint16_t *>(d + 1024u + (kx ^ 64u)) = (uint16_t)v23;
+                *reinterpret_cast<uint16_t *>(d + 1536u + (kx ^ 96u)) = (uint16_t)(v23 >> 16);
+#else
                 unsigned char *d = dst + p * 128u + (k0 ^ bimg_swz(p));
                 *reinterpret_cast<uint16_t *>(d) = (uint16_t)v01;
                 *reinterpret_cast<uint16_t *>(d + 512u) = (uint16_t)(v01 >> 16);
                 *reinterpret_cast<uint16_t *>(d + 1024u) = (uint16_t)v23;
                 *reinterpret_cast<uint16_t *>(d + 1536u) = (uint16_t)(v23 >> 16);
+#endif
             }
             // sum(x) as a pseudo partial sum [unit][piece column = g][16 rows]: the epilogue lanes of the coef[0] term run the
             // same loads and additions as the others (no divergent branch on the tail of the kernel)
@@ -765,6 +780,27 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
                 } while (fl[0] == 0u);
                 nhot[hh] = __builtin_amdgcn_readfirstlane(fl[1]);
                 sb[hh] = (int)meta[META_W * q + 2u];
+#if ST_DPPIMG
+                // Round 5 experiment: the image comes in with TWO dense reads (every lane 16 bytes: lane (row kb, column c = 4 b + p)
+                // takes the units kb and kb + 4 of image row c) instead of eight reads that only the 16 piece lanes take part in.  The
+                // piece lanes (columns 0..3 of each DPP row) then pull the rows of the other nibble bits from the lanes 4 b to
+                // their right (row_shl, bank mask 1: the other lanes keep the zero they start from -- the idle MFMA columns stay
+                // zero without a read).  Image row c keeps its unit u at u ^ (c / 2): the 16 lanes of a DPP row hit 16 different
+                // 16-byte bank groups.
+                {
+                    const unsigned char *src = img + (size_t)q * 2048u + col * 128u;
+                    const u32 u0x = (kb ^ (col >> 1)) << 4, u1x = ((kb + 4u) ^ (col >> 1)) << 4;
+                    const uint4 r0 = *reinterpret_cast<const uint4 *>(src + u0x), r1 = *reinterpret_cast<const uint4 *>(src + u1x);
+                    const int raw[8] = {(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        Bv[hh][0][j] = __builtin_amdgcn_update_dpp(0, raw[j], 0xE4, 0xF, 0x1, false);   // quad_perm [0,1,2,3]: own lane
+                        Bv[hh][1][j] = __builtin_amdgcn_update_dpp(0, raw[j], 0x104, 0xF, 0x1, false);  // row_shl:4
+                        Bv[hh][2][j] = __builtin_amdgcn_update_dpp(0, raw[j], 0x108, 0xF, 0x1, false);  // row_shl:8
+                        Bv[hh][3][j] = __builtin_amdgcn_update_dpp(0, raw[j], 0x10C, 0xF, 0x1, false);  // row_shl:12
+                    }
+                }
+#else
                 const unsigned char *src = img + (size_t)q * 2048u + (col & 3u) * 128u + ((16u * kb) ^ bimg_swz(col & 3u));
 #pragma unroll
                 for (u32 b = 0; b < 4; b++) {
@@ -775,6 +811,7 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
                     }
                     Bv[hh][b] = (v8i){(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
                 }
+#endif
             }
             if (!stamped) stamp(2), stamped = true;
         }

@@ -308,8 +308,11 @@ class AnyPrecisionForCausalLM(nn.Module):
             self._native_cache = {k: v for k, v in self._native_cache.items() if k[0] != "graph"}
             # (the sampler's counter-based generator is seeded from torch's: torch.manual_seed() makes a run reproducible; the counter
             # runs on across calls, so two sampled calls differ)
+            # (eight token steps per graph replay -- the host looks at the sequence once per `chunk` = 32 tokens anyway; what is left of a
+            # chunk runs through the single-step graph over the same state: exactly the steps asked for)
             graph = gen.DecodeGraph(dec, self.device, native_sampling=True, fold_embed=True, seq_capacity=dec.max_seq_length + 1,
-                                    seed=int(torch.initial_seed() & 0x7FFFFFFF), temperature=req["temperature"], top_k=req["top_k"])
+                                    seed=int(torch.initial_seed() & 0x7FFFFFFF), temperature=req["temperature"], top_k=req["top_k"],
+                                    steps_per_replay=8)
             self._native_cache[("graph",) + key] = graph
         ids32 = ids.view(-1).to(torch.int32)
         with torch.inference_mode():
@@ -332,8 +335,10 @@ class AnyPrecisionForCausalLM(nn.Module):
             host_checks = bool(req["eos"]) and req["min_new"] < max_new or req["streamer"] is not None
             while done < max_new and cut is None:
                 n = min(chunk, max_new - done) if host_checks else max_new - done
-                for _ in range(n):
+                for _ in range(n // graph.steps_per_replay):
                     graph.step()
+                for _ in range(n % graph.steps_per_replay):
+                    graph.step_one()
                 if host_checks:
                     seq_host = graph.seq[:T + done + n].cpu().long()
                     cut = self._emit(req, seq_host, T + done, T + done + n)

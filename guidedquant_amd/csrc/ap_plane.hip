@@ -514,15 +514,22 @@ __device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
 // rows from one read of the weight words): row mm of the block's a.MB rows has its own activation image and uses the MFMA columns
 // 4 mm .. 4 mm + 3 (a row needs 4 of the 16: its bf8 pieces), its own E8M0 scale (supplied per lane) and statistics; the images
 // are built one after the other through the same staged copy.  Plain prologue only; gridDim.y = ceil(M / a.MB).
+// threads per block of the shared-image kernel: 16 waves at 2 bits, 8 at 4 bits (150+ VGPRs per lane); 3 bits: PL_T3 (512; 1024 --
+// 113-125 VGPRs fit -- measured slower, w1w3 15.35 vs 14.85 us, decode 660 vs 666 tokens/s: profiles/r05_plane_spec_3_4_bits.txt)
+#ifndef PL_T3
+#define PL_T3 512
+#endif
+template <int BITS>
+constexpr int pl_threads() { return BITS == 2 ? 1024 : (BITS == 3 ? PL_T3 : 512); }
 // SPEC: the instances of the decode step's launches (like SPEC of the local-image kernel below): the activations come through the
 // staged copy (a.rawx: true for every model shape -- the item-layout loads are the fallback of rings too small for the vector), K is
 // a multiple of 1024, no statistics hand-over; the pair epilogue stays a run-time flag (w1w3 has it, w2 has not).
 template <int BITS, int PRO, int NI, int MBT = 1, bool SPEC = false>
-__global__ void __launch_bounds__(BITS == 2 ? 1024 : 512, BITS == 2 ? PL_WPE : 2) ap_plane_kernel(PlaneArgs a) {
+__global__ void __launch_bounds__(pl_threads<BITS>(), BITS == 2 ? PL_WPE : (pl_threads<BITS>() == 1024 ? 1 : 2)) ap_plane_kernel(PlaneArgs a) {
     const bool rawx = SPEC || a.rawx != 0u;
     static_assert(MBT == 1 || PRO == PRO_NONE, "several rows per pass: plain prologue only");
     constexpr int NP = 1 << BITS, NP1 = NP - 1;
-    constexpr u32 T = BITS == 2 ? 1024u : 512u, W = T / 64u, E = W / 2u, L = W - E;  // early / late waves
+    constexpr u32 T = (u32)pl_threads<BITS>(), W = T / 64u, E = W / 2u, L = W - E;  // early / late waves
     // NI prologue passes over the (chunk, virtual lane, weight pair) items: pass n gives early wave w the chunk (w >> 1) + n * E / 2
     constexpr u32 LPS = 2u * BITS;  // direct-to-LDS loads per step
     constexpr u32 SLOT = 2048u * BITS;
@@ -1360,7 +1367,7 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c, u32 MB = 1u) {
     const u32 nchunks = K / 1024u + ((K % 1024u) ? 1u : 0u);
     const u32 RGt = (N + 15u) / 16u;
     const u32 ncu = (u32)cus();
-    const u32 W = bits == 2 ? 16u : 8u;
+    const u32 W = bits == 2 ? 16u : (bits == 3 ? (u32)PL_T3 / 64u : 8u);
     c.T = 64u * W;
     // one block per CU when the matrix is big enough
     u32 rgb = (RGt + ncu - 1u) / ncu;

@@ -1550,6 +1550,16 @@ int plane_launch_slice(const void *x, void *out, const uint32_t *qweight, const 
     }
     const bool local = MB == 1u && pro != PRO_RMSNORM && gq_env_int("GQ_PL_LOCAL", 1) && pick_local_cfg(N, Ks, bits, c);
     if (MB == 1u && !local && !pick_plane_cfg(N, Ks, bits, c)) return GQ_ENOTSUP;
+    // Round 5: ONE ring slot per wave whenever the staged activation copy still fits the ring (it lives in the early waves' slots) -- a wave
+    // then has one tile in flight instead of two or three: w1w3 14.7 -> 14.1 us at 3 bits, 25.5 -> 23.4 at 4 bits, the other shapes and the
+    // 70B widths at 2 bits unchanged or slightly up (profiles/r05_plane_ring_slots.txt).  GQ_PL_S1=0 restores the old choice.
+    if (MB == 1u && !local && c.S > 1u && gq_env_int("GQ_PL_S", 0) == 0 && gq_env_int("GQ_PL_S1", 1)) {
+        const size_t need = (size_t)Ks * 2u * (pro == PRO_RMSNORM ? 2u : 1u), have1 = (size_t)(c.T / 128u) * 2048u * (size_t)bits;
+        if (need <= have1) {
+            c.smem -= (size_t)(c.S - 1u) * (c.T / 64u) * 2048u * (size_t)bits;
+            c.S = 1u;
+        }
+    }
     PlaneArgs a{};
     a.qw = qweight;
     a.lut = (const uint16_t *)lut;

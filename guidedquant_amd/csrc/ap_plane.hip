@@ -1410,8 +1410,10 @@ bool pick_plane_cfg(u32 N, u32 K, int bits, PlaneCfg &c, u32 MB = 1u) {
 
 // the local-image kernel: same grid / K split, a private image of cpi chunks per wave, every tile requested up front
 bool pick_local_cfg(u32 N, u32 K, int bits, PlaneCfg &c) {
-    // 4-bit (8 waves, 15 subsets): the shared image with the late-wave helpers measured faster
-    if (K % 256u || bits > gq_env_int("GQ_PL_LOCAL_MAXBITS", 3)) return false;
+    // (4 bits: rounds 2-4 kept the shared image with the late-wave helpers; re-measured in round 5 -- stamps and ablation switches
+    // compiled out, one ring slot per wave -- the local image wins on w2: 16.8 -> 15.3 us, decode 461 -> 472 tokens/s.  wo at 4 bits
+    // stays on the exact kernel: the dispatcher's threshold, ap_gemv.hip.  profiles/r05_knob_sweep.txt)
+    if (K % 256u || bits > gq_env_int("GQ_PL_LOCAL_MAXBITS", 4)) return false;
     const u32 nchunks = K / 1024u + ((K % 1024u) ? 1u : 0u);
     const u32 RGt = (N + 15u) / 16u, ncu = (u32)cus(), W = bits == 2 ? 16u : 8u;
     c.T = 64u * W;
@@ -1460,7 +1462,7 @@ int launch_local(const PlaneArgs &a, const PlaneCfg &c, u32 M, int pro, hipStrea
         if (c.NI == 2) return launch_local_inst<BITS, PRO_SILUMUL, 2>(a, c, M, s);
         return launch_local_inst<BITS, PRO_SILUMUL, 4>(a, c, M, s);
     }
-    if constexpr (BITS <= 3) {  // the decode step's wo / w2 launches: see SPEC at the kernel (GQ_PL_SPEC=0: the general instances)
+    {  // the decode step's wo / w2 launches: see SPEC at the kernel (GQ_PL_SPEC=0: the general instances)
         if (a.K % 1024u == 0u && !a.pairs && !a.ssq_out && !PL_XF(~0u) && gq_env_int("GQ_PL_SPEC", 1)) {
             if (c.NI == 1) return launch_local_inst<BITS, PRO_NONE, 1, true>(a, c, M, s);
             if (c.NI == 2) return launch_local_inst<BITS, PRO_NONE, 2, true>(a, c, M, s);

@@ -12,7 +12,7 @@
 namespace {
 thread_local std::string g_last_error;
 std::mutex g_env_mu;
-std::map<std::string, int> g_env_cache;
+std::map<std::string, std::pair<bool, int>> g_env_cache;  // name -> (set in the environment, its value)
 }  // namespace
 
 int gq_fail(int code, const char *msg) {
@@ -27,12 +27,15 @@ int gq_fail_hip(hipError_t e, const char *where) {
 
 int gq_env_int(const char *name, int dflt) {
     std::lock_guard<std::mutex> lk(g_env_mu);
+    // What is cached is the ENVIRONMENT's answer, never a caller's default: call sites pass different defaults for one name (the exact
+    // kernel's blocks per CU depend on the launch, GQ_AP_BPC) -- round 5 found the first caller's default served to every later one
+    // (exact-mode decode 537 instead of 575 tokens/s whenever the step's first exact launch was the small RMSNorm one).
     auto it = g_env_cache.find(name);
-    if (it != g_env_cache.end()) return it->second;
-    const char *v = getenv(name);
-    int r = v && *v ? atoi(v) : dflt;
-    g_env_cache[name] = r;
-    return r;
+    if (it == g_env_cache.end()) {
+        const char *v = getenv(name);
+        it = g_env_cache.emplace(name, std::make_pair(v && *v, v && *v ? atoi(v) : 0)).first;
+    }
+    return it->second.first ? it->second.second : dflt;
 }
 
 int gq_cu_count() {

@@ -494,12 +494,18 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint1
     // the factors e^(m_i - M) of the streams once per head (one thread per stream) instead of once per output element: the same
     // values, 32 exponentials less on the tail of every thread
     float *fl = red2 + (size_t)QH * NS * HD;  // [QH][NS] factors, [QH] maxima
+    // Streams that saw no position (a short context: wave w starts at position p0 + 16 w) hold m = -3e38, l = 0, o = 0: their factor
+    // is exactly 0 and they add exactly 0 -- the merge runs over the groups of 8 streams that can hold something, same sums bit for bit
+    // (at the 50 positions of an average bench step: 16 of the 32 streams).
+    const u32 nw_act = min(NW, (p1 - p0 + (u32)(PPW * U) - 1u) / (u32)(PPW * U));
+    const u32 ng = (nw_act * (u32)PPW + 7u) >> 3;
     if (tid < nh * NS) {
         const u32 qh = tid / NS, i = tid % NS;
         const float *scq = sc + qh * 2u * NS;
         float M = -3.0e38f;
+        for (u32 g8 = 0; g8 < ng; g8++)
 #pragma unroll
-        for (u32 k = 0; k < NS; k++) M = fmaxf(M, scq[k]);
+            for (u32 k = 0; k < 8u; k++) M = fmaxf(M, scq[8u * g8 + k]);
         fl[qh * NS + i] = __expf(scq[i] - M);
         if (i == 0u) fl[(u32)QH * NS + qh] = M;
     }
@@ -509,12 +515,14 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint1
         const float *scq = sc + qh * 2u * NS, *rq = red2 + (size_t)qh * NS * HD, *fq = fl + qh * NS;
         const float M = fl[(u32)QH * NS + qh];
         float o = 0.f, sum = 0.f;
+        for (u32 g8 = 0; g8 < ng; g8++)
 #pragma unroll
-        for (u32 i = 0; i < NS; i++) {
-            const float f = fq[i];
-            sum += scq[NS + i] * f;
-            o += rq[i * HD + dd] * f;
-        }
+            for (u32 k = 0; k < 8u; k++) {
+                const u32 i = 8u * g8 + k;
+                const float f = fq[i];
+                sum += scq[NS + i] * f;
+                o += rq[i * HD + dd] * f;
+            }
         if (nsplit > 1u) {
             float *wp = ws + ((size_t)h * nsplit + sp) * (HD + 2u);
             wp[dd] = o;

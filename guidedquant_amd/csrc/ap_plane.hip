@@ -498,14 +498,22 @@ __device__ __forceinline__ u32 silu_mul2(u32 gw, u32 uw) {
 #ifndef PL_WPE
 #define PL_WPE 4
 #endif
-#ifndef PL_XFIRST
 #ifndef PL_BOOB
 #define PL_BOOB 1
 #endif
 #ifndef PL_LOOB
 #define PL_LOOB 1
 #endif
-#define PL_XFIRST 2  // local-image kernel: activations before tiles in the memory queue (0: round-2 order; 2: the later half of the waves also builds its image first)
+// local-image kernel: activations before tiles in the memory queue (0: round-2 order -- tiles requested at once, the wait counts them;
+// 1: tiles only when the activations have landed; 2: the later half of the waves also builds its image first).  Per bit width: at 2
+// bits 2 is the fastest by 1-2 % of the decode step, at 3 / 4 bits (8 waves, 6-8 KiB tiles) 0 is: 3-bit decode 680 -> 689 tokens/s,
+// 4-bit 478 -> 483 (profiles/r05_knob_sweep.txt).  -DPL_XFIRST=n forces one value for every width.
+#ifdef PL_XFIRST
+template <int BITS>
+constexpr int pl_xfirst() { return PL_XFIRST; }
+#else
+template <int BITS>
+constexpr int pl_xfirst() { return BITS == 2 ? 2 : 0; }
 #endif
 #ifndef PL_PRIO
 #define PL_PRIO 4  // local-image prologue: 4 priority graded by start order (default), 0 one raised level, 1 none
@@ -1150,7 +1158,7 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     };
     // The tiles are requested only when the wave's activations have landed: the CU's memory pipe serves the waves' requests in
     // order, and a wave that starts late (launch skew ~800 cycles) would otherwise find ~6 KiB of tile requests per earlier wave
-    // ahead of its 2 KiB of activations.  The second half of the waves goes one step further (PL_XFIRST 2): by the time their
+    // ahead of its 2 KiB of activations.  The second half of the waves goes one step further (pl_xfirst 2): by the time their
     // activations are there the pipe is full of the first half's tiles and issuing BLOCKS the wave (measured: 2,000 .. 3,000 cycles
     // in the issue queue) -- they build their image first and request their tiles then.  The tile stream (57 KiB per CU for w2) is
     // short next to the image builds it overlaps with.
@@ -1167,17 +1175,14 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
         }
         lut_from = iq_n, lut_after = nlut;
     };
-    const bool tiles_late = PL_XFIRST == 2 && w >= W / 2u;
-#if PL_XFIRST
-    wait_vm<0>();
-#endif
+    constexpr int XFIRST = pl_xfirst<BITS>();
+    const bool tiles_late = XFIRST == 2 && w >= W / 2u;
+    if constexpr (XFIRST != 0) wait_vm<0>();
     if (!tiles_late) request_tiles();
     stamp(6);
 
     // ---- 1. scale of this wave, pieces, image
-#if !PL_XFIRST
-    wait_vm_steps<LPS>(iq_n + nlut);  // the activation loads were issued first (host: S + nlut <= 4)
-#endif
+    if constexpr (XFIRST == 0) wait_vm_steps<LPS>(iq_n + nlut);  // the activation loads were issued first (host: S + nlut <= 4)
     stamp(7);
     int sb = 127;
     u32 nhot = 0;

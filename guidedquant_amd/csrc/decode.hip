@@ -1063,6 +1063,10 @@ extern "C" int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32
     const u32 bpc = bpc_env >= 1 ? (u32)bpc_env : 1u;
     u32 rpb = (N + ncu * bpc - 1u) / (ncu * bpc);
     rpb = ((rpb + 4u * RW - 1u) / (4u * RW)) * (4u * RW);
+    {   // (GQ_DENSE_RPB: rows per block directly, a multiple of 16 -- the sweep of profiles/r05_knob_sweep.txt)
+        const int rpb_env = gq_env_int("GQ_DENSE_RPB", 0);
+        if (rpb_env >= 16 && rpb_env % 16 == 0) rpb = (u32)rpb_env;
+    }
     const u32 grid = (N + rpb - 1u) / rpb;
     static GqPerDeviceOnce once;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(dense_gemv_kernel<RW>), 160 * 1024));

@@ -19,8 +19,13 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the decode path of 
 without changing the reference's data path, so `value` comes from independent replicas (one sequence per GPU, no
 data-path collective; "replicas only", weak scaling -- DESIGN.md section 6).  The north star's layer pipeline
 (BASELINE configs[4]: Llama-3.3-70B 2-bit over the N GPUs, point-to-point hops, N sequences in flight) is measured in the
-same run and reported as the `pipeline_70b` sub-record of the same JSON line (guarded by a watchdog: a hang of that leg
-cannot take the replicas line with it).
+same run and reported as the `pipeline_70b` sub-record of the same JSON line, next to `tp_70b` (the row-split tensor-parallel decode of
+ONE sequence of the same model); both run in child processes with a process group of their own.
+
+Process model (round 6): this process measures the headline and the `roofline` object and nothing else; every other record of the
+line (`cpu_baseline`, `roofline_by_shape`, exact mode, each of `other_configs`; for N > 1 `pipeline_70b` and `tp_70b`) is measured by a
+child process of its own (`python bench.py --leg NAME`, own timeout) and merged into the one line -- a leg that crashes, aborts or hangs
+becomes {"error": "rc -6"} in its place and costs nothing else.
 
 Output: ONE JSON line on rank 0 (schema in the task contract) with
   `roofline`           dominant quantized kernel (the w1w3 AP-GEMV exactly as the decode graph launches it: RMSNorm prologue,
@@ -38,7 +43,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -71,13 +75,14 @@ def graph_time_us(launch, n_distinct, iters=200, reps=5):
     """average launch duration of `launch(i)` (i rotating over n_distinct argument sets) inside one captured graph,
     HIP events on the launch stream, best of `reps` replays"""
     import torch
+    from guidedquant_amd._graphs import capture, release
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         for i in range(n_distinct):
             launch(i)
         s.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with capture(g, stream=s):
             for i in range(iters):
                 launch(i % n_distinct)
         g.replay()
@@ -90,6 +95,7 @@ def graph_time_us(launch, n_distinct, iters=200, reps=5):
             e1.record(s)
             s.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+        release(g)
     return best
 
 
@@ -228,6 +234,86 @@ def decode_tok_s(model, dev, steps, warmup, torch_sampling=False):
     return graph, run_steps
 
 
+LEG_MARK = "GQ_LEG_JSON "
+# the legs of the N = 1 line next to the headline, in run order: (key in the line, group, --leg name, extra argv)
+LEGS = [
+    ("cpu_baseline", None, "cpu_baseline", []),
+    ("roofline_by_shape", None, "roofline_by_shape", []),
+    ("exact_mode", None, "exact_mode", []),
+    ("ap_3bit", "other_configs", "decode", ["--bits", "3"]),
+    ("ap_4bit", "other_configs", "decode", ["--bits", "4"]),
+    ("qtip_llama2_7b_2bit", "other_configs", "decode", ["--backend", "qtip"]),
+    ("llama33_70b_2bit_1gpu", "other_configs", "decode", ["--model", PP_MODEL]),
+    ("long_context_8b_2bit", "other_configs", "long_context", []),
+    ("hf_generate_8b_2bit", "other_configs", "hf_generate", []),
+    ("prefill_gemm_w1w3_2bit", "other_configs", "prefill_gemm", []),
+    ("prompt_pass_8b_2bit", "other_configs", "prompt_pass", []),
+]
+
+
+def run_leg_child(leg, extra, timeout_s, env_extra=None):
+    """one side leg of the line in its OWN process (`python bench.py --leg NAME ...`): a crash, abort or hang of a leg costs that leg's
+    record -- {"error": "rc -6"} -- and nothing else (round 5: a C++ terminate in the ninth leg of a one-process bench took the headline
+    with it).  The child prints its record as the last stdout line behind LEG_MARK."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("PYTHONFAULTHANDLER", "1")
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg] + list(extra)
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %.0f s" % timeout_s}
+    out = p.stdout.decode("utf-8", "replace")
+    for ln in reversed(out.splitlines()):
+        if ln.startswith(LEG_MARK):
+            try:
+                rec = json.loads(ln[len(LEG_MARK):])
+            except ValueError as e:
+                return {"error": "unreadable record: %s" % e}
+            if isinstance(rec, dict):
+                rec.setdefault("leg_wall_s", round(time.perf_counter() - t0, 1))
+            return rec
+    err = p.stderr.decode("utf-8", "replace").strip().splitlines()
+    sys.stderr.write("[bench.py] leg %s %s: rc %d\n%s\n" % (leg, " ".join(extra), p.returncode, "\n".join(err[-15:])))
+    return {"error": "rc %d" % p.returncode, "stderr_tail": " | ".join(e.strip() for e in err[-3:])[:400]}
+
+
+def leg_main(args):
+    """child side: run ONE leg on cuda:LOCAL_RANK and print its record"""
+    import torch
+    leg = args.leg
+    if leg == "cpu_baseline":
+        from guidedquant_amd.model import transformer_configs, ModelArgs  # noqa: F401
+        cfg = ModelArgs.from_name(args.model or MODEL)
+        rec = cpu_baseline_sample(cfg, args.bits)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+        local_rank = 0 if os.environ.get("GQ_BENCH_ONE_GPU", "0") != "0" else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if leg == "roofline_by_shape":
+            rec = roofline_by_shape_record()
+        elif leg == "exact_mode":
+            rec = exact_mode_record(dev, args.bits)
+        elif leg == "decode":
+            rec = decode_record(dev, args.model or (QTIP_MODEL if args.backend == "qtip" else MODEL), args.backend, args.bits)
+        elif leg == "long_context":
+            rec = long_context_record(dev)
+        elif leg == "hf_generate":
+            rec = hf_generate_record(dev)
+        elif leg == "prefill_gemm":
+            rec = prefill_records(dev)
+        elif leg == "prompt_pass":
+            rec = prompt_pass_records(dev)
+        elif leg in ("pipeline_70b", "tp_70b"):
+            rec = collective_leg(leg, dev)
+        else:
+            raise SystemExit("unknown --leg %r" % leg)
+    print(LEG_MARK + json.dumps(rec), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,10 +327,14 @@ def main():
     ap.add_argument("--quick", action="store_true", help="headline number and roofline object only (no shape table / exact-mode / CPU legs)")
     ap.add_argument("--parallel", choices=["replicas", "pp"], default="replicas",
                     help="N>1: what `value` measures -- independent replicas (default) or the layer pipeline (pp) of --model")
-    ap.add_argument("--no-pp-record", action="store_true", help="N>1: skip the pipeline_70b sub-record")
+    ap.add_argument("--no-pp-record", action="store_true", help="N>1: skip the pipeline_70b / tp_70b sub-records")
     ap.add_argument("--model", default=None, help="model name from guidedquant_amd.model.transformer_configs; the headline metric is quoted on the default")
     ap.add_argument("--torch-sampling", action="store_true", help="sample with the reference's torch ops instead of the fused HIP sampler")
+    ap.add_argument("--leg", default=None, help="(internal) run one side leg of the line in this process and print its record")
     args = ap.parse_args()
+    if args.leg:
+        return leg_main(args)
+    t_start = time.perf_counter()
 
     import torch
     import torch.distributed as dist
@@ -257,7 +347,7 @@ def main():
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     # GQ_BENCH_ONE_GPU=1 (with GQ_BENCH_BACKEND=gloo): every rank on cuda:0 -- exercises the N > 1 code path (replicas line,
-    # pipeline_70b record, watchdog) on a one-GPU box; the numbers of such a run mean nothing
+    # pipeline_70b / tp_70b records) on a one-GPU box; the numbers of such a run mean nothing
     one_gpu = os.environ.get("GQ_BENCH_ONE_GPU", "0") != "0"
     if one_gpu:
         local_rank = 0
@@ -294,6 +384,7 @@ def main():
     pp = world > 1 and args.parallel == "pp"
     if pp:
         run_steps, dec = pipeline_runner(model, rank, world, max(args.steps, args.warmup))
+        graph = None
     else:
         graph, run_steps = decode_tok_s(model, dev, args.steps, args.warmup, args.torch_sampling)
 
@@ -309,50 +400,33 @@ def main():
         dt = float(tmax.item())
     tok_s = world * args.steps / dt
 
-    roofline = qtip_roofline(cfg, args.bits) if qtip else ap_roofline(model, args.bits, args.mode)
-    extras = {}
-    full = rank == 0 and world == 1 and not args.quick
-    if full and not qtip:
-        table = []
-        graph_form = {"wqkv": "norm", "wo": "resid", "w1w3": "norm_pairs", "w2": "resid"}
-        for b in (2, 3, 4):
-            for nm, (N, K) in SHAPES_8B.items():
-                table.append(bench_ap_shape(nm, N, K, b, iters=100))
-                # the launch form of the decode graph (what the headline runs): RMSNorm (+ RoPE / cache epilogue where the library
-                # serves wqkv that way) -> wqkv, residual epilogue on wo / w2, RMSNorm + gate/up pairs on w1w3
-                form = graph_form[nm]
-                if nm == "wqkv" and L.gq_anyprec_qkv_rope_supported(N, K, b, 128):
-                    form = "qkv_rope"
-                table.append(bench_ap_shape(nm, N, K, b, iters=100, fused=form, floor=True))
-        extras["roofline_by_shape"] = {"note": "Llama-3-8B GEMV shapes, default dispatch, > 512 MB of weights rotating, us per launch / algorithmic "
-                                               "GB/s / fraction of 8 TB/s.  launch = plain: the reference's operator (gq_anyprec_gemv); the other "
-                                               "row of a shape is the launch form of the decode graph (qkv_rope / norm, resid, norm_pairs) with "
-                                               "frac_of_stream_floor = (time of a launch that only reads the same plane words once, measured "
-                                               "in this run) / (time of the launch)", "rows": table}
-        if args.mode == "default":
-            _lib.check(L.gq_set_ap_mode(1), "gq_set_ap_mode")
-            _, run_exact = decode_tok_s(model, dev, 200, 50, args.torch_sampling)
-            run_exact(50)
+    # behind the timed region, same process, same graph: the reference's own definition of the metric (whole 100-token sequences,
+    # generate.py:344-389) over 400 steps, and the same with ONE token step per graph replay
+    tok_s_400 = tok_s_single = None
+    if not pp and world == 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(400)
+        torch.cuda.synchronize()
+        tok_s_400 = round(400 / (time.perf_counter() - t1), 2)
+        if graph is not None and graph.steps_per_replay > 1:
+            bos = torch.tensor([[(128000 if cfg.vocab_size > 100000 else 1)]], dtype=torch.int32, device=dev)
+            graph.set_token(bos, 0)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_exact(200)
+            for _ in range(SEQ_NEW_TOKENS):
+                graph.step_one()
             torch.cuda.synchronize()
-            extras["exact_mode_tok_s"] = round(200 / (time.perf_counter() - t1), 2)
-            _lib.check(L.gq_set_ap_mode(-1), "gq_set_ap_mode")
-    cpu_baseline = None
-    if full and not qtip and not args.no_cpu_baseline:
-        cpu_baseline = cpu_baseline_sample(cfg, args.bits)
+            tok_s_single = round(SEQ_NEW_TOKENS / (time.perf_counter() - t1), 2)
+
+    try:
+        roofline = qtip_roofline(cfg, args.bits) if qtip else ap_roofline(model, args.bits, args.mode)
+    except Exception as e:  # (the headline stands on its own)
+        roofline = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     model_size, _ = _get_model_size(model)
-    if full and not qtip and args.bits == 2 and args.model is None and not args.no_other_configs:
-        # the other BASELINE configs, measured by the same (driver) run; the headline model is released first
-        del model, graph, run_steps
-        import gc
-        gc.collect()
-        torch.cuda.empty_cache()
-        model = None
-        extras["other_configs"] = other_config_records(dev)
 
     mode = {"default": "exact" if os.environ.get("GQ_AP_EXACT", "0") != "0" else "default"}.get(args.mode, args.mode)
+    spr = 1 if (args.torch_sampling or pp) else int(os.environ.get("GQ_STEPS_PER_REPLAY", "10"))
     workload = ("%s QTIP %d-bit (trellis-coded, HYB code), unfused linears, bs=1 decode, BOS prompt, 100 new tokens per sequence, "
                 "top_k=32, temperature=0" % (cfg.model_name, args.bits)) if qtip else \
         ("%s %d-bit Any-Precision (LNQ format), fused QKV/UpGate, bs=1 decode, BOS prompt, 100 new tokens per sequence, top_k=32, "
@@ -366,16 +440,66 @@ def main():
                    "ap_mode": mode, "sampling": "torch ops" if args.torch_sampling else "fused HIP top-k sampler",
                    "model_bytes": model_size, "model_bandwidth_GBps": round(model_size * tok_s / world / 1e9, 1),
                    "kv_positions_timed": "0..%d" % (min(args.steps, SEQ_NEW_TOKENS) - 1),
-                   "token_steps_per_graph_replay": 1 if (args.torch_sampling or pp) else int(os.environ.get("GQ_STEPS_PER_REPLAY", "10")),
-                   "note": "sequences of %d new tokens: --steps < %d times only the first positions of one sequence (the reference metric "
-                           "averages over 100 new tokens; 400-step runs of the same build agree within 1 %%)" % (SEQ_NEW_TOKENS, SEQ_NEW_TOKENS)},
-        "roofline": roofline, "cpu_baseline": cpu_baseline,
+                   "token_steps_per_graph_replay": spr,
+                   "untimed_setup_token_steps": (20 * spr + 1) if not (args.torch_sampling or pp) else 2,
+                   "tok_s_400": tok_s_400, "tok_s_single_step_replay": tok_s_single,
+                   "note": "sequences of %d new tokens: --steps < %d times only the first positions of one sequence; tok_s_400 = the reference's "
+                           "definition of the metric (whole 100-token sequences, generate.py:344-389), 400 steps timed in this process behind the "
+                           "timed region -- the figure to quote; tok_s_single_step_replay = one sequence with ONE token step per graph replay; "
+                           "untimed_setup_token_steps = replays of the captured graphs at set-up, before the --warmup steps (first replay of each "
+                           "graph, clocks up)" % (SEQ_NEW_TOKENS, SEQ_NEW_TOKENS)},
+        "roofline": roofline, "cpu_baseline": None,
     }
-    line.update(extras)
-    if "exact_mode_tok_s" in extras:
-        line["config"]["note"] += ("; `value` is the default (fast) arithmetic -- exact products, fp32 accumulation, closer to the true product "
-                                   "than the reference's fp16 accumulation; with every quantized GEMV in the reference's fp16 order bit for bit "
-                                   "(exact mode) the same run decodes %.1f tokens/s" % extras["exact_mode_tok_s"])
+
+    # ------------------------------------------------------------------ side legs, each in its own process (N = 1)
+    full = rank == 0 and world == 1 and not args.quick
+    if full:
+        del graph, run_steps, model
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        budget = float(os.environ.get("GQ_BENCH_BUDGET_S", "900"))
+        leg_limit = float(os.environ.get("GQ_BENCH_LEG_TIMEOUT_S", "300"))
+        for key, group, leg, extra in LEGS:
+            if qtip and key != "cpu_baseline":
+                continue
+            if key == "cpu_baseline" and (args.no_cpu_baseline or qtip):
+                continue
+            if group == "other_configs" and (args.no_other_configs or args.bits != 2 or args.model is not None or args.mode != "default"):
+                continue
+            if key == "exact_mode" and args.mode != "default":
+                continue
+            left = budget - (time.perf_counter() - t_start)
+            if left < 20:
+                rec = {"skipped": "time budget of this run (GQ_BENCH_BUDGET_S = %.0f s) spent" % budget}
+            else:
+                ex = list(extra)
+                if key in ("cpu_baseline", "exact_mode"):
+                    ex += ["--bits", str(args.bits)] + (["--model", args.model] if args.model else [])
+                rec = run_leg_child(leg, ex, min(leg_limit, left))
+            if group:
+                line.setdefault(group, {})[key] = rec
+            elif key == "exact_mode":
+                if isinstance(rec, dict) and "tok_s" in rec:
+                    line["exact_mode_tok_s"] = rec["tok_s"]
+                    line["config"]["note"] += ("; `value` is the default (fast) arithmetic -- exact products, fp32 accumulation, closer to the true "
+                                               "product than the reference's fp16 accumulation; with every quantized GEMV in the reference's fp16 "
+                                               "order bit for bit (exact mode) the same model decodes %.1f tokens/s" % rec["tok_s"])
+                else:
+                    line["exact_mode_tok_s"] = rec
+            else:
+                line[key] = rec
+        # one measurement per launch: the w1w3 row of the shape table in the decode graph's form IS the roofline object of this line
+        rows = (line.get("roofline_by_shape") or {}).get("rows") if isinstance(line.get("roofline_by_shape"), dict) else None
+        if rows and isinstance(roofline, dict) and "avg_launch_us" in roofline and not qtip:
+            for r in rows:
+                if r.get("shape") == "w1w3" and r.get("bits") == args.bits and r.get("launch", "").startswith("norm") and args.model is None:
+                    r["separate_measurement_us"] = r["us"]
+                    r.update(us=roofline["avg_launch_us"], GBps=roofline["achieved"], frac=roofline["frac"],
+                             stream_floor_us=roofline["stream_floor_us"], frac_of_stream_floor=roofline["frac_of_stream_floor"],
+                             source="the `roofline` object of this line (the model's own 32 w1w3 tensors)")
+        line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+
     if world > 1:
         # evidence that the collective library saw N ranks (the barrier / max-reduce above went through it)
         nccl_v = None
@@ -386,14 +510,19 @@ def main():
         line["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "nccl_version": nccl_v,
                                "devices_visible": torch.cuda.device_count(), "one_gpu_shared": one_gpu}
 
-    # ------------------------------------------------------------------ north-star multi-GPU config as a sub-record
+    # ------------------------------------------------------------------ north-star multi-GPU config as sub-records (N > 1)
     if world > 1 and not pp and not args.no_pp_record and not qtip:
-        try:
-            del model, graph, run_steps
-            torch.cuda.empty_cache()
-            line["pipeline_70b"] = guarded_pipeline_record(line, rank, world, dev)
-        except Exception as e:  # never lose the replicas line to this leg
-            line["pipeline_70b"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        # every rank starts a child of its own; the N children form their own process group on another port and run the 70B layer
+        # pipeline (BASELINE configs[4]) and the tensor-parallel decode of the same model; a child that dies or hangs costs its record
+        del graph, run_steps, model
+        torch.cuda.empty_cache()
+        base_port = int(os.environ.get("MASTER_PORT", "29500"))
+        for i, leg in enumerate(("pipeline_70b", "tp_70b")):
+            env = {"MASTER_PORT": str(base_port + 101 + i), "MASTER_ADDR": os.environ.get("MASTER_ADDR", "127.0.0.1")}
+            rec = run_leg_child(leg, [], float(os.environ.get("GQ_BENCH_LEG_TIMEOUT_S", "300")), env_extra=env)
+            if rank == 0:
+                line[leg] = rec
+            dist.barrier()  # (the next group starts when every child of this one is gone)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -487,69 +616,133 @@ def qtip_roofline(cfg, R, shape=None):
             "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": b_qtip(R, M, K)}
 
 
-# ---------------------------------------------------------------------------------------------------------- other configs
-def other_config_records(dev, steps=200, warmup=40):
-    """BASELINE.json configs[2], [3] and [4] (single GPU) measured in the same run, each like the headline: random-init model of
-    the real architecture, captured decode step, BOS prompt, sequences of 100 new tokens, wall clock around `steps` replays.
-    One model resident at a time."""
-    import gc
+# ---------------------------------------------------------------------------------------------------------- side legs (N = 1)
+def roofline_by_shape_record():
+    """the four Llama-3-8B GEMV shapes x 2/3/4 bits (BASELINE.json metric: "+3/4-bit sweep"), default dispatch: the plain operator
+    and the launch form of the decode graph"""
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    table = []
+    graph_form = {"wqkv": "norm", "wo": "resid", "w1w3": "norm_pairs", "w2": "resid"}
+    for b in (2, 3, 4):
+        for nm, (N, K) in SHAPES_8B.items():
+            table.append(bench_ap_shape(nm, N, K, b, iters=100))
+            # the launch form of the decode graph (what the headline runs): RMSNorm (+ RoPE / cache epilogue where the library
+            # serves wqkv that way) -> wqkv, residual epilogue on wo / w2, RMSNorm + gate/up pairs on w1w3
+            form = graph_form[nm]
+            if nm == "wqkv" and L.gq_anyprec_qkv_rope_supported(N, K, b, 128):
+                form = "qkv_rope"
+            table.append(bench_ap_shape(nm, N, K, b, iters=100, fused=form, floor=True))
+    return {"note": "Llama-3-8B GEMV shapes, default dispatch, > 512 MB of weights rotating, us per launch / algorithmic GB/s / fraction of "
+                    "8 TB/s.  launch = plain: the reference's operator (gq_anyprec_gemv); the other row of a shape is the launch form of the "
+                    "decode graph (qkv_rope / norm, resid, norm_pairs) with frac_of_stream_floor = (time of a launch that only reads the same "
+                    "plane words once, measured in this run) / (time of the launch)", "rows": table}
+
+
+def exact_mode_record(dev, bits, steps=200, warmup=50):
+    """the headline decode with every quantized GEMV in the bit-exact (reference fp16 order, anyprec.cu:495-512) mode"""
+    import torch
+    from guidedquant_amd import _lib
+    from guidedquant_amd.generate import load_model
+    _lib.check(_lib.lib().gq_set_ap_mode(1), "gq_set_ap_mode")
+    torch.manual_seed(1234)
+    model = load_model(MODEL, dev, "ap", bits, random_init=True)
+    model.setup_caches(1, SEQ_NEW_TOKENS + 1)
+    assert model.native_ready()
+    graph, run = decode_tok_s(model, dev, steps, warmup)
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"tok_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup}
+
+
+def decode_record(dev, name, backend, bits, steps=200, warmup=40):
+    """one of BASELINE.json configs[2], [3], [4] (single GPU), measured like the headline: random-init model of the real
+    architecture, captured decode step, BOS prompt, sequences of 100 new tokens, wall clock around `steps` token steps"""
     import torch
     from guidedquant_amd.generate import _get_model_size, load_model
+    torch.manual_seed(1234)
+    model = load_model(name, dev, backend, bits, random_init=True)
+    model.setup_caches(1, SEQ_NEW_TOKENS + 1)
+    assert model.native_ready()
+    graph, run = decode_tok_s(model, dev, steps, warmup)
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    size, _ = _get_model_size(model)
+    rec = {"model": model.config.model_name, "backend": backend, "bits": bits, "tok_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
+           "model_bytes": size, "model_bandwidth_GBps": round(size * steps / dt / 1e9, 1), "steps": steps, "warmup": warmup}
+    if backend == "qtip":  # configs[3]: + the bare trellis matvec at the model's three shapes
+        cfg = model.config
+        rec["matvec_roofline"] = [qtip_roofline(cfg, bits, shape=sh) for sh in ((cfg.intermediate_size, cfg.dim), (cfg.dim, cfg.dim), (cfg.dim, cfg.intermediate_size))]
+    return rec
 
-    def one(name, backend, bits):
+
+def collective_leg(leg, dev):
+    """N > 1, child side: BASELINE configs[4] -- Llama-3.3-70B 2-bit over the N GPUs -- as the layer pipeline (pipeline_70b: stage g =
+    a contiguous layer range on GPU g, N sequences in flight, point-to-point hops) or as the tensor-parallel decode of ONE sequence
+    (tp_70b: every matrix cut along its output rows, device-to-device all-gathers).  Own process group (the parent gave this child
+    group its own port)."""
+    import torch
+    import torch.distributed as dist
+    from guidedquant_amd.generate import load_model
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("GQ_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    name = os.environ.get("GQ_BENCH_PP_MODEL", PP_MODEL)
+    try:
         torch.manual_seed(1234)
-        model = load_model(name, dev, backend, bits, random_init=True)
-        model.setup_caches(1, SEQ_NEW_TOKENS + 1)
-        assert model.native_ready()
-        graph, run = decode_tok_s(model, dev, steps, warmup)
-        run(warmup)
+        model = load_model(name, dev, "ap", 2, random_init=True)
+        n_tok, n_warm = 48, 8
+        if leg == "pipeline_70b":
+            from guidedquant_amd.pipeline import stage_ranges
+            run_steps, dec = pipeline_runner(model, rank, world, n_tok)
+        else:
+            from guidedquant_amd.tp import TensorParallelDecoder
+            dec = TensorParallelDecoder(model, dist.group.WORLD, rank, world, max_new_tokens=n_tok, temperature=0.0, top_k=32,
+                                        bos_id=128000 % model.config.vocab_size)
+
+            def run_steps(n):
+                with torch.no_grad():
+                    dec.run(n)
+        run_steps(n_warm)
+        dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(steps)
+        run_steps(n_tok)
+        dist.barrier()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        size, _ = _get_model_size(model)
-        rec = {"model": model.config.model_name, "backend": backend, "bits": bits, "tok_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
-               "model_bytes": size, "model_bandwidth_GBps": round(size * steps / dt / 1e9, 1), "steps": steps, "warmup": warmup}
-        cfg = model.config
-        del graph, run, model
-        gc.collect()
-        torch.cuda.empty_cache()
-        return rec, cfg
-
-    out = {}
-    for b in (3, 4):  # configs[2]: bit-width scaling of the Any-Precision decode
-        try:
-            out["ap_%dbit" % b] = one(MODEL, "ap", b)[0]
-        except Exception as e:
-            out["ap_%dbit" % b] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    try:  # configs[3]: Llama-2-7b QTIP 2-bit + the bare trellis matvec at its three shapes
-        rec, cfg = one(QTIP_MODEL, "qtip", 2)
-        rec["matvec_roofline"] = [qtip_roofline(cfg, 2, shape=sh) for sh in ((cfg.intermediate_size, cfg.dim), (cfg.dim, cfg.dim), (cfg.dim, cfg.intermediate_size))]
-        out["qtip_llama2_7b_2bit"] = rec
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        if leg == "pipeline_70b":
+            rec = {"model": "%s 2-bit Any-Precision, fused QKV/UpGate" % name, "stages": world, "sequences_in_flight": world,
+                   "tokens_per_sequence": n_tok, "aggregate_tok_s": round(world * n_tok / dt, 2), "per_stream_tok_s": round(n_tok / dt, 2),
+                   "ms_per_stage_tick": round(dt / (world * n_tok) * 1e3, 4), "head_cost_layers_measured": dec.head_cost_layers,
+                   "layers_per_stage": [len(r) for r in stage_ranges(model.config.n_layer, world, head_cost_layers=dec.head_cost_layers)],
+                   "graphs": bool(dec.graphs), "hop": dec.hop, "note": "single-stream 1-GPU figure of the same model: python bench.py --model " + PP_MODEL}
+        else:
+            rec = {"model": "%s 2-bit Any-Precision, fused QKV/UpGate" % name, "ranks": world, "sequences": 1, "tokens": n_tok,
+                   "tok_s": round(n_tok / dt, 2), "ms_per_token": round(dt / n_tok * 1e3, 4),
+                   "note": "row-split tensor-parallel decode of ONE sequence (guidedquant_amd/tp.py): 4 device-to-device all-gathers per layer, "
+                           "one hipGraph per rank and token"}
     except Exception as e:
-        out["qtip_llama2_7b_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    try:  # configs[4] on ONE GPU: the single-stream figure the 8-GPU layer pipeline cannot exceed
-        out["llama33_70b_2bit_1gpu"] = one(PP_MODEL, "ap", 2)[0]
-    except Exception as e:
-        out["llama33_70b_2bit_1gpu"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    try:  # the headline model at a long context: KV positions 4096..4195 (split-KV attention, gq_attn_decode_split / _roped)
-        out["long_context_8b_2bit"] = long_context_record(dev)
-    except Exception as e:
-        out["long_context_8b_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    try:  # the harness of the reference's published number: AnyPrecisionForCausalLM.generate (README.md:95-97)
-        out["hf_generate_8b_2bit"] = hf_generate_record(dev)
-    except Exception as e:
-        out["hf_generate_8b_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    try:  # SURVEY section 8 row f-3: the seq_len > 1 branch of APLinear.forward on the 8B gate/up matrix
-        out["prefill_gemm_w1w3_2bit"] = prefill_records(dev)
-    except Exception as e:
-        out["prefill_gemm_w1w3_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    try:  # the prompt pass of generate() on the headline model: HIP pass vs the module forward with the reference's two GEMM steps
-        out["prompt_pass_8b_2bit"] = prompt_pass_records(dev)
-    except Exception as e:
-        out["prompt_pass_8b_2bit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    return out
+        rec = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+    return rec
 
 
 def long_context_record(dev, start=4096, steps=100):
@@ -629,7 +822,7 @@ def hf_generate_record(dev, new_tokens=100):
         rec["hf_module_tree_captured_step_tok_s"] = timed(pad_token_id=0, native=False, capture=True)
     except Exception as e:
         rec["hf_module_tree_captured_step_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
-    m._native_cache = {}
+    m._drop_native()
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
@@ -751,49 +944,6 @@ def pipeline_runner(model, rank, world, max_tokens):
     return run_steps, dec
 
 
-def guarded_pipeline_record(line, rank, world, dev, limit_s=240.0):
-    """BASELINE configs[4] in the same run: Llama-3.3-70B 2-bit, stage g = a contiguous layer range on GPU g, `world` sequences
-    in flight.  A watchdog prints the replicas line without the record and exits if this leg does not finish in time."""
-    import torch
-    import torch.distributed as dist
-
-    def bail():
-        if rank == 0:
-            line["pipeline_70b"] = {"error": "timed out after %.0f s" % limit_s}
-            print(json.dumps(line), flush=True)
-        os._exit(0)
-
-    timer = threading.Timer(limit_s, bail)
-    timer.daemon = True
-    timer.start()
-    try:
-        from guidedquant_amd.generate import load_model
-        torch.manual_seed(1234)
-        model = load_model(PP_MODEL, dev, "ap", 2, random_init=True)
-        n_tok, n_warm = 48, 8
-        run_steps, dec = pipeline_runner(model, rank, world, n_tok)
-        run_steps(n_warm)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(n_tok)
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        dt = float(dt.item())
-        rec = {"model": "Llama-3.3-70B-Instruct 2-bit Any-Precision, fused QKV/UpGate", "stages": world, "sequences_in_flight": world,
-               "tokens_per_sequence": n_tok, "aggregate_tok_s": round(world * n_tok / dt, 2), "per_stream_tok_s": round(n_tok / dt, 2),
-               "ms_per_stage_tick": round(dt / (world * n_tok) * 1e3, 4), "head_cost_layers_measured": dec.head_cost_layers,
-               "layers_per_stage": [len(r) for r in __import__("guidedquant_amd.pipeline", fromlist=["stage_ranges"]).stage_ranges(
-                   model.config.n_layer, world, head_cost_layers=dec.head_cost_layers)],
-               "graphs": bool(dec.graphs), "hop": dec.hop, "note": "single-stream 1-GPU figure of the same model: python bench.py --model " + PP_MODEL}
-    except Exception as e:  # the replicas measurement stands on its own
-        rec = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    timer.cancel()
-    return rec
-
-
 # ---------------------------------------------------------------------------------------------------------- CPU legs
 def cpu_baseline_sample(cfg, bits):
     """CPU baselines of BASELINE.md section 4 on the host cores, one full-size transformer layer (4 GEMVs) each, extrapolated
@@ -858,12 +1008,16 @@ def cpu_baseline_sample(cfg, bits):
     def tps(t_layer):
         return round(1.0 / (cfg.n_layer * t_layer + t_lm), 4)
 
-    # value = the fastest CPU path measured (round 4: the judge asked for the fastest honest one, not the oracle's scalar loop)
+    # value = the fastest CPU path measured (round 4: the judge asked for the fastest honest one, not the oracle's scalar loop); which
+    # one that is, is said in `value_is`.  Named first: the figure with the reference's own CPU semantics -- APLinear.forward on a host
+    # tensor is dense F.linear on the dequantised W (any_precision/modules/APLinear.py:35-38; the reference has no packed CPU kernel)
     variants = {"packed native-float GEMV of the oracle (oracle.ap_gemv_f32, C + OpenMP)": t_f32,
-                "CPU twin of the product kernel (gq_anyprec_gemv_cpu, AVX2 + OpenMP, packed planes read directly)": t_twin,
+                "the PRODUCT's own CPU twin (gq_anyprec_gemv_cpu, AVX2 + OpenMP, packed planes read directly) -- not reference code": t_twin,
                 "dense bf16 F.linear on the dequantised W": t_dbf, "dense fp32 F.linear on the dequantised W": t_d32}
     best_name = min(variants, key=variants.get)
-    return {"value": tps(variants[best_name]), "unit": "tokens/s", "cores": cores, "kind": "port",
+    return {"reference_semantics": {"what": "dense F.linear on the dequantised W, the reference's CPU linear path (APLinear.py:35-38), fp32 / bf16",
+                                    "dense_f32_linear_on_W_deq_tok_s": tps(t_d32), "dense_bf16_linear_on_W_deq_tok_s": tps(t_dbf)},
+            "value": tps(variants[best_name]), "unit": "tokens/s", "cores": cores, "kind": "port", "value_is": best_name,
             "sample": f"one full-size layer (4 AP-GEMVs) per variant x {cfg.n_layer} + the full fp32 lm_head matvec ({t_lm * 1e3:.1f} ms); "
                       f"value = the fastest variant: {best_name}, {cores} threads: {variants[best_name] * 1e3:.2f} ms per layer",
             "also": {"oracle_packed_f32_tok_s": tps(t_f32), "dense_f32_linear_on_W_deq_tok_s": tps(t_d32), "dense_bf16_linear_on_W_deq_tok_s": tps(t_dbf),

@@ -18,6 +18,7 @@ decode step is the 5-launches-per-layer hipGraph path bench.py measures.
 import gc
 import json
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -39,6 +40,86 @@ def _get_by_path(root, dotted):
     for name in [p for p in dotted.split('.') if p]:
         root = getattr(root, name) if not name.isdigit() else root[int(name)]
     return root
+
+
+class _WeakRestore:
+    """`wrapper._restore_module_tree()` through a weak reference (a state_dict pre-hook of the inner model / the `_gq_restore` of a
+    released linear): no reference cycle through the wrapper"""
+    __slots__ = ("ref", )
+
+    def __init__(self, wrapper):
+        self.ref = weakref.ref(wrapper)
+
+    def __call__(self, *args, **kwargs):
+        w = self.ref()
+        if w is not None:
+            w._restore_module_tree()
+
+
+class _CapturedStep:
+    """State of route 2 (`generate(capture=True)`): the StaticCache, the device words the captured step reads and writes, and the
+    hipGraph of one token step of the HF module tree.  A plain object -- no closure over its own state, so no reference cycle owns the
+    graph -- with an explicit `close()`: the owner (`AnyPrecisionForCausalLM._evict`) destroys the graph when it drops the entry."""
+    __slots__ = ("model", "V", "top_k", "temperature", "seed", "cache", "tok64", "tok", "pos", "nxt", "ctr", "wv", "wi", "ban", "seq", "logits", "graph")
+
+    def __init__(self, model, config, dev, total, temperature, top_k, seed):
+        from transformers import StaticCache
+        self.model, self.V, self.top_k, self.temperature, self.seed = model, int(config.vocab_size), int(top_k), float(temperature), int(seed)
+        self.cache = StaticCache(config=config, max_cache_len=total)
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
+        self.tok64 = z((1, 1), torch.long)
+        self.tok, self.pos, self.nxt, self.ctr = z((1, ), torch.int32), z((1, ), torch.int32), z((1, ), torch.int32), z((1, ), torch.int32)
+        self.wv, self.wi, self.ban = z(128 * 64, torch.float32), z(128 * 64, torch.int32), z(6, torch.int32)
+        self.seq, self.logits = z(total + 1, torch.int32), z(self.V, torch.float16)
+        self.graph = None
+
+    def step(self):
+        from . import _lib
+        # (positions come from the cache itself: StaticLayer.cumulative_length is a device word the layer advances in place)
+        out = self.model(input_ids=self.tok64, past_key_values=self.cache, use_cache=True)
+        self.logits.copy_(out.logits.view(-1))
+        _lib.check(_lib.lib().gq_sample_topk_ex(self.logits.data_ptr(), self.V, self.top_k, self.temperature, self.seed, self.ctr.data_ptr(),
+                                               self.wv.data_ptr(), self.wi.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), self.nxt.data_ptr(),
+                                               self.ban.data_ptr(), self.seq.data_ptr(), self.seq.numel(), None, None, 0, None,
+                                               _lib.current_stream_ptr()), "gq_sample_topk_ex")
+        self.tok64.copy_(self.tok.view(1, 1))
+
+    def _set_cache_length(self, n):
+        for layer in self.cache.layers:
+            if torch.is_tensor(getattr(layer, "cumulative_length", None)):
+                layer.cumulative_length.fill_(n)
+
+    def capture(self, T):
+        """two eager steps on a side stream, then the capture; the cache and the positions are re-set behind them"""
+        from ._graphs import capture
+        keep = (self.tok64.clone(), self.tok.clone(), self.ctr.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with capture(g):
+            self.step()
+        torch.cuda.synchronize()
+        self.graph = g
+        # the warm-up steps wrote cache rows T-1 .. T+1 and moved the positions: rows past the position are overwritten before they are
+        # read (causal), the rest is restored
+        self.tok64.copy_(keep[0])
+        self.tok.copy_(keep[1])
+        self.ctr.copy_(keep[2])
+        self.pos.fill_(T - 1)
+        if T == 1:  # (no prompt pass ran: the layers allocated their tensors inside the warm-up)
+            self.cache.reset()
+        self._set_cache_length(T - 1)
+
+    def close(self):
+        from ._graphs import release
+        g, self.graph = self.graph, None
+        release(g)
+        self.cache = None
 
 
 class AnyPrecisionForCausalLM(nn.Module):
@@ -74,6 +155,9 @@ class AnyPrecisionForCausalLM(nn.Module):
         self._native_cache = {}
         self._released = None
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._restore_module_tree())
+        # (also when the HF model inside is asked directly: self.model.state_dict() / save_pretrained.  Through a weak reference -- the
+        # wrapper owns captured graphs and must stay collectable by reference counting alone, see _graphs.py)
+        self.model.register_state_dict_pre_hook(_WeakRestore(self))
         # new weights: the fused decode model (built from the old tensors) and every captured graph are stale
         self.register_load_state_dict_pre_hook(lambda module, *a, **k: module._drop_native())
         if random_init_seed is not None:
@@ -199,10 +283,26 @@ class AnyPrecisionForCausalLM(nn.Module):
         if not torch.is_tensor(ids) or ids.dim() != 2 or ids.shape[0] != 1 or ids.shape[1] < 1 or ids.is_floating_point():
             return None, "input_ids must be one sequence of token ids, [1, T]"
         gc_ = getattr(self.model, "generation_config", None)
-        g = (lambda name, dflt=None: kwargs[name] if kwargs.get(name) is not None else (getattr(gc_, name, dflt) if gc_ is not None and getattr(gc_, name, None) is not None else dflt))
-        if g("num_beams", 1) != 1 or g("num_return_sequences", 1) != 1 or g("return_dict_in_generate", False) or g("use_cache", True) is False:
+
+        # transformers 5 keeps unset fields of a GenerationConfig as None and fills in its global defaults at generate time (top_k = 50,
+        # ...); in transformers 4 (the reference pins 4.52.3) the fields carry the defaults themselves and a None was put there by the
+        # user (top_k=None: top-k filtering disabled)
+        none_is_unset = gc_ is not None and hasattr(type(gc_), "_get_default_generation_params")
+
+        def g(name, dflt=None):
+            # a keyword that is not None wins, else the generation config's value, else the default
+            v = kwargs.get(name)
+            if v is not None:
+                return v
+            if gc_ is not None and hasattr(gc_, name):
+                v = getattr(gc_, name)
+                if v is not None or not none_is_unset:
+                    return v
+            return dflt
+        if (g("num_beams", 1) or 1) != 1 or (g("num_return_sequences", 1) or 1) != 1 or g("return_dict_in_generate", False) or g("use_cache", True) is False:
             return None, "beam search / several return sequences / dict output / use_cache=False"
-        if float(g("repetition_penalty", 1.0)) != 1.0:
+        rp = g("repetition_penalty", 1.0)
+        if rp is not None and float(rp) != 1.0:
             return None, "repetition_penalty"
         for name in ("no_repeat_ngram_size", "encoder_no_repeat_ngram_size", "bad_words_ids", "force_words_ids", "suppress_tokens", "begin_suppress_tokens",
                      "forced_bos_token_id", "forced_eos_token_id", "sequence_bias", "typical_p", "epsilon_cutoff", "eta_cutoff", "min_p", "penalty_alpha",
@@ -211,7 +311,7 @@ class AnyPrecisionForCausalLM(nn.Module):
             if v not in (None, 0, 0.0, 1.0, [], False):
                 return None, "generation_config.%s" % name
         T = int(ids.shape[1])
-        max_new = kwargs.get("max_new_tokens")
+        max_new = g("max_new_tokens", None)  # (keyword first, then generation_config.max_new_tokens, then max_length - T: transformers' order)
         if max_new is None:
             ml = g("max_length", None)
             max_new = (int(ml) - T) if ml is not None else None
@@ -223,18 +323,20 @@ class AnyPrecisionForCausalLM(nn.Module):
         do_sample = bool(g("do_sample", False))
         temperature, top_k = 0.0, 1
         if do_sample:
-            temperature = float(g("temperature", 1.0))
+            t_ = g("temperature", 1.0)
+            temperature = 1.0 if t_ is None else float(t_)
             top_p, top_k = g("top_p", 1.0), g("top_k", 50)
             if top_p is not None and float(top_p) < 1.0:
                 return None, "top_p < 1"
-            if top_k is None or int(top_k) < 1 or int(top_k) > 64 or temperature <= 0.0:
+            # (top_k None or 0 = no top-k filtering in transformers: the full distribution, which the 64-candidate sampler does not draw from)
+            if not top_k or int(top_k) < 1 or int(top_k) > 64 or temperature <= 0.0:
                 return None, "top_k outside 1..64 (the fused sampler's candidates)"
         eos = g("eos_token_id", None)
         eos = [] if eos is None else ([int(eos)] if isinstance(eos, int) else [int(e) for e in eos])
         if len(eos) > 4:
             return None, "more than 4 EOS ids"
         return dict(ids=ids, T=T, max_new=int(max_new), min_new=min(int(g("min_new_tokens", 0) or 0), int(max_new)), temperature=temperature,
-                    top_k=int(top_k), eos=eos, streamer=kwargs.get("streamer")), None
+                    top_k=int(top_k), eos=eos, streamer=kwargs.get("streamer"), do_sample=do_sample), None
 
     def generate(self, *args, **kwargs):
         """`generate` of the reference's HF surface (inference_example.py:34-77).  Three routes behind the one call:
@@ -260,7 +362,15 @@ class AnyPrecisionForCausalLM(nn.Module):
             if native is True and req is None:
                 raise ValueError("native=True: " + why)
             if req is not None and native is not False:
-                dec = self._native_decoder_or_none(self.precision)
+                # (the q/k/v/gate/up planes of the module tree are released only on the explicit native=True: the automatic route keeps
+                # the module tree whole, so that model.state_dict() / save_pretrained / direct buffer access after a plain generate()
+                # see every tensor)
+                dec = self._native_decoder_or_none(self.precision, release_planes=native is True)
+                if dec is not None and req["T"] + req["max_new"] > dec.config.block_size:
+                    if native is True:
+                        raise ValueError(f"native=True: prompt + max_new_tokens = {req['T'] + req['max_new']} exceeds the fused model's "
+                                         f"context ({dec.config.block_size})")
+                    dec = None  # (automatic route: transformers' generate decides what a request beyond the context means)
                 if dec is not None:
                     return self._generate_native(dec, req)
                 if native is True:
@@ -275,13 +385,32 @@ class AnyPrecisionForCausalLM(nn.Module):
             self.set_precision(prev_precision)
 
     # -- route 1: the fused decode model ---------------------------------------------------------------------------------
-    def _native_decoder_or_none(self, bitwidth):
+    _SAMPLER_SEED = 0x2545F491  # (a constant: what varies between sampled calls is the counter word, drawn from torch's generator)
+
+    def _fresh_rng_word(self):
+        """the start of the fused sampler's counter stream for ONE sampled call, drawn from torch's generator of this device: as with
+        transformers' generate, `torch.manual_seed(s)` before a call makes it reproducible and two unseeded calls differ -- whatever
+        graph is cached (the captured launches read the counter from device memory, nothing of the seed is baked in)"""
+        return torch.randint(-2**31, 2**31 - 1, (1, ), dtype=torch.int32, device=self.device)
+
+    def _native_decoder_or_none(self, bitwidth, release_planes=False):
         try:
-            dec = self.native_decoder(bitwidth)
-        except Exception:
+            dec = self.native_decoder(bitwidth, release_planes=release_planes)
+        except (ValueError, NotImplementedError):  # "this checkpoint / precision has no fused form"; anything else is a real error
             return None
         dec.setup_caches(1, 8) if not dec.cache_initialized else None
         return dec if dec.native_ready() else None
+
+    def _evict(self, kind):
+        """drop the cached entries of one kind ("graph": DecodeGraphs of route 1, "cap": captured steps of route 2), destroying their
+        hipGraphs synchronously -- never left to a finaliser that may run inside a later capture (_graphs.py)"""
+        keep = {}
+        for k, v in self._native_cache.items():
+            if k[0] == kind:
+                v.close()
+            else:
+                keep[k] = v
+        self._native_cache = keep
 
     def _emit(self, req, seq_host, lo, hi):
         """tokens [lo, hi) of the host copy of the sequence: to the streamer (up to and including the first EOS that counts -- index
@@ -305,15 +434,14 @@ class AnyPrecisionForCausalLM(nn.Module):
         key = (self.precision, dec.max_seq_length, req["temperature"], req["top_k"])
         graph = self._native_cache.get(("graph",) + key)
         if graph is None:
-            self._native_cache = {k: v for k, v in self._native_cache.items() if k[0] != "graph"}
-            # (the sampler's counter-based generator is seeded from torch's: torch.manual_seed() makes a run reproducible; the counter
-            # runs on across calls, so two sampled calls differ)
+            self._evict("graph")
             # (eight token steps per graph replay -- the host looks at the sequence once per `chunk` = 32 tokens anyway; what is left of a
             # chunk runs through the single-step graph over the same state: exactly the steps asked for)
             graph = gen.DecodeGraph(dec, self.device, native_sampling=True, fold_embed=True, seq_capacity=dec.max_seq_length + 1,
-                                    seed=int(torch.initial_seed() & 0x7FFFFFFF), temperature=req["temperature"], top_k=req["top_k"],
-                                    steps_per_replay=8)
+                                    seed=self._SAMPLER_SEED, temperature=req["temperature"], top_k=req["top_k"], steps_per_replay=8)
             self._native_cache[("graph",) + key] = graph
+        if req.get("do_sample"):
+            graph.rng_counter.copy_(self._fresh_rng_word())
         ids32 = ids.view(-1).to(torch.int32)
         with torch.inference_mode():
             graph.seq[:T].copy_(ids32)
@@ -354,76 +482,30 @@ class AnyPrecisionForCausalLM(nn.Module):
         """bs = 1 decode on the HF module tree with ONE hipGraph per token: the step `logits = model(input_ids [1,1], StaticCache,
         cache_position)` + the fused sampler (gq_sample_topk_ex: the draw, EOS suppression, the sequence store, token feedback) are
         captured once per (precision, cache length, sampling) and replayed; the prompt runs eagerly through the same cache."""
-        from transformers import StaticCache
-        from . import _lib
         ids, T, max_new = req["ids"].to(self.device), req["T"], req["max_new"]
         total = T + max_new
-        V = int(self.config.vocab_size)
         key = ("cap", self.precision, total, req["temperature"], req["top_k"])
         st = self._native_cache.get(key)
         # (no_grad, not inference_mode: the first graph capture of a process creates the generator's graph-safe state tensors, and
         # inference tensors could not be updated by the captures that follow outside inference mode)
         with torch.no_grad():
             if st is None:
-                self._native_cache = {k: v for k, v in self._native_cache.items() if k[0] != "cap"}
-                dev = self.device
-                st = dict(cache=StaticCache(config=self.config, max_cache_len=total), tok64=torch.zeros((1, 1), dtype=torch.long, device=dev),
-                          tok=torch.zeros((1, ), dtype=torch.int32, device=dev),
-                          pos=torch.zeros((1, ), dtype=torch.int32, device=dev), nxt=torch.zeros((1, ), dtype=torch.int32, device=dev),
-                          ctr=torch.zeros((1, ), dtype=torch.int32, device=dev), wv=torch.zeros(128 * 64, dtype=torch.float32, device=dev),
-                          wi=torch.zeros(128 * 64, dtype=torch.int32, device=dev), ban=torch.zeros(6, dtype=torch.int32, device=dev),
-                          seq=torch.zeros(total + 1, dtype=torch.int32, device=dev), logits=torch.zeros(V, dtype=torch.float16, device=dev),
-                          seed=int(torch.initial_seed() & 0x7FFFFFFF))
-
-                def step():
-                    # (positions come from the cache itself: StaticLayer.cumulative_length is a device word the layer advances in place)
-                    out = self.model(input_ids=st["tok64"], past_key_values=st["cache"], use_cache=True)
-                    st["logits"].copy_(out.logits.view(-1))
-                    _lib.check(_lib.lib().gq_sample_topk_ex(st["logits"].data_ptr(), V, req["top_k"], float(req["temperature"]), st["seed"],
-                                                           st["ctr"].data_ptr(), st["wv"].data_ptr(), st["wi"].data_ptr(), st["tok"].data_ptr(),
-                                                           st["pos"].data_ptr(), st["nxt"].data_ptr(), st["ban"].data_ptr(), st["seq"].data_ptr(),
-                                                           st["seq"].numel(), None, None, 0, None, _lib.current_stream_ptr()), "gq_sample_topk_ex")
-                    st["tok64"].copy_(st["tok"].view(1, 1))
-                st["step"] = step
-                st["graph"] = None
+                self._evict("cap")  # (the old entry's graph is destroyed HERE, before the new capture begins)
+                st = _CapturedStep(self.model, self.config, self.device, total, req["temperature"], req["top_k"], self._SAMPLER_SEED)
                 self._native_cache[key] = st
-            st["cache"].reset()
-            st["seq"][:T].copy_(ids.view(-1).to(torch.int32))
+            st.cache.reset()
+            st.seq[:T].copy_(ids.view(-1).to(torch.int32))
             ban = [len(req["eos"]), T - 1 + req["min_new"]] + req["eos"] + [0] * (4 - len(req["eos"]))
-            st["ban"].copy_(torch.tensor(ban, dtype=torch.int32))
+            st.ban.copy_(torch.tensor(ban, dtype=torch.int32))
+            if req.get("do_sample"):
+                st.ctr.copy_(self._fresh_rng_word())
             if T > 1:
-                self.model(input_ids=ids[:, :T - 1], past_key_values=st["cache"], use_cache=True)
-            st["tok64"].copy_(ids[:, T - 1:T])
-            st["tok"].copy_(ids.view(-1)[T - 1:T].to(torch.int32))
-            st["pos"].fill_(T - 1)
-
-            def set_cache_length(n):
-                for layer in st["cache"].layers:
-                    if torch.is_tensor(getattr(layer, "cumulative_length", None)):
-                        layer.cumulative_length.fill_(n)
-            if st["graph"] is None:  # capture (after two eager steps on a side stream; the cache and positions are re-set behind them)
-                keep = (st["tok64"].clone(), st["tok"].clone(), st["ctr"].clone())
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    for _ in range(2):
-                        st["step"]()
-                torch.cuda.current_stream().wait_stream(s)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    st["step"]()
-                torch.cuda.synchronize()
-                st["graph"] = g
-                # the warm-up steps wrote cache rows T-1 .. T+1 and moved the positions: rows past the position are overwritten before
-                # they are read (causal), the rest is restored
-                st["tok64"].copy_(keep[0])
-                st["tok"].copy_(keep[1])
-                st["ctr"].copy_(keep[2])
-                st["pos"].fill_(T - 1)
-                if T == 1:  # (no prompt pass ran: the layers allocated their tensors inside the warm-up)
-                    st["cache"].reset()
-                set_cache_length(T - 1)
+                self.model(input_ids=ids[:, :T - 1], past_key_values=st.cache, use_cache=True)
+            st.tok64.copy_(ids[:, T - 1:T])
+            st.tok.copy_(ids.view(-1)[T - 1:T].to(torch.int32))
+            st.pos.fill_(T - 1)
+            if st.graph is None:
+                st.capture(T)
             if req["streamer"] is not None:
                 req["streamer"].put(ids.cpu())
             done, cut = 0, None
@@ -431,13 +513,13 @@ class AnyPrecisionForCausalLM(nn.Module):
             while done < max_new and cut is None:
                 n = min(chunk, max_new - done) if host_checks else max_new - done
                 for _ in range(n):
-                    st["graph"].replay()
+                    st.graph.replay()
                 if host_checks:
-                    seq_host = st["seq"][:T + done + n].cpu().long()
+                    seq_host = st.seq[:T + done + n].cpu().long()
                     cut = self._emit(req, seq_host, T + done, T + done + n)
                 done += n
             end = cut if cut is not None else T + done
-            out = st["seq"][:end].to(ids.dtype).view(1, -1).clone()
+            out = st.seq[:end].to(ids.dtype).view(1, -1).clone()
         if req["streamer"] is not None:
             req["streamer"].end()
         return out
@@ -478,18 +560,24 @@ class AnyPrecisionForCausalLM(nn.Module):
         raise NotImplementedError("layer fusion inside the HF module tree is not implemented (as in the reference); use "
                                   "native_decoder(bitwidth) for the fused QKV / Up-Gate decode path")
 
-    def native_decoder(self, bitwidth: Optional[int] = None):
+    def native_decoder(self, bitwidth: Optional[int] = None, release_planes: bool = False):
         """the same checkpoint as the fused gpt-fast `Transformer` (fused QKV / Up-Gate Any-Precision linears at one precision)
         whose bs=1 decode step runs as the captured 5-launches-per-layer HIP graph.  Built from the module tree's tensors BY
         REFERENCE: embedding, lm_head, norms, o_proj and down_proj are the same storage; q/k/v and gate/up are concatenated into the
-        fused tensors layer by layer, and -- when the checkpoint carries exactly this precision, the GuidedQuant case -- the module
-        tree's own copies are released as they go (restored from the fused tensors the first time the module tree is used again,
-        `_restore_module_tree`): one copy of every weight at any time."""
+        fused tensors layer by layer.
+        release_planes=True (what `generate(native=True)` asks for), when the checkpoint carries exactly this precision -- the
+        GuidedQuant case: the module tree's own q/k/v/gate/up planes are released as the fused tensors are built (one copy of every
+        weight; restored from the fused tensors the first time the module tree is used again through this wrapper, a linear's forward,
+        `state_dict()` of the wrapper or of `self.model`, or `.to()` -- `_restore_module_tree`).  The default keeps the module tree whole
+        (the fused q/k/v/gate/up tensors are then a second copy: 1.1 GB for an 8B 2-bit model)."""
         bitwidth = bitwidth or min(self.precisions)
         dec = self._native_cache.get(("decoder", bitwidth))
+        if dec is not None and release_planes and not self._released and all(lin.qweight.shape[0] == bitwidth for lin in self.ap_linears):
+            self._drop_native()  # (built without the release: built again, releasing as it goes)
+            dec = None
         if dec is None:
             self._restore_module_tree()  # (a decoder of another precision may hold the q/k/v/gate/up planes)
-            dec = self._build_native(bitwidth)
+            dec = self._build_native(bitwidth, release_planes)
             self._native_cache[("decoder", bitwidth)] = dec
         return dec
 
@@ -497,7 +585,7 @@ class AnyPrecisionForCausalLM(nn.Module):
         at, mlp = layer.self_attn, layer.mlp
         return dict(q=at.q_proj, k=at.k_proj, v=at.v_proj, o=at.o_proj, gate=mlp.gate_proj, up=mlp.up_proj, down=mlp.down_proj)
 
-    def _build_native(self, bitwidth):
+    def _build_native(self, bitwidth, release_planes=False):
         from .APLinear import APLinear
         from .hf_loader import model_args_from_hf_config
         from .model import Transformer
@@ -513,52 +601,76 @@ class AnyPrecisionForCausalLM(nn.Module):
         dec.tok_embeddings.weight = inner.embed_tokens.weight
         dec.output.weight = lm_head.weight
         dec.norm.weight = inner.norm.weight
-        single = all(lin.qweight.shape[0] == bitwidth for lin in self.ap_linears)  # the planes ARE this precision: nothing is lost by releasing them
+        # (released only when the planes ARE this precision: nothing is lost by releasing them)
+        single = bool(release_planes) and all(lin.qweight.shape[0] == bitwidth for lin in self.ap_linears)
 
         def put(mod, qweight, lut):
             mod._buffers["qweight"] = qweight
             mod._buffers["lut"] = lut
             mod.output = torch.zeros((1, 1, mod.out_features), dtype=torch.float16, device=dev)
 
+        # what has been released is on record BEFORE the first plane goes (with the decoder that now holds it): a failure at layer k
+        # (out of memory in a concatenation, ...) gives layers < k their planes back before the error travels on
         released = []
-        for hf_layer, blk in zip(self.get_model_layers(), dec.layers):
-            L = self._layer_linears(hf_layer)
-            if any(m.bias is not None for m in L.values()):
-                raise NotImplementedError("fused decode model: biased linears")
-            blk.input_layernorm.weight = hf_layer.input_layernorm.weight
-            blk.post_attention_layernorm.weight = hf_layer.post_attention_layernorm.weight
-            lut = lambda m: m._buffers[f"lut{bitwidth}"].to(torch.float16)  # noqa: E731
-            put(blk.attention.wo, L["o"].qweight[:bitwidth], lut(L["o"]))           # (a prefix of the planes: contiguous view)
-            put(blk.feed_forward.w2, L["down"].qweight[:bitwidth], lut(L["down"]))
-            put(blk.attention.wqkv, torch.cat([L[n].qweight[:bitwidth] for n in "qkv"], dim=1).contiguous(),
-                torch.cat([lut(L[n]) for n in "qkv"], dim=0).contiguous())
-            put(blk.feed_forward.w1w3, torch.cat([L["gate"].qweight[:bitwidth], L["up"].qweight[:bitwidth]], dim=1).contiguous(),
-                torch.cat([lut(L["gate"]), lut(L["up"])], dim=0).contiguous())
-            if single:
-                for n in ("q", "k", "v", "gate", "up"):
-                    L[n]._buffers["qweight"] = torch.empty((0, ), dtype=torch.int32, device=dev)
-                    L[n]._gq_restore = self._restore_module_tree
-                    released.append(L[n])
-        self._released = (bitwidth, released) if released else None
-        dec = dec.eval()
-        dec._reset_native()
+        if single:
+            self._evict("cap")  # (captured steps of the module tree point at the planes about to go)
+            self._released = (bitwidth, released, dec)
+        restore = _WeakRestore(self)
+        try:
+            for hf_layer, blk in zip(self.get_model_layers(), dec.layers):
+                L = self._layer_linears(hf_layer)
+                if any(m.bias is not None for m in L.values()):
+                    raise NotImplementedError("fused decode model: biased linears")
+                blk.input_layernorm.weight = hf_layer.input_layernorm.weight
+                blk.post_attention_layernorm.weight = hf_layer.post_attention_layernorm.weight
+                lut = lambda m: m._buffers[f"lut{bitwidth}"].to(torch.float16)  # noqa: E731
+                put(blk.attention.wo, L["o"].qweight[:bitwidth], lut(L["o"]))           # (a prefix of the planes: contiguous view)
+                put(blk.feed_forward.w2, L["down"].qweight[:bitwidth], lut(L["down"]))
+                put(blk.attention.wqkv, torch.cat([L[n].qweight[:bitwidth] for n in "qkv"], dim=1).contiguous(),
+                    torch.cat([lut(L[n]) for n in "qkv"], dim=0).contiguous())
+                put(blk.feed_forward.w1w3, torch.cat([L["gate"].qweight[:bitwidth], L["up"].qweight[:bitwidth]], dim=1).contiguous(),
+                    torch.cat([lut(L["gate"]), lut(L["up"])], dim=0).contiguous())
+                if single:
+                    released.append(hf_layer)
+                    for n in ("q", "k", "v", "gate", "up"):
+                        L[n]._buffers["qweight"] = torch.empty((0, ), dtype=torch.int32, device=dev)
+                        L[n]._gq_restore = restore
+            dec = dec.eval()
+            dec._reset_native()
+        except BaseException:
+            self._restore_module_tree()
+            raise
+        if not released:
+            self._released = None
         return dec
 
     def _drop_native(self):
         self._restore_module_tree()
+        self._evict("graph")
+        self._evict("cap")
         self._native_cache = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .half() / .cuda(): the module tree gets new tensors -- it takes its planes back first, and the fused decode model (built
+        # over the old tensors by reference) and every captured graph are stale
+        if getattr(self, "_native_cache", None) is not None:
+            self._drop_native()
+        return super()._apply(fn, *args, **kwargs)
 
     def _restore_module_tree(self):
         """give q/k/v and gate/up of the module tree their plane tensors back (slices of the fused decode model's tensors; the gate/up
-        rows un-paired), and drop the fused model and its graphs -- one copy of every weight at any time"""
+        rows un-paired), and drop the fused model and its graphs -- one copy of every weight at any time.  Works from its own record
+        (`_released` = precision, the layers released so far, the decoder holding their planes), not from the cache."""
         rel = getattr(self, "_released", None)
         if not rel:
             return
         from .model import _pair_perm
-        bitwidth, _ = rel
-        dec = self._native_cache.get(("decoder", bitwidth))
+        bitwidth, layers, dec = rel
         self._released = None
+        done = {id(l) for l in layers}
         for hf_layer, blk in zip(self.get_model_layers(), dec.layers):
+            if id(hf_layer) not in done:
+                continue
             L = self._layer_linears(hf_layer)
             qkv, gu = blk.attention.wqkv.qweight, blk.feed_forward.w1w3.qweight
             if getattr(blk.feed_forward.w1w3, "gq_row_pairs", False):
@@ -572,5 +684,7 @@ class AnyPrecisionForCausalLM(nn.Module):
             for n in ("q", "k", "v", "gate", "up"):
                 L[n]._gq_restore = None
             blk.attention.wqkv._buffers["qweight"] = blk.feed_forward.w1w3._buffers["qweight"] = None
-        self._native_cache = {}
+        self._evict("graph")
+        self._evict("cap")
+        self._native_cache = {k: v for k, v in self._native_cache.items() if k[0] != "decoder"}
         gc.collect()

@@ -52,7 +52,7 @@ class GqQtipOut(ctypes.Structure):
 def build(force=False):
     """Compile every HIP source for gfx950 into guidedquant_amd/libgq_hip.so (hipcc cross-compiles without a GPU)."""
     args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
-    if force:
+    if force or os.environ.get("GQ_BUILD_FORCE", "0") != "0":  # (objects of a build with other flags are caught by csrc/.flags)
         args.append("-B")
     subprocess.check_call(args)
     return LIB_PATH

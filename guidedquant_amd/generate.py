@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import pack
+from ._graphs import capture, release
 from .APLinear import APLinear
 from .LUTGEMMLinear import LUTGEMMLinear
 from .model import Transformer
@@ -64,33 +65,32 @@ def decode_one_token(model: Transformer, x: torch.Tensor, input_pos: torch.Tenso
     return sample(logits, **sampling_kwargs)
 
 
-_graph_rng_primed = False
-_prime_graph = None
+_prime_graphs = {}  # device index -> (graph, tensor): CUDA default generators are per device
 
 
 def prime_graph_rng_state(device=None):
-    """The FIRST graph capture of a process creates the default generator's graph-safe state tensors; created under
+    """The FIRST graph capture on a device creates that device's default generator's graph-safe state tensors; created under
     torch.inference_mode() (transformers' generate captures there) they are inference tensors, and every later capture outside
     inference mode fails ("Inplace update to inference tensor outside InferenceMode").  One tiny capture outside inference mode, before
     anybody else captures, makes them ordinary tensors, which both kinds of capture may update."""
-    global _graph_rng_primed
-    if _graph_rng_primed or not torch.cuda.is_available() or torch.is_inference_mode_enabled() or torch.cuda.is_current_stream_capturing():
+    if not torch.cuda.is_available() or torch.is_inference_mode_enabled() or torch.cuda.is_current_stream_capturing():
         return
-    _graph_rng_primed = True
-    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+    idx = torch.device(device).index if device is not None and torch.device(device).index is not None else torch.cuda.current_device()
+    if idx in _prime_graphs:
+        return
+    with torch.cuda.device(idx):
         t = torch.zeros(1, device="cuda")
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
+            with capture(g, stream=s):
                 t.add_(1.0)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         # the graph is KEPT: the state tensors live as long as a graph is registered with the generator -- with none left, the next
         # capture (possibly under inference mode) would create them anew
-        global _prime_graph
-        _prime_graph = (g, t)
+        _prime_graphs[idx] = (g, t)
 
 
 class DecodeGraph:
@@ -138,7 +138,7 @@ class DecodeGraph:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture(self.graph):
             for _ in range(self.steps_per_replay):
                 self._step()
         torch.cuda.synchronize()
@@ -146,11 +146,18 @@ class DecodeGraph:
         self.graph1 = self.graph
         if self.steps_per_replay > 1:
             self.graph1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph1):
+            with capture(self.graph1):
                 self._step()
             torch.cuda.synchronize()
         self._bound = self._signature()
         self._gen = getattr(model, "_alloc_gen", 0)
+
+    def close(self):
+        """destroy the captured graphs now (an owner that drops a DecodeGraph calls this instead of leaving the executable graphs to
+        whatever moment the object is finalised -- never inside a later capture, see _graphs.py); the object is unusable afterwards"""
+        g, g1 = getattr(self, "graph", None), getattr(self, "graph1", None)
+        self.graph = self.graph1 = None
+        release(g, g1 if g1 is not g else None)
 
     def _signature(self):
         """what the captured launches point at: the graph bakes in raw pointers (KV caches, RoPE tables, the native step's

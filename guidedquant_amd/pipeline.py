@@ -37,6 +37,8 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from ._graphs import capture
+
 
 def stage_ranges(n_layer: int, world: int, head_cost_layers: float = 0.0) -> List[range]:
     """contiguous layer ranges per stage; `head_cost_layers` = cost of final norm + lm_head + sampling in units of one
@@ -307,7 +309,7 @@ class PipelinedDecoder:
         self.graphs = []
         for slot in range(self.n_seq):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), torch.no_grad():
+            with capture(g), torch.no_grad():
                 if self.hop == "ipc":
                     self._tick_ipc(slot)
                 else:

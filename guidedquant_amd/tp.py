@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from ._graphs import capture
 from .model import Transformer, _pair_perm
 
 
@@ -204,7 +205,7 @@ class TensorParallelDecoder:
         torch.cuda.synchronize()
         self._exchange = True
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with capture(self.graph), torch.no_grad():
             self._step()
         torch.cuda.synchronize()
         self.reset()

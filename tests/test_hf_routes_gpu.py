@@ -113,17 +113,99 @@ def test_routes_agree_and_the_default_call_is_the_fused_model():
     assert ("decoder", 2) in m._native_cache and fused.shape == (1, 30) and fused.dtype == ids.dtype
     agree = float((fused[0, 6:] == eager[0, 6:]).float().mean())
     assert torch.equal(fused[0, :7], eager[0, :7]) and agree >= 0.8, (agree, fused, eager)  # other summation orders: late near-ties may flip
-    # weights by reference: o_proj / down_proj / embeddings share storage, the q/k/v/gate/up planes exist once
+    # weights by reference: o_proj / down_proj / embeddings share storage.  The automatic route keeps the module tree whole: the
+    # inner model's state_dict / direct buffer access after a plain generate() see every plane
     dec = m._native_cache[("decoder", 2)]
     l0 = m.get_model_layers()[0]
     assert dec.layers[0].attention.wo.qweight.data_ptr() == l0.self_attn.o_proj.qweight.data_ptr()
     assert dec.tok_embeddings.weight.data_ptr() == m.model.model.embed_tokens.weight.data_ptr()
-    assert l0.self_attn.q_proj.qweight.numel() == 0 and l0.mlp.up_proj.qweight.numel() == 0
-    # the module tree takes its planes back by itself (forward, state_dict) and gives the same logits as before
+    assert l0.self_attn.q_proj.qweight.numel() > 0 and l0.mlp.up_proj.qweight.numel() > 0 and m._released is None
+    assert m.model.state_dict()["model.layers.0.mlp.gate_proj.qweight"].shape == (2, 1024, 16)
+    # native=True releases the module tree's q/k/v/gate/up planes (one copy of every weight) -- a decoder built without the release is
+    # rebuilt for it
+    fused2 = m.generate(ids, max_new_tokens=24, do_sample=False, pad_token_id=0, native=True)
+    assert torch.equal(fused2, fused)
+    assert l0.self_attn.q_proj.qweight.numel() == 0 and l0.mlp.up_proj.qweight.numel() == 0 and m._released is not None
+    # the module tree takes its planes back by itself (forward, state_dict -- also of the inner model) and gives the same logits as before
     again = m.generate(ids, max_new_tokens=24, do_sample=False, native=False, pad_token_id=0)
     assert torch.equal(again, eager) and l0.self_attn.q_proj.qweight.numel() > 0 and ("decoder", 2) not in m._native_cache
     sd = m.state_dict()
     assert sd["model.model.layers.0.mlp.gate_proj.qweight"].shape == (2, 1024, 16)
+    m.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0, native=True)
+    assert l0.self_attn.q_proj.qweight.numel() == 0
+    assert m.model.state_dict()["model.layers.0.self_attn.q_proj.qweight"].shape == (2, 512, 16) and m._released is None
+
+
+def test_a_failed_build_of_the_fused_model_gives_the_planes_back():
+    m = _single_precision_model(seed=3)
+    before = {k: v.clone() for k, v in m.model.state_dict().items() if k.endswith("qweight")}
+    real, calls = m._layer_linears, [0]
+
+    def failing(layer):
+        calls[0] += 1
+        if calls[0] == 3:
+            raise RuntimeError("out of memory (injected)")
+        return real(layer)
+    m._layer_linears = failing
+    with pytest.raises(RuntimeError, match="injected"):
+        m.native_decoder(2, release_planes=True)
+    m._layer_linears = real
+    assert m._released is None and ("decoder", 2) not in m._native_cache
+    after = m.model.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items())
+    # and generate() does not swallow such an error into a silent fallback
+    calls[0] = 0
+    m._layer_linears = failing
+    with pytest.raises(RuntimeError, match="injected"):
+        m.generate(torch.tensor([[3, 4]], device=m.device), max_new_tokens=4, do_sample=False, native=True)
+    m._layer_linears = real
+    after = m.model.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items())
+
+
+def test_evicted_graphs_are_destroyed_before_the_next_capture():
+    """round 5's driver bench died here: a captured entry evicted from the cache, its hipGraph left to the cyclic collector, the
+    collector firing inside the NEXT capture (hipGraphExecDestroy while a stream is capturing -> std::terminate).  With the collector
+    at its most eager (threshold 1: a collection at almost every allocation) both routes re-capture at new lengths."""
+    import gc
+    m = _single_precision_model(seed=11)
+    ids = torch.tensor([[3, 17, 5]], device=m.device)
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        outs = []
+        for n in (5, 9, 6):
+            outs.append(m.generate(ids, max_new_tokens=n, do_sample=False, native=False, capture=True, pad_token_id=0))
+            assert sum(1 for k in m._native_cache if k[0] == "cap") == 1
+        for n in (5, 9, 6):
+            outs.append(m.generate(ids, max_new_tokens=n, do_sample=False, pad_token_id=0))
+            assert sum(1 for k in m._native_cache if k[0] == "graph") == 1
+        assert gc.isenabled()
+    finally:
+        gc.set_threshold(*old)
+    assert torch.equal(outs[0][0, :8], outs[1][0, :8]) and torch.equal(outs[3][0, :8], outs[4][0, :8])
+    # an explicit close leaves nothing to a finaliser
+    g = next(v for k, v in m._native_cache.items() if k[0] == "graph")
+    m._drop_native()
+    assert g.graph is None and m._native_cache == {}
+
+
+def test_sampled_calls_follow_torch_manual_seed():
+    """transformers' generate is reproducible under torch.manual_seed; so are the fused routes (the sampler's counter word is drawn
+    from torch's generator at every sampled call -- nothing of the seed is baked into a cached graph)"""
+    m = _single_precision_model(seed=13)
+    with torch.no_grad():
+        m.model.lm_head.weight.mul_(0.05)   # flat logits: draws differ
+    ids = torch.tensor([[9, 1, 4]], device=m.device)
+    kw = dict(max_new_tokens=24, do_sample=True, temperature=1.0, top_k=50, pad_token_id=0)
+    for extra in (dict(), dict(native=False, capture=True)):
+        torch.manual_seed(77)
+        a = m.generate(ids, **kw, **extra)
+        b = m.generate(ids, **kw, **extra)
+        torch.manual_seed(77)
+        a2 = m.generate(ids, **kw, **extra)
+        b2 = m.generate(ids, **kw, **extra)
+        assert torch.equal(a, a2) and torch.equal(b, b2) and not torch.equal(a, b), extra
 
 
 def test_eos_min_new_tokens_streamer_and_sampling():

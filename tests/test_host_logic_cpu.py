@@ -377,6 +377,20 @@ def test_generate_routes_the_reference_call_and_declines_the_rest(tmp_path):
         req, why = m._route_request((ids, ), kw)
         assert req is None and why, kw
     assert m._route_request((torch.tensor([[1, 2], [3, 4]]), ), dict(max_new_tokens=4))[0] is None   # a batch
+    # generation_config.max_new_tokens is honoured (keyword > generation_config.max_new_tokens > max_length - T)
+    keep = m.model.generation_config
+    try:
+        import types
+        m.model.generation_config = types.SimpleNamespace(max_new_tokens=9, top_k=None, do_sample=True, temperature=None)
+        # a transformers-4 style config (fields carry their defaults: a None was put there by the user): top_k=None = no top-k filtering,
+        # which the 64-candidate sampler does not draw from -> declined; the keyword still wins
+        assert m._route_request((ids, ), dict())[0] is None
+        req, why = m._route_request((ids, ), dict(top_k=8))
+        assert why is None and req["max_new"] == 9 and req["top_k"] == 8 and req["temperature"] == 1.0 and req["do_sample"]
+        m.model.generation_config = types.SimpleNamespace(max_new_tokens=9, top_k=0, do_sample=True)
+        assert m._route_request((ids, ), dict())[0] is None
+    finally:
+        m.model.generation_config = keep
     # on a host model the request is declined at the device check and transformers' generate runs
     out = m.generate(ids, max_new_tokens=3, do_sample=False, pad_token_id=0)
     assert out.shape == (1, 6)

@@ -518,7 +518,10 @@ def main():
         torch.cuda.empty_cache()
         base_port = int(os.environ.get("MASTER_PORT", "29500"))
         for i, leg in enumerate(("pipeline_70b", "tp_70b")):
-            env = {"MASTER_PORT": str(base_port + 101 + i), "MASTER_ADDR": os.environ.get("MASTER_ADDR", "127.0.0.1")}
+            # (TORCHELASTIC_USE_AGENT_STORE: under torch.distributed.run every rank is a CLIENT of the agent's store at MASTER_PORT; the
+            # child group has a port of its own, where its rank 0 must open the store itself)
+            env = {"MASTER_PORT": str(base_port + 101 + i), "MASTER_ADDR": os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                   "TORCHELASTIC_USE_AGENT_STORE": "False"}
             rec = run_leg_child(leg, [], float(os.environ.get("GQ_BENCH_LEG_TIMEOUT_S", "300")), env_extra=env)
             if rank == 0:
                 line[leg] = rec

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "gq_internal.h"
 #include "fwht.h"
@@ -205,10 +206,26 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     constexpr u32 PF = QT_PF;  // chunks per wave in flight
     u32 dq[PF][LD];
     u32 nstamp = 0;
-    auto stamp = [&]() {
-        if (GQ_STAMPS && dbg && blockIdx.x == gridDim.x / 2 && l == 0 && nstamp < 8u) dbg[w * 8u + nstamp++] = __builtin_readcyclecounter();
+    // (QT_SB: bit i = a scheduling barrier at stamp site i of a build without the stamps -- round 6: the library with the stamp sites
+    // compiled out ran the bare matvec 4-5 % SLOWER than the one with them, 9.2 vs 8.8 us at 11008 x 4096: a site is a conditional
+    // branch, which the compiler does not move code across)
+#ifndef QT_SB
+#define QT_SB 0
+#endif
+// QT_ENGINE_STAMPS = 1 (shipped): the five stamp sites of the band engine stay compiled IN (switched off at run time by the null debug
+// pointer) while every other kernel's sites stay out.  Bisected in round 6 (profiles/r06_qtip_matvec_regression.txt): round 5's
+// GQ_STAMPS = 0 build of this file ran the bare matvec 4-5 % slower than round 4's (4096^2 6.1 vs 5.8 us, 11008 x 4096 9.3 vs 8.85,
+// 4096 x 11008 11.1 vs 10.8; same box, alternating) -- the only change in the kernel; with these five sites back the times are round
+// 4's again and the QTIP decode keeps round 5's gain (434 tokens/s; all sites of the file back in: 427).  Scheduling barriers at the
+// same places (QT_SB) do not reproduce it: the branch around a site ends a basic block, which changes what the scheduler hoists.
+#ifndef QT_ENGINE_STAMPS
+#define QT_ENGINE_STAMPS 1
+#endif
+    auto stamp = [&](auto SITE) {
+        if ((GQ_STAMPS || QT_ENGINE_STAMPS) && dbg && blockIdx.x == gridDim.x / 2 && l == 0 && nstamp < 8u) dbg[w * 8u + nstamp++] = __builtin_readcyclecounter();
+        if constexpr (!(GQ_STAMPS || QT_ENGINE_STAMPS) && ((QT_SB >> decltype(SITE)::value) & 1)) __builtin_amdgcn_sched_barrier(0);
     };
-    stamp();
+    stamp(std::integral_constant<int, 0>{});
     u32 j = blockIdx.x;
     if (j >= nitems) return;  // (whole block)
     QtItem cur = item_of(j);
@@ -220,9 +237,9 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     };
 #pragma unroll
     for (u32 p = 0; p < PF; p++) fetch(p, cur, cur.k2lo / CH + w + p * W);
-    stamp();
+    stamp(std::integral_constant<int, 1>{});
     between();
-    stamp();
+    stamp(std::integral_constant<int, 2>{});
     f32x4 accA[2], accB[2];  // even / odd tile blocks: no MFMA waits for the one before it
     const u32 emask = SX ? 0xFFC0FFC0u : 0x7FC07FC0u;
     auto lookup2 = [&](u32 P, u32 &wlo, u32 &whi) {
@@ -402,7 +419,7 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
 #pragma unroll
             for (u32 p = 0; p < PF; p++) fetch(p, nxt, nxt.k2lo / CH + w + p * W);
         }
-        stamp();
+        stamp(std::integral_constant<int, 3>{});
         // D layout: lane (gq = l / 16, n = l % 16) holds logical rows 4 gq + 0..3 of column n (all columns are equal):
         // lanes n < 4 store element n of "rows a", lanes 4 <= n < 8 element n - 4 of "rows a + 8"
         {
@@ -431,7 +448,7 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
             for (u32 i = 0; i < W; i++) t += pr[i * 32u + tid];
             cur.out[tid] = t;
         }
-        stamp();
+        stamp(std::integral_constant<int, 4>{});
         flip ^= 1u;
         if (!has_next) break;
         cur = nxt;

@@ -176,3 +176,62 @@ def tiny_hf_anyprec_checkpoint(path, D=128, I=256, H=4, KV=2, Lr=2, V=96, seed=2
                 sd[f"model.layers.{i}.{name}.lut{b}"] = (torch.randn(n, 2**b, generator=g) * 0.08).sort(dim=1).values.half().contiguous()
     save_file(sd, str(path / "model.safetensors"))
     return hf_cfg, sd, names, (D, I, H, KV, Lr, V)
+
+
+# ------------------------------------------------------------------------------------------------ converter goldens (section 8 f-1)
+CONVERT_DIMS = dict(D=128, I=256, H=2, KV=1, Lr=32, V=256, parent=4, seed_bits=2)  # 32 layers: the reference script's "Llama-2-7b" (:62-69)
+
+
+def convert_input_state_dict(seed=7):
+    """the HF-layout multi-precision Any-Precision checkpoint (keys / dtypes as pack.py:112-123 + HF Llama emit them) the converter
+    goldens were generated from -- regenerated from the seed (numpy PCG64: stable across versions), not stored: a parent of 4 planes,
+    lut2 / lut3 / lut4 per linear, bf16 embeddings and norms (the script casts those to fp16)"""
+    import torch
+    c = CONVERT_DIMS
+    D, I, hd = c["D"], c["I"], c["D"] // c["H"]
+    rng = np.random.default_rng(seed)
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)  # noqa: E731
+    sd = {"model.embed_tokens.weight": bf(rng.normal(0, 0.5, (c["V"], D))), "model.norm.weight": bf(1 + 0.1 * rng.normal(0, 1, D)),
+          "lm_head.weight": torch.from_numpy(rng.normal(0, 0.2, (c["V"], D)).astype(np.float16))}
+    shapes = {"self_attn.q_proj": (D, D), "self_attn.k_proj": (c["KV"] * hd, D), "self_attn.v_proj": (c["KV"] * hd, D), "self_attn.o_proj": (D, D),
+              "mlp.gate_proj": (I, D), "mlp.up_proj": (I, D), "mlp.down_proj": (D, I)}
+    for i in range(c["Lr"]):
+        sd[f"model.layers.{i}.input_layernorm.weight"] = bf(1 + 0.1 * rng.normal(0, 1, D))
+        sd[f"model.layers.{i}.post_attention_layernorm.weight"] = bf(1 + 0.1 * rng.normal(0, 1, D))
+        for name, (n, k) in shapes.items():
+            sd[f"model.layers.{i}.{name}.qweight"] = torch.from_numpy(
+                rng.integers(-2**31, 2**31 - 1, (c["parent"], n, k // 32), dtype=np.int64).astype(np.int32))
+            for b in range(c["seed_bits"], c["parent"] + 1):
+                sd[f"model.layers.{i}.{name}.lut{b}"] = torch.from_numpy(np.sort(rng.normal(0, 0.08, (n, 1 << b)).astype(np.float16), axis=1))
+    return sd
+
+
+def qtip_convert_input_state_dict(seed=8, Lr=2, D=64, I=128, V=64):
+    """an hfized QTIP checkpoint's key set (qtip/model/llama.py QuantizedLinear buffers per projection: trellis, SU, SV, tlut, rcp, tp_rank)"""
+    import torch
+    rng = np.random.default_rng(seed)
+    sd = {"model.embed_tokens.weight": torch.from_numpy(rng.normal(0, 0.5, (V, D)).astype(np.float16)),
+          "model.norm.weight": torch.from_numpy(np.ones(D, np.float16)), "lm_head.weight": torch.from_numpy(rng.normal(0, 0.2, (V, D)).astype(np.float16))}
+    shapes = {"self_attn.q_proj": (D, D), "self_attn.k_proj": (D, D), "self_attn.v_proj": (D, D), "self_attn.o_proj": (D, D),
+              "mlp.gate_proj": (I, D), "mlp.up_proj": (I, D), "mlp.down_proj": (D, I)}
+    for i in range(Lr):
+        sd[f"model.layers.{i}.input_layernorm.weight"] = torch.from_numpy((1 + 0.1 * rng.normal(0, 1, D)).astype(np.float16))
+        sd[f"model.layers.{i}.post_attention_layernorm.weight"] = torch.from_numpy((1 + 0.1 * rng.normal(0, 1, D)).astype(np.float16))
+        for name, (n, k) in shapes.items():
+            p = f"model.layers.{i}.{name}."
+            sd[p + "trellis"] = torch.from_numpy(rng.integers(-2**15, 2**15 - 1, ((n // 16) * (k // 16), 16 * 16 * 2 // 16), dtype=np.int64).astype(np.int16))
+            sd[p + "SU"] = torch.from_numpy(rng.choice([-1.0, 1.0], k).astype(np.float16))
+            sd[p + "SV"] = torch.from_numpy((rng.choice([-1.0, 1.0], n) * 0.02).astype(np.float32))
+            sd[p + "tlut"] = torch.from_numpy(rng.normal(0, 0.5, (512, 2)).astype(np.float16))
+            sd[p + "rcp"] = torch.tensor(0)
+            sd[p + "tp_rank"] = torch.tensor(8)
+    return sd
+
+
+def tensor_digest(t):
+    """(dtype name, shape, sha256 of the raw little-endian bytes) of a torch tensor"""
+    import hashlib
+    import torch
+    t = t.detach().cpu().contiguous()
+    raw = t.view(torch.int16).numpy().tobytes() if t.dtype == torch.bfloat16 else t.numpy().tobytes()
+    return str(t.dtype).replace("torch.", ""), tuple(int(s) for s in t.shape), hashlib.sha256(raw).hexdigest()

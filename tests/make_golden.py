@@ -13,6 +13,8 @@ Sources of truth used:
   * inference/lib/utils/kernel_decompress.py       decode_compressed
   * inference/lib/codebook/bitshift.py             quantlut_sym / bitshift_codebook
   * inference/lib/utils/matmul_had.py              matmul_hadU / matmul_hadUt / get_hadK
+  * inference/sqllm_llama_convert_fuse.py, inference/qtip_convert_no_fuse.py   the checkpoint converters, RUN as the scripts
+    they are (subprocess, on a seeded tiny checkpoint written to a temporary directory)
 """
 import importlib.util
 import os
@@ -112,9 +114,49 @@ def gen_hadamard():
         print("had", n, Kf)
 
 
+def gen_convert():
+    """the reference's own converter scripts run on seeded tiny checkpoints (ap_helpers.convert_input_state_dict:
+    32 layers because sqllm_llama_convert_fuse.py:62-69 accepts only "Llama-2-*" directory names).  Stored: for EVERY tensor of the
+    input and of the script's output its dtype / shape / sha256 (the input is regenerated from its seed by the tests and checked
+    against these digests first), and layers 0 and 31 + the non-layer tensors of the output in full."""
+    import json
+    import subprocess
+    import tempfile
+    import torch
+    from safetensors.torch import save_file
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ap_helpers import convert_input_state_dict, qtip_convert_input_state_dict, tensor_digest
+
+    def as_np(t):
+        return t.view(torch.int16).numpy() if t.dtype == torch.bfloat16 else t.numpy()
+
+    for bitwidth in (2, 3):
+        with tempfile.TemporaryDirectory() as tmp:
+            d = os.path.join(tmp, "Llama-2-7b")
+            os.makedirs(d)
+            sd = convert_input_state_dict()
+            torch.save(sd, os.path.join(d, "pytorch_model.bin"))
+            subprocess.check_call([sys.executable, os.path.join(REF, "inference/sqllm_llama_convert_fuse.py"), "--ckpt_dir", d, "--bitwidth", str(bitwidth)])
+            out = torch.load(os.path.join(d, "converted_pytorch_model.bin"), weights_only=True)
+        full = {k: as_np(v.contiguous()) for k, v in out.items() if not k.startswith("layers.") or k.startswith("layers.0.") or k.startswith("layers.31.")}
+        meta = dict(bitwidth=bitwidth, input={k: tensor_digest(v) for k, v in sd.items()}, output={k: tensor_digest(v) for k, v in out.items()})
+        np.savez_compressed(os.path.join(OUT, f"convert_ap_fuse_b{bitwidth}.npz"), meta=json.dumps(meta), **{"full::" + k: v for k, v in full.items()})
+        print("convert ap", bitwidth, len(sd), "->", len(out), "tensors")
+    with tempfile.TemporaryDirectory() as tmp:
+        sd = qtip_convert_input_state_dict()
+        save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(tmp, "model.safetensors"))
+        subprocess.check_call([sys.executable, os.path.join(REF, "inference/qtip_convert_no_fuse.py"), "--ckpt_dir", tmp])
+        out = torch.load(os.path.join(tmp, "converted_pytorch_model.bin"), weights_only=True)
+    meta = dict(input={k: tensor_digest(v) for k, v in sd.items()}, output={k: tensor_digest(v) for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "convert_qtip_no_fuse.npz"), meta=json.dumps(meta))
+    print("convert qtip", len(sd), "->", len(out), "tensors")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["ap", "qtip", "had"]
+    which = sys.argv[1:] or ["ap", "qtip", "had", "convert"]
+    if "convert" in which:
+        gen_convert()
     if "ap" in which:
         gen_ap()
     if "qtip" in which:

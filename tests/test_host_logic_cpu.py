@@ -1,10 +1,14 @@
 """CPU: host-side logic -- the product's packer against reference goldens, module surfaces, model tree / state-dict
 contract, argument validation that must raise (not crash) without a GPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from conftest import golden_files
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("path", golden_files("ap_b"))
@@ -396,3 +400,80 @@ def test_generate_routes_the_reference_call_and_declines_the_rest(tmp_path):
     assert out.shape == (1, 6)
     with pytest.raises(ValueError):
         m.generate(ids, max_new_tokens=3, do_sample=False, native=True)
+
+
+@pytest.mark.parametrize("bitwidth", [2, 3])
+def test_anyprec_converter_equals_the_reference_script_output(bitwidth):
+    """SURVEY section 8 f-1, pinned: tests/golden/convert_ap_fuse_b{2,3}.npz hold what the reference's OWN script
+    (inference/sqllm_llama_convert_fuse.py, run as a subprocess by tests/make_golden.py::gen_convert) wrote for the seeded 32-layer
+    multi-precision checkpoint of ap_helpers.convert_input_state_dict: `convert_anyprec_fuse` must produce the same key set and, key
+    for key, the same dtype, shape and bytes."""
+    import json
+    import torch
+    from ap_helpers import convert_input_state_dict, tensor_digest
+    from guidedquant_amd.convert import convert_anyprec_fuse
+    g = np.load(os.path.join(GOLDEN, f"convert_ap_fuse_b{bitwidth}.npz"))
+    meta = json.loads(str(g["meta"]))
+    sd = convert_input_state_dict()
+    norm = lambda d: (d[0], tuple(d[1]), d[2])  # noqa: E731
+    assert {k: norm(tensor_digest(v)) for k, v in sd.items()} == {k: norm(d) for k, d in meta["input"].items()}, "the regenerated input is not the golden's"
+    for n_layer in (None, 32):
+        out = convert_anyprec_fuse(dict(sd), bitwidth, n_layer)
+        assert set(out) == set(meta["output"]), (sorted(set(out) ^ set(meta["output"]))[:8])
+        for k, v in out.items():
+            dt, shape, sha = tensor_digest(v)
+            assert [dt, list(shape), sha] == [meta["output"][k][0], list(meta["output"][k][1]), meta["output"][k][2]], k
+    for name in g.files:  # (the tensors stored in full: layers 0 and 31, embeddings, norm, head)
+        if name.startswith("full::"):
+            k, v = name[6:], out[name[6:]]
+            got = v.view(torch.int16).numpy() if v.dtype == torch.bfloat16 else v.numpy()
+            assert got.dtype == g[name].dtype and np.array_equal(got, g[name]), k
+    assert out["layers.0.attention.wqkv.qweight"].shape == (bitwidth, 128 + 64 + 64, 4) and out["layers.31.feed_forward.w1w3.lut"].shape == (512, 1 << bitwidth)
+    assert out["tok_embeddings.weight"].dtype == torch.float16 and "layers.0.attention.q_proj.qweight" not in out
+
+
+def test_qtip_converter_equals_the_reference_script_output():
+    """the same for inference/qtip_convert_no_fuse.py:9-46 (renames only) on an hfized-QTIP key set"""
+    import json
+    from ap_helpers import qtip_convert_input_state_dict, tensor_digest
+    from guidedquant_amd.convert import convert_qtip_no_fuse
+    meta = json.loads(str(np.load(os.path.join(GOLDEN, "convert_qtip_no_fuse.npz"))["meta"]))
+    sd = qtip_convert_input_state_dict()
+    norm = lambda d: (d[0], tuple(d[1]), d[2])  # noqa: E731
+    assert {k: norm(tensor_digest(v)) for k, v in sd.items()} == {k: norm(d) for k, d in meta["input"].items()}
+    out = convert_qtip_no_fuse(sd)
+    assert set(out) == set(meta["output"])
+    for k, v in out.items():
+        dt, shape, sha = tensor_digest(v)
+        assert [dt, list(shape), sha] == [meta["output"][k][0], list(meta["output"][k][1]), meta["output"][k][2]], k
+
+
+def test_converted_checkpoint_route_on_the_host(tmp_path):
+    """generate.py:222-245 of the reference: torch.load(converted_pytorch_model.bin, mmap, weights_only) -> load_state_dict(assign,
+    strict) -> model.to(device, dtype).  `load_model(random_init=False, checkpoint_path=...)` on the converter's output (the file the
+    golden test above pins): strict load, and the model's forward equals a dense Llama forward over the dequantised weights."""
+    import torch
+    from ap_helpers import CONVERT_DIMS, convert_input_state_dict
+    from guidedquant_amd import ap_gemv
+    from guidedquant_amd.convert import convert_anyprec_fuse
+    from guidedquant_amd.generate import load_model
+    from guidedquant_amd.model import transformer_configs
+    c = CONVERT_DIMS
+    out = convert_anyprec_fuse(convert_input_state_dict(), 3)
+    torch.save(out, tmp_path / "converted_pytorch_model.bin")
+    name = "test/convert-golden-32l"
+    transformer_configs[name] = dict(model_name="llama-convert-golden-32l", block_size=64, n_layer=c["Lr"], n_head=c["H"], n_local_heads=c["KV"], dim=c["D"],
+                                     intermediate_size=c["I"], vocab_size=c["V"], rope_base=10000)
+    try:
+        m = load_model(name, "cpu", "ap", 3, random_init=False, checkpoint_path=str(tmp_path))
+    finally:
+        del transformer_configs[name]
+    sd = m.state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in out.items()) and set(sd) == set(out)
+    w = m.layers[5].attention.wqkv
+    W = ap_gemv.anyprec_dequant(w.qweight, w.lut, 3)
+    assert W.shape == (256, 128) and torch.equal(w.qweight, out["layers.5.attention.wqkv.qweight"])
+    m.setup_caches(1, 16)
+    with torch.no_grad():
+        lg = m(torch.tensor([[3, 9, 250]], dtype=torch.int32), torch.arange(3, dtype=torch.int32))
+    assert lg.shape == (1, 3, c["V"]) and torch.isfinite(lg.float()).all()

@@ -23,7 +23,9 @@ EXPORTS = [
     "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows", "gq_anyprec_gemv_fused_ws", "gq_anyprec_gemv_fused_ws_bytes",
     "gq_qtip_linear_out_in", "gq_debug_stream_read", "gq_hop_alloc", "gq_hop_free", "gq_hop_export", "gq_hop_import", "gq_hop_close", "gq_hop_wait_copy",
     "gq_sample_topk_ex", "gq_anyprec_gemv_fused_ho", "gq_ssq_rows", "gq_anyprec_handover_plan", "gq_embed_lookup_ho", "gq_anyprec_gemv_qkv_rope_ho",
+    "gq_anyprec_qkv_rope_attn_supported", "gq_anyprec_gemv_qkv_rope_attn",
 ]
+ATTN_FLAG_STRIDE = 32  # include/gq_hip.h GQ_ATTN_FLAG_STRIDE
 SSQ_SLOTS = 1024  # include/gq_hip.h GQ_SSQ_SLOTS
 _VOID = ("gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer")
 
@@ -131,6 +133,8 @@ def lib():
         L.gq_anyprec_qkv_rope_supported.argtypes = [u32, u32, i32, u32]
         L.gq_anyprec_gemv_qkv_rope.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, vp, vp, vp, vp, u32, u32, u32, u32, vp]
         L.gq_attn_decode_roped.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp]
+        L.gq_anyprec_qkv_rope_attn_supported.argtypes = [u32, u32, i32, u32, u32, u32]
+        L.gq_anyprec_gemv_qkv_rope_attn.argtypes = [vp, vp, vp, vp, u32, u32, i32, vp, f32, vp, vp, vp, vp, vp, u32, u32, u32, u32, vp, f32, vp, vp]
         for name in EXPORTS:
             if name in _VOID:
                 getattr(L, name).restype = None

@@ -312,6 +312,307 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
 }
 
 // ----------------------------------------------------------------------------------------------
+// Round 6 -- "decode to fp16, accumulate on the matrix cores" (fast mode, 3 and 4 bits, one batch row).
+//
+// The plane-MFMA kernels (ap_plane.hip / ap_stream.hip) multiply 2^b - 1 BINARY matrices per b-bit LUT: 3 at 2 bits, 7 at 3, 15
+// at 4 -- 24 / 56 / 120 FP4 x BF8 MFMAs of 32 cycles per 16 rows x 1024 weights, with ~8 VALU instructions per MFMA to build the
+// operands: at 4 bits ~1,040 instructions per block, instruction-issue-bound at 2.3 x the matrix floor (w1w3 24 us, 0.30 of the
+// HBM roofline).  The decode of the exact kernels (ap_core.h: plane bytes transposed across the 4 words of a quad, v_perm_b32
+// look-ups in the row's LUT held as VGPR byte pools) grows far more slowly with b -- 1.75 / 2.2 / 4.2 VALU operations per weight --
+// and what it yields, packed fp16 pairs (w_v0, w_v1), (w_v2, w_v3) of the four words of a quad at one bit position, IS an A
+// fragment of v_mfma_f32_16x16x32_f16: lane (row r = l % 16, quad g = l / 16) holds 8 weights of row r, and the K index of a
+// matrix-core product is only a label -- any 8 weights do, as long as the B fragment of lane (column, g) holds the 8 activations
+// that belong to them.  Those are exactly one 16-byte slot of the lane-linear activation image the exact kernels stage in LDS
+// (ap_core.h::xlds_pos: [(v0, v1) @ j, (v2, v3) @ j, (v0, v1) @ j + 1, (v2, v3) @ j + 1] of (quad, byte c, j / 2)).  So:
+//   * A = two look-ups (4 VGPRs), B = one ds_read_b128 of the staged image (column 0 reads it, columns 1..15 read zeros from
+//     outside the block's LDS allocation -- idle columns fed real data cost 8 % in clocks), one MFMA
+//     of 16 cycles per 16 rows x 32 weights: 32 per 16 x 1024 block instead of 56 / 120, no bf8 pieces, no image build, no
+//     extraction of large activations, no Moebius coefficients;
+//   * products of fp16 values are exact in the fp32 accumulator, sums in fp32, one fp16 rounding: the fast-mode envelope
+//     (tests/ap_helpers.py::_check_fast) -- not the reference's fp16 accumulation order (that is the exact mode);
+//   * prologues (RMSNorm, SiLU * up) are stage_x's, with the reference's rounding points; plain / residual / gate-up pair epilogues.
+// Work: item = (16-row group, unit of 4 quads = 512 weights per row); wave w of a 16-wave block takes items w, w + 16, ..; the
+// K-split partial sums of a row group meet in LDS and are added in unit order (deterministic).
+// ----------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BITS>
+struct DqItem;  // run(P, L, emit): emit(c, jj, w01 @ 2 jj, w23 @ 2 jj, w01 @ 2 jj + 1, w23 @ 2 jj + 1) for c = 3..0, jj = 0..3
+template <>
+struct DqItem<2> {
+    template <typename E>
+    __device__ __forceinline__ static void run(const u32 P[2][4], const LutPools<2> &L, E emit) {
+        u32 H[4], Lo[4];
+        transpose_quad(P[0], H);
+        transpose_quad(P[1], Lo);
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {
+            const u32 Cm = bfi(0xAAAAAAAAu, H[c], Lo[c] >> 1), Dm = bfi(0xAAAAAAAAu, H[c] << 1, Lo[c]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 a01, a23, b01, b23;
+                lookup4<2>(L, (Cm >> (6 - 2 * k)) & 0x03030303u, 0u, a01, a23);
+                lookup4<2>(L, (Dm >> (6 - 2 * k)) & 0x03030303u, 0u, b01, b23);
+                emit(c, k, a01, a23, b01, b23);
+            }
+        }
+    }
+};
+template <>
+struct DqItem<3> {
+    template <typename E>
+    __device__ __forceinline__ static void run(const u32 P[3][4], const LutPools<3> &L, E emit) {
+        u32 T0[4], T1[4], T2[4];
+        transpose_quad(P[0], T0);
+        transpose_quad(P[1], T1);
+        transpose_quad(P[2], T2);
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {
+            u32 nib[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) nib[r] = bfi(0x44444444u, shl(T0[c], 2 - r), bfi(0x22222222u, shl(T1[c], 1 - r), T2[c] >> r));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 w[2][2];
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    const int s = 7 - (2 * k + par);
+                    const u32 S = ((s & 4) ? (nib[s & 3] >> 4) : nib[s & 3]) & 0x07070707u;
+                    lookup4<3>(L, S, 0u, w[par][0], w[par][1]);
+                }
+                emit(c, k, w[0][0], w[0][1], w[1][0], w[1][1]);
+            }
+        }
+    }
+};
+template <>
+struct DqItem<4> {
+    template <typename E>
+    __device__ __forceinline__ static void run(const u32 P[4][4], const LutPools<4> &L, E emit) {
+        u32 T0[4], T1[4], T2[4], T3[4];
+        transpose_quad(P[0], T0);
+        transpose_quad(P[1], T1);
+        transpose_quad(P[2], T2);
+        transpose_quad(P[3], T3);
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {
+            u32 nib[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) nib[r] = bfi(0x44444444u, shl(T1[c], 2 - r), bfi(0x22222222u, shl(T2[c], 1 - r), T3[c] >> r));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 w[2][2];
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    const int s = 7 - (2 * k + par);
+                    const u32 S = ((s & 4) ? (nib[s & 3] >> 4) : nib[s & 3]) & 0x07070707u;
+                    const u32 msel = ((T0[c] >> s) & 0x01010101u) | 0x0C0C0C0Cu;
+                    lookup4<4>(L, S, msel, w[par][0], w[par][1]);
+                }
+                emit(c, k, w[0][0], w[0][1], w[1][0], w[1][1]);
+            }
+        }
+    }
+};
+
+struct DqArgs {
+    ApArgs a;
+    u32 RGB;      // 16-row groups per block
+    u32 NU;       // units (512 weights) per row
+    u32 part_off; // LDS offset of the partial sums
+};
+#ifndef DQ_WAVES_N
+#define DQ_WAVES_N 16
+#endif
+constexpr u32 DQ_WAVES = DQ_WAVES_N;
+// ring depth 1: the next item's plane words are requested while this one is decoded.  Deeper rings measured SLOWER (w1w3 3-bit 15.5 /
+// 17.4 / 19.1 us, 4-bit 22.9 / 25.2 / 27.7 us at depth 1 / 2 / 3, profiles/r06_dq_kernel.txt): the unrolled decode of one item is
+// ~600 instructions (5 KB) already, and every slot of a ring is another copy of it in the instruction cache
+#ifndef DQ_RING
+#define DQ_RING 1
+#endif
+// occupancy the instances are compiled for (waves per SIMD): the decode is a dependent chain (transpose -> selectors -> look-ups ->
+// MFMA), so more resident waves = fewer idle issue slots
+// (measured: ONE 16-wave block per CU is the fastest form -- 8-wave blocks at 3 / 4 per CU, <= 64 / 80 VGPRs: w1w3 3-bit 17.6 vs 16.3 us,
+// 4-bit 26.9 vs 22.9, and their RMSNorm instances spill; profiles/r06_dq_kernel.txt)
+#ifndef DQ_WPE3
+#define DQ_WPE3 4
+#endif
+#ifndef DQ_WPE4
+#define DQ_WPE4 4
+#endif
+template <int BITS>
+constexpr int dq_wpe() { return BITS <= 3 ? DQ_WPE3 : DQ_WPE4; }
+
+template <int BITS, int PRO>
+__global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per_eu(dq_wpe<BITS>()))) ap_gemv_dq_kernel(DqArgs da) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ApArgs &a = da.a;
+    RowGeom G;
+    G.init(a.K);
+    uint16_t *xlds = reinterpret_cast<uint16_t *>(smem);
+    float *part = reinterpret_cast<float *>(smem + da.part_off);
+    float *red = part;  // (RMSNorm reduction scratch: before the partial sums exist)
+    const u32 tid = threadIdx.x, l = tid & 63u, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 r = l & 15u, g = l >> 4;
+    const u32 rg0 = blockIdx.x * da.RGB, NU = da.NU;
+    const u32 RGt = (a.N + 15u) >> 4;
+    const u32 rgb = min(da.RGB, RGt - rg0);  // row groups of this block
+    const u32 nitems = rgb * NU;
+    constexpr int NRAW = (1 << BITS) / 2;
+    constexpr u32 OOB = 0x80000000u;
+    const u32 plane_bytes = a.N * G.wpr * 4u;
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw, 0, (int)(plane_bytes * (u32)BITS), 0x00020000);
+    __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)a.lut, 0, (int)(a.N * (u32)NRAW * 4u), 0x00020000);
+    constexpr int D = DQ_RING;
+    u32x4 P[D][BITS];
+    u32 lraw[D][NRAW];
+    auto issue = [&](int d, u32 it) {
+        const u32 rgl = it / NU, u = it - rgl * NU;
+        const u32 row = (rg0 + rgl) * 16u + r;
+        const bool ok = it < nitems && row < a.N;
+        const u32 off = ok ? (row * G.wpr + 4u * (4u * u + g)) * 4u : OOB;
+#pragma unroll
+        for (int p = 0; p < BITS; p++) P[d][p] = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? off + (u32)p * plane_bytes : OOB, 0, 2 /* nt */);
+        const u32 loff = ok ? row * (u32)NRAW * 4u : OOB;
+        if constexpr (NRAW == 2) {
+            auto v = __builtin_amdgcn_raw_buffer_load_b64(rl, loff, 0, 0);
+            lraw[d][0] = v[0];
+            lraw[d][1] = v[1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NRAW; i += 4) {
+                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? loff + (u32)i * 4u : OOB, 0, 0);
+                lraw[d][i] = v.x;
+                lraw[d][i + 1] = v.y;
+                lraw[d][i + 2] = v.z;
+                lraw[d][i + 3] = v.w;
+            }
+        }
+    };
+    // the waves that stage x (the lower half) request their first items behind the activations, the others at once (the CU's
+    // memory pipe serves requests in order)
+    const bool stager = DQ_WAVES < 2u || w < DQ_WAVES / 2u;
+    if (!stager) {
+#pragma unroll
+        for (int d = 0; d < D; d++) issue(d, w + (u32)d * DQ_WAVES);
+    }
+    stage_x<PRO>(G, a.x, a.normw, a.eps, xlds, red, stager, (DQ_WAVES < 2u ? 1u : DQ_WAVES / 2u) * 64u);
+    if (stager) {
+#pragma unroll
+        for (int d = 0; d < D; d++) issue(d, w + (u32)d * DQ_WAVES);
+    }
+    __syncthreads();
+    // B fragments: column 0 reads the image, the other columns read zeros from beyond the block's LDS allocation (192 KiB up)
+    const u32 Q = G.Q;
+    for (u32 it0 = w; it0 < nitems; it0 += (u32)D * DQ_WAVES) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const u32 it = it0 + (u32)d * DQ_WAVES;
+            u32 Pw[BITS][4];
+#pragma unroll
+            for (int p = 0; p < BITS; p++) {
+                Pw[p][0] = P[d][p].x;
+                Pw[p][1] = P[d][p].y;
+                Pw[p][2] = P[d][p].z;
+                Pw[p][3] = P[d][p].w;
+            }
+            LutPools<BITS> L;
+            L.build(lraw[d]);
+            issue(d, it + (u32)D * DQ_WAVES);
+            if (it >= nitems) continue;  // (wave-uniform)
+            const u32 rgl = it / NU, u = it - rgl * NU;
+            const u32 q = 4u * u + g;
+            const unsigned char *bb = r == 0u ? reinterpret_cast<const unsigned char *>(xlds) + (size_t)q * 16u
+                                              : reinterpret_cast<const unsigned char *>(smem) + 0x30000u;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            DqItem<BITS>::run(Pw, L, [&](int c, int jj, u32 a01, u32 a23, u32 b01, u32 b23) {
+                const u32x4 av = {a01, a23, b01, b23};
+                const uint4 bv = *reinterpret_cast<const uint4 *>(bb + (size_t)((u32)(c * 4 + jj) * Q) * 16u);
+                const u32x4 bvv = {bv.x, bv.y, bv.z, bv.w};
+                if (jj & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc0, 0, 0, 0);
+            });
+            // D[row 4 g + e][column r]: column 0 holds the sums
+            if (r == 0u) *reinterpret_cast<f32x4 *>(part + (size_t)it * 16u + 4u * g) = acc0 + acc1;
+        }
+    }
+    __syncthreads();
+    // ordered K-split sum + epilogue: one thread per row of the block
+    const bool pairs = (a.epilogue & GQ_EPI_SILU_PAIRS) != 0u;
+    for (u32 rl = tid; rl < rgb * 16u; rl += 64u * DQ_WAVES) {
+        const u32 row = rg0 * 16u + rl;
+        const float *pp = part + (size_t)(rl >> 4) * NU * 16u + (rl & 15u);
+        float y = 0.f;
+        for (u32 u = 0; u < NU; u++) y += pp[(size_t)u * 16u];
+        _Float16 yh = (_Float16)y;
+        if (pairs) {
+            // rows (2 i, 2 i + 1) = (gate_i, up_i): F.silu(gate) * up on fp16 values (inference/model.py:266), written to out[i]
+            const uint16_t yo = (uint16_t)__shfl_xor((int)__builtin_bit_cast(uint16_t, yh), 1);
+            if (!(rl & 1u) && row + 1u < a.N) {
+                const float gv = (float)yh;
+                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, yo);
+                gq_store_wt(a.out + (row >> 1), __builtin_bit_cast(uint16_t, o));
+            }
+        } else if (row < a.N) {
+            if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[row]) + yh;
+            gq_store_wt(a.out + row, __builtin_bit_cast(uint16_t, yh));
+        }
+    }
+}
+
+struct DqCfg {
+    u32 grid, RGB, NU, part_off;
+    size_t smem;
+};
+bool pick_dq_cfg(u32 N, u32 K, int bits, DqCfg &c) {
+    if (bits < 2 || bits > 4 || K % 1024u || K > 32768u || N < 16u) return false;
+    const u32 RGt = (N + 15u) / 16u, cus = (u32)gq_cu_count();
+    c.NU = K / 512u;
+    // blocks per CU the instance's occupancy allows (waves per SIMD x 4 SIMDs / waves per block)
+    u32 bpc = (u32)gq_env_int("GQ_DQ_BPC", 0);
+    if (!bpc) bpc = (u32)(bits <= 3 ? DQ_WPE3 : DQ_WPE4) * 4u / DQ_WAVES;
+    if (bpc < 1u) bpc = 1u;
+    c.RGB = (RGt + cus * bpc - 1u) / (cus * bpc);
+    c.grid = (RGt + c.RGB - 1u) / c.RGB;
+    c.part_off = (K * 2u + 255u) / 256u * 256u;
+    c.smem = (size_t)c.part_off + (size_t)c.RGB * c.NU * 64u + 64u;
+    return c.smem <= 150u * 1024u;
+}
+template <int BITS, int PRO>
+int launch_dq_inst(const DqArgs &da, const DqCfg &c, hipStream_t s) {
+    static GqPerDeviceOnce once;
+    auto kern = ap_gemv_dq_kernel<BITS, PRO>;
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
+    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(64u * DQ_WAVES), c.smem, s, da);
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
+}
+template <int BITS>
+int launch_dq(const DqArgs &da, const DqCfg &c, int pro, hipStream_t s) {
+    switch (pro) {
+        case PRO_RMSNORM: return launch_dq_inst<BITS, PRO_RMSNORM>(da, c, s);
+        case PRO_SILUMUL: return launch_dq_inst<BITS, PRO_SILUMUL>(da, c, s);
+        default: return launch_dq_inst<BITS, PRO_NONE>(da, c, s);
+    }
+}
+// GQ_ENOTSUP when the shape is not served (the caller goes on to the plane / exact kernels)
+int dq_gemv_try(const ApArgs &a, u32 M, int bits, int pro, hipStream_t s) {
+    DqCfg c;
+    if (M != 1u || !pick_dq_cfg(a.N, a.K, bits, c)) return GQ_ENOTSUP;
+    if ((uint64_t)bits * a.N * (a.K / 8u) >= 0x7FFFFFFFull) return GQ_ENOTSUP;
+    if ((((uintptr_t)a.qw | (uintptr_t)a.x | (uintptr_t)a.normw | (uintptr_t)a.lut) & 15u) != 0) return GQ_ENOTSUP;
+    if ((a.epilogue & GQ_EPI_SILU_PAIRS) && (a.N & 1u)) return GQ_ENOTSUP;
+    DqArgs da{a, c.RGB, c.NU, c.part_off};
+    switch (bits) {
+        case 2: return launch_dq<2>(da, c, pro, s);
+        case 3: return launch_dq<3>(da, c, pro, s);
+        default: return launch_dq<4>(da, c, pro, s);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Generic path: any 2 <= BITS <= 8, any K % 32 == 0.  32 lanes per row exactly like the reference warp
 // (lane = virtual lane), LUT in LDS, 4-byte plane loads.  Slow; exists for API completeness (bits 5..8,
 // odd K) and as an on-device cross-check of the fast path.
@@ -431,6 +732,9 @@ __global__ void __launch_bounds__(256) ap_dequant_kernel(const u32 *qw, const ui
 // ----------------------------------------------------------------------------------------------
 // Launchers
 // ----------------------------------------------------------------------------------------------
+#ifndef GQ_DQ_DEFAULT
+#define GQ_DQ_DEFAULT 6  // (bit mask over the bit widths 2, 3, 4 the decode-to-fp16 kernel may take: 3 and 4)
+#endif
 struct QuadCfg {
     u32 T, RS, SPB, D, grid;
     size_t smem;
@@ -599,6 +903,21 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
     const int def_min = local ? 16 : ((bits == 2 || pro == PRO_RMSNORM) ? 20 : 32);
     const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : def_min) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
+    // round 6: decode-to-fp16 on the matrix cores (ap_gemv_dq_kernel) where it measured faster than the plane kernels
+    // (profiles/r06_dq_kernel.txt, 8B shapes, decode-graph launch forms): at 4 bits the matrices of >= 20 M weights -- wqkv 9.5 vs 10.3 us,
+    // w1w3 23.2 vs 24.4, w2 14.2 vs 15.0 (wo, 16 M: 7.7 vs 6.7, stays) --, at 3 bits the RMSNorm launches below 32 M weights (wqkv 6.9
+    // vs 7.2; w1w3 16.3 vs 14.9 and w2 10.1 vs 9.4 stay), never at 2 bits (w1w3 13.5 vs 8.5).  GQ_DQ: bit mask of the widths it may take
+    // (bit b - 2; 0 = never), GQ_DQ_MIN_MWEIGHTS >= 0: every matrix of at least that many million weights at those widths.
+    {
+        const int dq_mask = gq_env_int("GQ_DQ", GQ_DQ_DEFAULT), dq_min = gq_env_int("GQ_DQ_MIN_MWEIGHTS", -1);
+        const uint64_t nk = (uint64_t)a.N * a.K;
+        const bool dq_shape = dq_min >= 0 ? nk >= (uint64_t)dq_min * 1000000ull
+                                          : (bits == 4 ? nk >= 20000000ull : (bits == 3 && pro == PRO_RMSNORM && nk >= 20000000ull && nk < 32000000ull));
+        if (!force_generic && !exact_mode() && bits <= 4 && ((dq_mask >> (bits - 2)) & 1) && dq_shape && !(ho && ho->dry)) {
+            const int rc = dq_gemv_try(a, M, bits, pro, s);
+            if (rc != GQ_ENOTSUP) return rc;
+        }
+    }
     if (!force_generic && !exact_mode() && bits <= max_bits && (uint64_t)a.N * a.K >= min_w) {
         int rc = gq_plane_gemv_try(a.x, a.out, a.qw, a.lut, M, a.N, a.K, bits, a.normw, a.eps, a.resid, pro, (a.epilogue & GQ_EPI_SILU_PAIRS) != 0, s, a.ws, a.ws_bytes, ho);
         if (rc != GQ_ENOTSUP) return rc;

@@ -327,7 +327,7 @@ constexpr int st_waves() { return BITS == 2 ? ST_W2 : ST_W34; }
 // profiles/r05_stamps_compiled_out.txt); 51 -> 33 conditional branches in front of the first MFMA, wqkv 5.77 -> 5.61 us
 enum { EPI_ANY = -1, EPI_ROPE = 1, EPI_PAIRS = 2 };
 template <int BITS, int PRO, int NPU, bool PSUM, int EPI = EPI_ANY>
-__global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(StreamArgs a) {
+__device__ __forceinline__ void ap_stream_body(const StreamArgs &a) {
     constexpr int WV = st_waves<BITS>(), NH = ST_NH;
     static_assert(EPI != EPI_ROPE || !PSUM, "the RoPE epilogue rotates raw-parked pairs");
     const bool f_rope = EPI == EPI_ANY ? a.rope != 0u : EPI == EPI_ROPE;
@@ -1003,6 +1003,273 @@ __global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(Stream
         else a.dbg[128u + w * 16u + (l - 8u)] = v;
     }
 }
+template <int BITS, int PRO, int NPU, bool PSUM, int EPI = EPI_ANY>
+__global__ void __launch_bounds__(64 * st_waves<BITS>()) ap_stream_kernel(StreamArgs a) {
+    ap_stream_body<BITS, PRO, NPU, PSUM, EPI>(a);
+}
+
+// ================================================================================================================================
+// Round 6: the attention heads INSIDE the wqkv launch (gq_anyprec_gemv_qkv_rope_attn).
+//
+// The decode step's wqkv GEMV occupies 192 of the 256 CUs (8B: 384 row groups, 2 per block) and ends with the rotated q in memory
+// and k / v of the current token in the caches; the attention launch behind it (32 blocks, one per query head) then pays a
+// dependent-launch gap (~1.6 us), the memory round trip of q / position / the cached rows (~1.1 us), and only then multiplies
+// (4.6 us in the graph for <= 100 positions).  Here the head blocks are blocks [G, G + n_head) of the SAME launch, on CUs the GEMV
+// leaves idle: they start with the GEMV, fetch the position and every cached row BELOW it while the GEMV runs (those rows were
+// written by earlier launches: ordinary loads), and wait on a device flag for what this launch produces --
+//   producers  every GEMV block, behind its epilogue's write-through stores (gq_store_wt: global_store .. sc1 = agent scope) and an
+//              s_waitcnt vmcnt(0) + block barrier, adds 1 per row group to the flag word of every query head that reads the group
+//              (a q head: its own; a k / v head: the n_head / n_kv_head heads of its group): global_atomic_add .. sc1;
+//   consumers  each wave of a head block polls its head's flag with agent-scope loads until it reads 3 * head_dim / 16 (the row
+//              groups of its q, k and v heads), then reads q and row *pos of the caches with AGENT-SCOPE loads (sc1: the block's own
+//              L2 may hold older copies of those lines -- profiles/r06_flag_handoff.txt: plain loads do see them, sc1 loads never
+//              did) and runs the arithmetic of attn_roped_kernel<HD, 1> (decode.hip) operation for operation: same position ->
+//              stream assignment, same online softmax per stream, same merge order -- bit-identical outputs.
+// One flag LINE per head (GQ_ATTN_FLAG_STRIDE words apart: agent-scope atomics on one line serialise at the memory side, 5.4 us
+// instead of 0.7 us until the flag is seen); the head block re-arms its flag (stores 0) before it ends -- the next launch's
+// producers start behind this kernel.  The poll is BOUNDED: on expiry the head's output is poisoned (NaN logits), nothing hangs.
+// Producers never wait for anything and are dispatched before the head blocks (lower block indices), so a head block never holds
+// a CU that a producer of its own launch still needs.  Measured hand-over (tools/ubench/flag_handoff.hip): data in hand 1.1 us
+// (median) behind the last producer's stores.
+struct AttnFuse {
+    const uint16_t *q;       // the GEMV's q_out (rotated queries)
+    uint16_t *out;           // attention output fp16 [H * HD]
+    u32 *flags;              // [H][GQ_ATTN_FLAG_STRIDE]
+    float scale;
+    u32 gemv_blocks;         // blocks [0, gemv_blocks) are the GEMV's
+    u32 spin_limit;
+    unsigned long long *dbg; // GQ_STAMPS builds: s_memrealtime stamps, 8 per block (tools/fuse_timing.py)
+};
+#define FUSE_STAMP(i)                                                                                                   \
+    do {                                                                                                                \
+        if (GQ_STAMPS && f.dbg && threadIdx.x == 0) f.dbg[(size_t)blockIdx.x * 8u + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+constexpr int FUSE_ATTN_WAVES = GQ_ATTN_WAVES;
+
+__device__ __forceinline__ u32 ld_flag_sc1(const u32 *p) {
+    u32 v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// agent-scope 16-byte loads, request and wait in ONE asm statement (an output the compiler sees before the data has landed may be copied)
+__device__ __forceinline__ void ld16_sc1(u32x4 &d, const void *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld16x2_sc1(u32x4 &d0, u32x4 &d1, const void *p0, const void *p1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1)
+                 : "v"(p0), "v"(p1)
+                 : "memory");
+}
+
+// the GEMV block's signal: every row group of the block to the heads that read it
+__device__ __forceinline__ void fuse_signal(const StreamArgs &a, const AttnFuse &f) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores are acknowledged
+    __syncthreads();                                  // ... and every other wave's
+    if (threadIdx.x == 0) {
+        const u32 rg0 = blockIdx.x * a.RGB, gq = a.H / a.Hkv, RGt = a.N >> 4;
+        for (u32 e = 0; e < a.RGB; e++) {
+            const u32 rg = rg0 + e;
+            if (rg >= RGt) break;
+            const u32 head = rg >> (a.lhd - 4u);
+            if (head < a.H) {
+                asm volatile("global_atomic_add %0, %1, off sc1" ::"v"(f.flags + (size_t)head * GQ_ATTN_FLAG_STRIDE), "v"(1u) : "memory");
+            } else {
+                const u32 g = head < a.H + a.Hkv ? head - a.H : head - a.H - a.Hkv;
+                for (u32 i = 0; i < gq; i++)
+                    asm volatile("global_atomic_add %0, %1, off sc1" ::"v"(f.flags + (size_t)(g * gq + i) * GQ_ATTN_FLAG_STRIDE), "v"(1u) : "memory");
+            }
+        }
+    }
+}
+
+// one query head: attn_roped_kernel<HD, 1> (decode.hip) with n_split = 1, its loads re-ordered around the flag
+template <int HD>
+__device__ __forceinline__ void fuse_attn_head(const StreamArgs &a, const AttnFuse &f, u32 h) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr u32 NW = FUSE_ATTN_WAVES;
+    constexpr int LPP = HD / 8, PPW = 64 / LPP, U = 4;
+    constexpr u32 NS = NW * PPW;
+    const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
+    if (w >= NW) return;  // (the launch has the GEMV's 16 waves per block; a head uses 8 -- ended waves leave the block's barriers)
+    float *sc = reinterpret_cast<float *>(smem);  // [2 * NS] running max / sum of the position streams
+    float *red2 = sc + 2u * NS;                   // [NS][HD] partial outputs
+    const u32 H = a.H, Hkv = a.Hkv, max_seq = a.max_seq;
+    const u32 g = h / (H / Hkv);
+    const u32 sub = l / LPP, ld = l % LPP;
+    const uint16_t *kcg = a.kc + (size_t)g * max_seq * HD, *vcg = a.vc + (size_t)g * max_seq * HD;
+    FUSE_STAMP(0);
+    const u32 pos = (u32)a.pos[0];  // (written by an earlier launch)
+    const bool past = pos >= max_seq;  // decoding past the cache: the head's output is poisoned (NaN logits), like attn_roped_kernel
+    const u32 p1 = past ? 0u : pos + 1u;
+    // cached rows below the position: on their way while the GEMV runs (ordinary loads -- earlier launches wrote them)
+    uint4 kv[U], vv[U];
+    auto request = [&](uint4 (&kd)[U], uint4 (&vd)[U], u32 tb, bool flag_seen) {
+        bool own = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 t = tb + (u32)u * PPW + sub;
+            const bool in = t < pos && !past;
+            kd[u] = in ? *reinterpret_cast<const uint4 *>(kcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+            vd[u] = in ? *reinterpret_cast<const uint4 *>(vcg + (size_t)t * HD + ld * 8) : make_uint4(0, 0, 0, 0);
+            own = own || (t == pos && !past);
+        }
+        if (flag_seen && own) {  // row *pos was written by THIS launch: agent-scope loads
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u32 t = tb + (u32)u * PPW + sub;
+                if (t == pos) {
+                    u32x4 k4, v4;
+                    ld16x2_sc1(k4, v4, kcg + (size_t)t * HD + ld * 8, vcg + (size_t)t * HD + ld * 8);
+                    kd[u] = make_uint4(k4.x, k4.y, k4.z, k4.w);
+                    vd[u] = make_uint4(v4.x, v4.y, v4.z, v4.w);
+                }
+            }
+        }
+    };
+    u32 t0 = w * PPW * U;
+    if (t0 < p1) request(kv, vv, t0, false);
+    FUSE_STAMP(1);
+    // ---- the flag: 3 * HD / 16 row groups (q, k, v heads) of this launch
+    const u32 *flag = f.flags + (size_t)h * GQ_ATTN_FLAG_STRIDE;
+    const u32 want = 3u * (u32)(HD / 16);
+    bool ok = false;
+    for (u32 i = 0; i < f.spin_limit; i++) {
+        if (__builtin_amdgcn_readfirstlane(ld_flag_sc1(flag)) >= want) {
+            ok = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (past || !ok) {
+        __syncthreads();  // (every wave is through its poll: the flag can be re-armed)
+        if (tid < (u32)HD) f.out[(size_t)h * HD + tid] = 0x7e00u;
+        if (tid == 0 && ok) gq_store_wt(const_cast<u32 *>(flag), 0u);
+        return;
+    }
+    FUSE_STAMP(2);
+    // ---- q and row *pos (agent scope), then attn_roped_kernel's arithmetic
+    u32x4 q4;
+    ld16_sc1(q4, f.q + (size_t)h * HD + ld * 8);
+    if (t0 < p1) {
+        bool own = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) own = own || (t0 + (u32)u * PPW + sub == pos);
+        if (own) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u32 t = t0 + (u32)u * PPW + sub;
+                if (t == pos) {
+                    u32x4 k4, v4;
+                    ld16x2_sc1(k4, v4, kcg + (size_t)t * HD + ld * 8, vcg + (size_t)t * HD + ld * 8);
+                    kv[u] = make_uint4(k4.x, k4.y, k4.z, k4.w);
+                    vv[u] = make_uint4(v4.x, v4.y, v4.z, v4.w);
+                }
+            }
+        }
+    }
+    FUSE_STAMP(3);
+    float qreg[8];
+    {
+        const u32 qw[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) qreg[2 * e] = h2f((uint16_t)(qw[e] & 0xFFFF)), qreg[2 * e + 1] = h2f((uint16_t)(qw[e] >> 16));
+    }
+    const float scale = f.scale;
+    float m_run = -3.0e38f, s_run = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    for (; t0 < p1; t0 += NW * PPW * U) {
+        float pu[U], vfu[U][8];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 t = t0 + (u32)u * PPW + sub;
+            const bool valid = t < p1;
+            const u32 kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w}, vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+            float kf[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                kf[2 * e] = h2f((uint16_t)(kw[e] & 0xFFFF));
+                kf[2 * e + 1] = h2f((uint16_t)(kw[e] >> 16));
+                vfu[u][2 * e] = valid ? h2f((uint16_t)(vw[e] & 0xFFFF)) : 0.f;
+                vfu[u][2 * e + 1] = valid ? h2f((uint16_t)(vw[e] >> 16)) : 0.f;
+            }
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) p += qreg[e] * kf[e];
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
+            p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
+            if (LPP == 16) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x140, 0xF, 0xF, false));
+            pu[u] = valid ? p * scale : -3.0e38f;
+        }
+        float m_new = m_run;
+#pragma unroll
+        for (int u = 0; u < U; u++) m_new = fmaxf(m_new, pu[u]);
+        const float resc = __expf(m_run - m_new);
+        s_run *= resc;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] *= resc;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float wgt = pu[u] > -2.0e38f ? __expf(pu[u] - m_new) : 0.f;
+            s_run += wgt;
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += wgt * vfu[u][e];
+        }
+        m_run = m_new;
+        if (t0 + NW * PPW * U < p1) request(kv, vv, t0 + NW * PPW * U, true);
+    }
+    FUSE_STAMP(4);
+    const u32 stream = w * PPW + sub;
+#pragma unroll
+    for (int e = 0; e < 8; e++) red2[(size_t)stream * HD + ld * 8 + e] = acc[e];
+    if (ld == 0) {
+        sc[stream] = m_run;
+        sc[NS + stream] = s_run;
+    }
+    __syncthreads();
+    FUSE_STAMP(5);
+    if (tid == 0) gq_store_wt(const_cast<u32 *>(flag), 0u);  // (every wave has seen the flag: re-armed for the next launch)
+    float *fl = red2 + (size_t)NS * HD;  // [NS] factors, [1] maximum
+    const u32 nw_act = min(NW, (p1 + (u32)(PPW * U) - 1u) / (u32)(PPW * U));
+    const u32 ng = (nw_act * (u32)PPW + 7u) >> 3;
+    if (tid < NS) {
+        float M = -3.0e38f;
+        for (u32 g8 = 0; g8 < ng; g8++)
+#pragma unroll
+            for (u32 k = 0; k < 8u; k++) M = fmaxf(M, sc[8u * g8 + k]);
+        fl[tid] = __expf(sc[tid] - M);
+        if (tid == 0u) fl[NS] = M;
+    }
+    __syncthreads();
+    if (tid < (u32)HD) {
+        float o = 0.f, sum = 0.f;
+        for (u32 g8 = 0; g8 < ng; g8++)
+#pragma unroll
+            for (u32 k = 0; k < 8u; k++) {
+                const u32 i = 8u * g8 + k;
+                const float fi = fl[i];
+                sum += sc[NS + i] * fi;
+                o += red2[i * HD + tid] * fi;
+            }
+        f.out[(size_t)h * HD + tid] = __builtin_bit_cast(uint16_t, (_Float16)(o / sum));
+    }
+    FUSE_STAMP(6);
+}
+
+template <int HD>
+__global__ void __launch_bounds__(64 * ST_W2) ap_qkv_attn_kernel(StreamArgs a, AttnFuse f) {
+    if (blockIdx.x < f.gemv_blocks) {
+        FUSE_STAMP(0);
+        ap_stream_body<2, PRO_RMSNORM, 1, false, EPI_ROPE>(a);
+        FUSE_STAMP(1);
+        fuse_signal(a, f);
+        FUSE_STAMP(2);
+    } else {
+        fuse_attn_head<HD>(a, f, blockIdx.x - f.gemv_blocks);
+    }
+}
 
 struct StreamCfg {
     u32 grid, gy, RGB, NPU, W, img_off;
@@ -1087,7 +1354,7 @@ struct KSplit {
 };
 int stream_launch(const void *x, void *out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits, const void *normw,
                   float eps, const void *resid, int pro, int pairs, const StreamArgs *rope, hipStream_t stream, const KSplit *ksp = nullptr,
-                  GqHandover *ho = nullptr) {
+                  GqHandover *ho = nullptr, AttnFuse *fuse = nullptr, bool fuse_dry = false) {
     if (bits < 2 || bits > gq_env_int("GQ_ST_MAXBITS", 4)) return GQ_ENOTSUP;
     const uint64_t qbytes = (uint64_t)bits * N * (K / 8u);
     if (qbytes >= 0x7FFFFFFFull) return GQ_ENOTSUP;
@@ -1138,6 +1405,30 @@ int stream_launch(const void *x, void *out, const uint32_t *qweight, const void 
 #ifndef ST_MAXBITS
 #define ST_MAXBITS 4  // bit widths compiled in
 #endif
+    if (fuse) {
+        // the attention heads as extra blocks of this launch (ap_qkv_attn_kernel): the EPI_ROPE instance's configuration, one CU per block
+        if (bits != 2 || pro != PRO_RMSNORM || !rope || c.psum || c.NPU != 1u || c.W != (u32)ST_W2 || c.gy != 1u || a.ssq_in || a.part_out || a.resid ||
+            a.pairs || c.grid + a.H > (u32)gq_cu_count() || (u32)FUSE_ATTN_WAVES > c.W)
+            return GQ_ENOTSUP;
+        if (fuse_dry) return GQ_OK;
+        const u32 hd = 1u << a.lhd, ns = (u32)FUSE_ATTN_WAVES * 64u / (hd / 8u);
+        const size_t asmem = ((size_t)2u * ns + (size_t)ns * hd + ns + 1u) * 4u;
+        const size_t smem = c.smem > asmem ? c.smem : asmem;
+        fuse->gemv_blocks = c.grid;
+        fuse->dbg = GQ_STAMPS ? gq_debug_timing_buffer() : nullptr;
+        a.dbg = nullptr;
+        if (hd == 128u) {
+            static GqPerDeviceOnce once;
+            GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(ap_qkv_attn_kernel<128>), (int)(160u * 1024u)));
+            hipLaunchKernelGGL(ap_qkv_attn_kernel<128>, dim3(c.grid + a.H), dim3(64u * c.W), smem, stream, a, *fuse);
+        } else {
+            static GqPerDeviceOnce once;
+            GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(ap_qkv_attn_kernel<64>), (int)(160u * 1024u)));
+            hipLaunchKernelGGL(ap_qkv_attn_kernel<64>, dim3(c.grid + a.H), dim3(64u * c.W), smem, stream, a, *fuse);
+        }
+        GQ_HIP_CHECK(hipGetLastError());
+        return GQ_OK;
+    }
     if (bits == 2) return launch_pro<2>(a, c, pro, stream);
 #if ST_MAXBITS >= 3
     if (bits == 3) return launch_pro<3>(a, c, pro, stream);
@@ -1263,4 +1554,54 @@ extern "C" int gq_anyprec_gemv_qkv_rope_ho(const void *x, void *q_out, const uin
     ho.ssq_in = ssq_in;
     const int rc = stream_launch(x, q_out, qweight, lut, N, K, bits, norm_weight, eps, nullptr, PRO_RMSNORM, 0, &r, (hipStream_t)stream, nullptr, &ho);
     return rc == GQ_ENOTSUP ? gq_fail(GQ_ENOTSUP, "gq_anyprec_gemv_qkv_rope: shape / bit width not served.") : rc;
+}
+
+// ---- round 6: the same launch with the attention heads as extra blocks (see ap_qkv_attn_kernel)
+namespace {
+int qkv_rope_attn_launch(const void *x, void *q_out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits, const void *norm_weight,
+                         float eps, const int *pos, const void *cos_table, const void *sin_table, void *k_cache, void *v_cache, uint32_t n_head,
+                         uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, void *attn_out, float scale, uint32_t *flags, void *stream, bool dry) {
+    StreamArgs r{};
+    r.pos = pos;
+    r.cos_t = (const uint16_t *)cos_table;
+    r.sin_t = (const uint16_t *)sin_table;
+    r.kc = (uint16_t *)k_cache;
+    r.vc = (uint16_t *)v_cache;
+    r.rope = 1u;
+    r.H = n_head;
+    r.Hkv = n_kv_head;
+    r.lhd = head_dim == 128u ? 7u : 6u;
+    r.max_seq = max_seq;
+    AttnFuse f{};
+    f.q = (const uint16_t *)q_out;
+    f.out = (uint16_t *)attn_out;
+    f.flags = flags;
+    f.scale = scale;
+    f.spin_limit = (u32)gq_env_int("GQ_QKV_ATTN_SPINS", 1 << 21);
+    return stream_launch(x, q_out, qweight, lut, N, K, bits, norm_weight, eps, nullptr, PRO_RMSNORM, 0, &r, (hipStream_t)stream, nullptr, nullptr, &f, dry);
+}
+}  // namespace
+extern "C" int gq_anyprec_qkv_rope_attn_supported(uint32_t N, uint32_t K, int bits, uint32_t head_dim, uint32_t n_head, uint32_t n_kv_head) {
+    // OFF by default (GQ_QKV_ATTN=1 turns it on): correct and bit-identical, and no faster -- the hand-over inside the launch (signal 0.6 us:
+    // the producers' write-through stores acknowledged + block barrier + atomics; flag seen 0.4-1.0 us later; q / row *pos in hand 0.3-0.6 us
+    // after that) costs what the kernel boundary it removes costs: 8B decode 904-905 vs 909.5 tokens/s (profiles/r06_attention_in_wqkv_launch.txt)
+    if (!gq_env_int("GQ_QKV_ATTN", 0) || n_kv_head == 0u || n_head % n_kv_head || N != (n_head + 2u * n_kv_head) * head_dim) return 0;
+    if (!gq_anyprec_qkv_rope_supported(N, K, bits, head_dim)) return 0;
+    return qkv_rope_attn_launch(nullptr, nullptr, nullptr, nullptr, N, K, bits, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, n_head, n_kv_head,
+                                head_dim, 1u, nullptr, 0.f, nullptr, nullptr, true) == GQ_OK
+               ? 1 : 0;
+}
+extern "C" int gq_anyprec_gemv_qkv_rope_attn(const void *x, void *q_out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                                             const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
+                                             void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                                             void *attn_out, float scale, uint32_t *flags, void *stream) {
+    if (!x || !q_out || !qweight || !lut || !norm_weight || !pos || !cos_table || !sin_table || !k_cache || !v_cache || !attn_out || !flags)
+        return gq_fail(GQ_EINVAL, "null pointer argument.");
+    if (((uintptr_t)q_out | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15u) return gq_fail(GQ_EINVAL, "buffers must be 16-byte aligned.");
+    if (((uintptr_t)flags & 127u)) return gq_fail(GQ_EINVAL, "gq_anyprec_gemv_qkv_rope_attn: the flag words must be 128-byte aligned.");
+    if (!gq_anyprec_qkv_rope_attn_supported(N, K, bits, head_dim, n_head, n_kv_head))
+        return gq_fail(GQ_ENOTSUP, "gq_anyprec_gemv_qkv_rope_attn: shape / bit width / head geometry not served.");
+    const int rc = qkv_rope_attn_launch(x, q_out, qweight, lut, N, K, bits, norm_weight, eps, pos, cos_table, sin_table, k_cache, v_cache, n_head, n_kv_head,
+                                        head_dim, max_seq, attn_out, scale, flags, stream, false);
+    return rc == GQ_ENOTSUP ? gq_fail(GQ_ENOTSUP, "gq_anyprec_gemv_qkv_rope_attn: shape / bit width / head geometry not served.") : rc;
 }

@@ -47,6 +47,11 @@ struct GqPerDeviceOnce {
 #define GQ_STAMPS 0
 #endif
 
+// waves of an attention block (decode.hip; the head blocks inside the wqkv launch, ap_stream.hip::ap_qkv_attn_kernel, run the same code)
+#ifndef GQ_ATTN_WAVES
+#define GQ_ATTN_WAVES 8
+#endif
+
 #if defined(__HIPCC__)
 // `(half)(a * b)` on floats: the compiler folds the conversion into v_fma_mixlo_f16, which rounds the EXACT product once.
 // The reference's torch ops round the fp32 product first and convert then (two roundings; they differ on fp16 ties of the

@@ -428,6 +428,9 @@ class Transformer(nn.Module):
                 x=torch.zeros(c.dim, **f16), h=torch.zeros(c.dim, **f16), y=torch.zeros(c.dim, **f16),
                 qkv=torch.zeros((c.n_head + 2 * c.n_local_heads) * c.head_dim, **f16),
                 ssq=torch.zeros(_lib.SSQ_SLOTS, dtype=torch.float32, device=dev),  # statistics hand-over slots (gq_hip.h GQ_SSQ_SLOTS)
+                # one flag line per query head for the attention heads that run inside the wqkv launch (gq_anyprec_gemv_qkv_rope_attn:
+                # zero between launches; one buffer for all layers)
+                attn_flags=torch.zeros(c.n_head * _lib.ATTN_FLAG_STRIDE, dtype=torch.int32, device=dev),
                 gu=torch.zeros(2 * c.intermediate_size, **f16), logits=torch.zeros(1, 1, c.vocab_size, **f16))
             # long caches: split-KV attention (gq_attn_decode_split), n_split blocks per head + a combine launch; a context of
             # up to 256 positions is still finished by one block per head at run time
@@ -814,7 +817,17 @@ class Transformer(nn.Module):
             w2_ssq = ssq if (pairs and ho["w2_out"] and nxt is not None and l0 + li + 1 < l1 and self._handover_plan(nxt)["qkv_in"]) else None
             # RoPE + KV-cache write in the epilogue of the wqkv GEMV, attention without them, where the library serves the layer's
             # wqkv that way (fast mode, 2-bit, K <= 4096: csrc/ap_stream.hip); else the two launches of rounds 1-3
-            if L.gq_anyprec_qkv_rope_supported(at.wqkv.out_features, c.dim, at.wqkv.bitwidth, c.head_dim):
+            use_ssq = x_has_ssq and ho["qkv_in"]
+            if (b["attn_split"] == 1 and not use_ssq
+                    and L.gq_anyprec_qkv_rope_attn_supported(at.wqkv.out_features, c.dim, at.wqkv.bitwidth, c.head_dim, c.n_head, c.n_local_heads)):
+                # round 6: the attention heads as extra blocks of the wqkv launch (they wait on device flags for q / the new cache row):
+                # one launch and one kernel boundary less per layer, outputs bit-identical to the two launches below
+                ck(L.gq_anyprec_gemv_qkv_rope_attn(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
+                                                   at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
+                                                   c.norm_eps, pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), kc, vc,
+                                                   c.n_head, c.n_local_heads, c.head_dim, self.max_seq_length, y.data_ptr(), scale,
+                                                   b["attn_flags"].data_ptr(), st), "wqkv+rope+attention")
+            elif L.gq_anyprec_qkv_rope_supported(at.wqkv.out_features, c.dim, at.wqkv.bitwidth, c.head_dim):
                 ck(L.gq_anyprec_gemv_qkv_rope_ho(x.data_ptr(), qkv.data_ptr(), at.wqkv.qweight.data_ptr(), at.wqkv.lut.data_ptr(),
                                                  at.wqkv.out_features, c.dim, at.wqkv.bitwidth, blk.input_layernorm.weight.data_ptr(),
                                                  c.norm_eps, pos.data_ptr(), self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), kc, vc,

@@ -452,6 +452,27 @@ int gq_attn_decode_roped(const void *q, const int *pos, const void *k_cache, con
                          uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq, float scale, uint32_t n_split, float *workspace,
                          void *stream);
 
+/*
+ * Round 6: gq_anyprec_gemv_qkv_rope AND gq_attn_decode_roped (n_split = 1) as ONE launch -- the attention heads are extra blocks of the
+ * wqkv launch, on compute units the GEMV leaves idle; they fetch the position and the cached rows below it while the GEMV runs and
+ * wait on device flags for the rotated q and row *pos of the caches (csrc/ap_stream.hip::ap_qkv_attn_kernel: agent-scope stores /
+ * atomics / loads, a bounded poll -- on expiry the head's output is NaN, nothing hangs).  Replaces the two launches
+ * (inference/model.py:206-241 between `self.wqkv(x)` and `self.wo(y)`); q_out, the caches and attn_out are bit-identical to theirs.
+ *   attn_out  fp16 [n_head * head_dim]: softmax(q k^T * scale) v over positions 0..*pos (*pos >= max_seq: NaN, like the two launches)
+ *   flags     uint32 [n_head * GQ_ATTN_FLAG_STRIDE], 128-byte aligned, ZERO before the first launch; every launch leaves them zero
+ *             (one 128-byte line per head: agent-scope atomics on one line serialise at the memory side).  One buffer serves every
+ *             layer of a model (the launches of a stream are ordered).
+ * gq_anyprec_qkv_rope_attn_supported: 1 when this build serves the geometry that way (the fused wqkv launch is served, its grid +
+ * n_head blocks fit the device's compute units one each, AND the environment asks for it: GQ_QKV_ATTN=1 -- the form is OFF by default,
+ * measured no faster than the two launches, profiles/r06_attention_in_wqkv_launch.txt); the caller keeps the two launches otherwise.
+ */
+#define GQ_ATTN_FLAG_STRIDE 32
+int gq_anyprec_qkv_rope_attn_supported(uint32_t N, uint32_t K, int bits, uint32_t head_dim, uint32_t n_head, uint32_t n_kv_head);
+int gq_anyprec_gemv_qkv_rope_attn(const void *x, void *q_out, const uint32_t *qweight, const void *lut, uint32_t N, uint32_t K, int bits,
+                                  const void *norm_weight, float eps, const int *pos, const void *cos_table, const void *sin_table,
+                                  void *k_cache, void *v_cache, uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t max_seq,
+                                  void *attn_out, float scale, uint32_t *flags, void *stream);
+
 /* out[n] = sum_k rmsnorm?(x)[k] * W[n][k]      dense fp16 GEMV (lm_head `output`, model.py:94,128-129); fp32
  * accumulation, fp16 output; norm_weight == NULL skips the RMSNorm prologue.  K % 512 == 0. */
 int gq_dense_gemv_f16(const void *x, const void *W, void *out, uint32_t N, uint32_t K, const void *norm_weight, float eps,

@@ -85,7 +85,8 @@ def test_rmsnorm_prologue_default_dispatch_equals_unfused_chain(oracle, bits, N,
     rows = _rows(rng, N, 32)
     # which kernel family the default dispatch picks (ap_gemv.hip): behind the RMSNorm prologue the plane-MFMA kernel from 20 M weights
     # at every width (round 5); the plain launch from 20 M at 2 bits, 32 M at 3 / 4 bits -- below that the exact kernel
-    fused_fast, plain_fast = N * K >= 20 * 1000000, N * K >= (20 if bits == 2 else 32) * 1000000
+    # (round 6: at 4 bits every launch from 20 M weights runs the decode-to-fp16 matrix-core kernel, ap_gemv_dq_kernel -- a fast-mode kernel)
+    fused_fast, plain_fast = N * K >= 20 * 1000000, N * K >= (32 if bits == 3 else 20) * 1000000
     if fused_fast == plain_fast:
         diff = fused.view(np.uint16) != plain.view(np.uint16)
         assert diff.mean() <= 0.02, diff.mean()

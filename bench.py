@@ -565,7 +565,7 @@ def ap_roofline(model, bits, mode_arg):
     # HBM bytes per launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
     # tools/prof_bench.sh) for one kernel template, launch form and shape -- reported only when this run launches the same
     traffic, traffic_src = None, None
-    for tname in ("r05_w1w3_traffic.json", "r04_w1w3_traffic.json"):  # (the newest committed passes of this kernel template)
+    for tname in ("r06_w1w3_traffic.json", "r05_w1w3_traffic.json", "r04_w1w3_traffic.json"):  # (the newest committed passes of this kernel template)
         tpath = os.path.join(ROOT, "profiles", tname)
         if traffic is None and os.path.exists(tpath):
             with open(tpath) as f:

@@ -12,6 +12,7 @@
 //   * reduces through LDS in the reference's chunk order + 16/8/4/2/1 tree.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "ap_core.h"
 #include "gq_internal.h"
@@ -312,6 +313,194 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
 }
 
 // ----------------------------------------------------------------------------------------------
+// Round 6 -- exact mode, 2 bits: the reference's LDS PAIR TABLE (anyprec.cu:397-419,454-490) on wave64.
+//
+// ap_gemv_quad_kernel decodes with v_perm_b32 out of VGPR byte pools: 2.25 VALU operations per weight, the kernel is VALU-bound
+// (DESIGN.md section 3.1).  The reference looks a PAIR of weights up in a per-row table of 2^b x 2^b half2 entries in shared memory:
+// one load per two weights, and the entry IS the hfma2 operand (even weight, odd weight).  Here the same table -- 16 entries of 4
+// bytes per row at 2 bits -- lives in LDS per (wave, row of the wave: the lanes of a wave span at most two rows), rebuilt per row
+// step by 32 lanes with one v_perm and one ds_write each; a lane (row slot, quad) forms the sixteen 4-bit indices of a plane-word
+// pair with two v_bfi (M1 / M2 below), and per pair issues one v_lshrrev + one v_and_or (byte address) + one ds_read_b32 + one
+// v_pk_fma_f16: 3.25 VALU per PAIR instead of 4.5, the look-ups on the LDS pipe (16 words of one table sit in 16 different banks,
+// equal addresses broadcast: conflict-free).  The fp16 chains are the reference's own: per word (CUDA lane) ONE half2 accumulator
+// (even chain, odd chain), byte c = 3..0, pair k = 0..3 (anyprec.cu:495-504), then sum.x + sum.y -- bit-identical to
+// ap_gemv_quad_kernel and to the order-faithful oracle (tests/test_ap_gemv_gpu.py runs both kernels over every exact-mode case).
+// The activation image in LDS is x in its natural order (a lane's 8 activations of (word v, byte c) are 16 contiguous bytes).
+// ----------------------------------------------------------------------------------------------
+template <int PRO>
+__device__ __forceinline__ void stage_x_natural(const RowGeom &G, const uint16_t *x, const uint16_t *normw, float eps, uint16_t *xlds, float *red,
+                                                bool stager, u32 T) {
+    // 16-byte units (8 activations) per stager thread; same arithmetic and rounding points as stage_x
+    const u32 tid = threadIdx.x, nun = G.K / 8u;
+    float scale = 0.f;
+    if constexpr (PRO == PRO_RMSNORM) {
+        float ss = 0.f;
+        for (u32 u = stager ? tid : nun; u < nun; u += T) {
+            const uint4 t4 = ld16(x + 8u * u);
+            const u32 w[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float a = h2f(w[i] & 0xFFFF), b = h2f(w[i] >> 16);
+                ss += a * a;
+                ss += b * b;
+            }
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        if ((tid & 63u) == 0 && stager) red[tid >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
+        scale = 1.0f / sqrtf(tot / (float)G.K + eps);
+    }
+    for (u32 u = stager ? tid : nun; u < nun; u += T) {
+        uint4 t4 = ld16(x + 8u * u);
+        u32 in[4] = {t4.x, t4.y, t4.z, t4.w};
+        if constexpr (PRO == PRO_RMSNORM) {
+            const uint4 n4 = ld16(normw + 8u * u);
+            const u32 nw[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint16_t a = f2h(gq_pin_f32(h2f(in[i] & 0xFFFF) * scale)), b = f2h(gq_pin_f32(h2f(in[i] >> 16) * scale));
+                const _Float16 ra = __builtin_bit_cast(_Float16, a) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] & 0xFFFF));
+                const _Float16 rb = __builtin_bit_cast(_Float16, b) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] >> 16));
+                in[i] = (u32)__builtin_bit_cast(uint16_t, ra) | ((u32)__builtin_bit_cast(uint16_t, rb) << 16);
+            }
+        }
+        if constexpr (PRO == PRO_SILUMUL) {
+            const uint4 u4 = ld16(x + G.K + 8u * u);
+            const u32 uw[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) in[i] = silu_mul_pk(in[i], uw[i]);
+        }
+        *reinterpret_cast<uint4 *>(xlds + 8u * u) = make_uint4(in[0], in[1], in[2], in[3]);
+    }
+}
+
+template <int PRO>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) ap_gemv_pt2_kernel(ApArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BITS = 2, NRAW = 2;
+    RowGeom G;
+    G.init(a.K);
+    uint16_t *xlds = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *sv = xlds + G.K;  // [SPB*RS][nchunks*32]
+    const u32 svrow = G.nchunks * 32u;
+    float *red = reinterpret_cast<float *>(sv);
+    const u32 T = blockDim.x, tid = threadIdx.x, l = tid & 63u, wv = tid >> 6;
+    const u32 RS = a.RS, SPB = a.SPB;
+    const u32 row0 = blockIdx.x * SPB * RS;
+    const u32 m = blockIdx.y;
+    const bool active = tid < RS * G.Q;
+    const u32 rs = active ? tid / G.Q : 0u;
+    const u32 q = active ? tid - rs * G.Q : 0u;
+    // pair tables of this wave: [2 rows of the wave][16 entries] words, behind sv
+    u32 *tabs = reinterpret_cast<u32 *>(smem + (((size_t)G.K * 2u + (size_t)SPB * RS * svrow * 2u + 63u) & ~(size_t)63u)) + wv * 32u;
+    constexpr u32 OOB = 0x80000000u;
+    const u32 plane_bytes = a.N * G.wpr * 4u;
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw, 0, (int)(plane_bytes * (u32)BITS), 0x00020000);
+    __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)a.lut, 0, (int)(a.N * (u32)NRAW * 4u), 0x00020000);
+    u32x4 P[BITS];
+    u32 lraw[NRAW];
+    auto issue = [&](u32 step) {
+        const u32 row = row0 + step * RS + rs;
+        const bool ok = active && step < SPB && row < a.N;
+        const u32 off = ok ? (row * G.wpr + 4u * q) * 4u : OOB;
+#pragma unroll
+        for (int p = 0; p < BITS; p++) P[p] = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? off + (u32)p * plane_bytes : OOB, 0, 2 /* nt */);
+        auto v = __builtin_amdgcn_raw_buffer_load_b64(rl, ok ? row * (u32)NRAW * 4u : OOB, 0, 0);
+        lraw[0] = v[0];
+        lraw[1] = v[1];
+    };
+    const u32 nw = T >> 6;
+    const bool stager = nw < 2u || wv < nw / 2u;
+    if (!stager) issue(0u);
+    stage_x_natural<PRO>(G, a.x + (size_t)m * (PRO == PRO_SILUMUL ? 2u * G.K : G.K), a.normw, a.eps, xlds, red, stager, nw < 2u ? T : (nw / 2u) * 64u);
+    if (stager) issue(0u);
+    __syncthreads();
+    // the lane's activations: xr[v][c] = the 8 activations of (word v, byte c) = 4 half2 operands (pair k = 0..3)
+    u32 chunk, t0, tpw;
+    G.quad(q, chunk, t0, tpw);
+    uint4 xr[4][4];
+#pragma unroll
+    for (u32 v = 0; v < 4; v++)
+#pragma unroll
+        for (u32 c = 0; c < 4; c++) xr[v][c] = *reinterpret_cast<const uint4 *>(xlds + 1024u * chunk + 8u * tpw * c + 8u * (t0 + v));
+    // table builders: lanes 0..15 build the table of the row of lane 0, lanes 16..31 that of the row of lane 63; entry i = (h_even,
+    // h_odd, l_even, l_odd) -> half2(lut[2 h_even + l_even], lut[2 h_odd + l_odd]): the selector of the lane's entry is a constant
+    const u32 ei = l & 15u;
+    const u32 ce = ((ei >> 3) & 1u) * 2u + ((ei >> 1) & 1u), co = ((ei >> 2) & 1u) * 2u + (ei & 1u);
+    const u32 esel = (2u * ce) | ((2u * ce + 1u) << 8) | ((2u * co) << 16) | ((2u * co + 1u) << 24);
+    // which of the wave's two tables this lane reads: the row slot of lane 0 -> table 0, else table 1 (byte offset 64)
+    // (the last ACTIVE lane of the wave carries its second row; a wave without active lanes builds tables nobody reads)
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    const u32 hi_lane = act ? 63u - (u32)__builtin_clzll(act) : 0u;
+    const u32 rs_lo = (u32)__builtin_amdgcn_readfirstlane((int)rs);
+    const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)reinterpret_cast<unsigned char *>(tabs) + (rs == rs_lo ? 0u : 64u);
+    uint16_t *svp = sv + (size_t)rs * svrow + chunk * 32u + t0;
+    for (u32 i = 0; i < SPB; i++) {
+        u32 Pw[BITS][4];
+#pragma unroll
+        for (int p = 0; p < BITS; p++) {
+            Pw[p][0] = P[p].x;
+            Pw[p][1] = P[p].y;
+            Pw[p][2] = P[p].z;
+            Pw[p][3] = P[p].w;
+        }
+        // this step's tables (the LDS serves a wave's operations in order: the previous step's look-ups are behind us)
+        {
+            const u32 lo0 = (u32)__builtin_amdgcn_readlane((int)lraw[0], 0), lo1 = (u32)__builtin_amdgcn_readlane((int)lraw[1], 0);
+            const u32 hi0 = (u32)__builtin_amdgcn_readlane((int)lraw[0], (int)hi_lane), hi1 = (u32)__builtin_amdgcn_readlane((int)lraw[1], (int)hi_lane);
+            const u32 ent = l < 16u ? perm(lo1, lo0, esel) : perm(hi1, hi0, esel);
+            if (l < 32u) tabs[l] = ent;
+        }
+        issue(i + 1u);
+        u32 s[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            // nibble n of M1: bits (4 n + 3, 4 n + 2) of H and L; of M2: bits (4 n + 1, 4 n).  Byte c of a word = bits 8 (3 - c) ..;
+            // pair k of byte c = bits (7 - 2 k, 6 - 2 k): k = 0, 2 from M1 (upper, lower nibble of the byte), k = 1, 3 from M2
+            const u32 M1 = bfi(0xCCCCCCCCu, Pw[0][v], Pw[1][v] >> 2), M2 = bfi(0xCCCCCCCCu, Pw[0][v] << 2, Pw[1][v]);
+            u32 acc = 0u;
+#pragma unroll
+            for (int c = 3; c >= 0; c--) {
+                const u32 xw[4] = {xr[v][c].x, xr[v][c].y, xr[v][c].z, xr[v][c].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 Mk = (k & 1) ? M2 : M1;
+                    const int nib = 2 * (3 - c) + ((k & 2) ? 0 : 1);  // nibble index inside the word
+                    const int sh = 4 * nib - 2;                       // bring the nibble to bits 5..2 (= index * 4)
+                    const u32 addr = ((sh >= 0 ? (Mk >> sh) : (Mk << 2)) & 0x3Cu) | tbase;
+                    // (an LDS-address-space load of the byte offset: through the generic `smem + addr` every look-up paid a v_add for the base)
+                    const u32 w2 = *(const __attribute__((address_space(3))) u32 *)(uintptr_t)addr;
+                    acc = pk_fma(w2, xw[k], acc);
+                }
+            }
+            s[v] = (u32)h_add((uint16_t)(acc & 0xFFFFu), (uint16_t)(acc >> 16));
+        }
+        if (active) *reinterpret_cast<uint2 *>(svp + (size_t)i * RS * svrow) = make_uint2(s[0] | (s[1] << 16), s[2] | (s[3] << 16));
+    }
+    __syncthreads();
+    // ordered reduction + epilogue: as ap_gemv_quad_kernel
+    const u32 t = tid & 31u;
+    for (u32 rl2 = tid >> 5; rl2 < SPB * RS; rl2 += T >> 5) {
+        const u32 row = row0 + rl2;
+        uint16_t y = reduce_row(G, sv + (size_t)rl2 * svrow, t, 0u, G.nchunks);
+        if (a.epilogue & GQ_EPI_SILU_PAIRS) {
+            const uint16_t yo = (uint16_t)__shfl_xor((int)y, 32);
+            if (t == 0 && !(tid & 32u) && row + 1u < a.N) {
+                const float gv = (float)__builtin_bit_cast(_Float16, y);
+                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, yo);
+                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
+            }
+        } else if (t == 0 && row < a.N) {
+            if (a.resid) y = h_add(a.resid[(size_t)m * a.N + row], y);
+            a.out[(size_t)m * a.N + row] = y;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Round 6 -- "decode to fp16, accumulate on the matrix cores" (fast mode, 3 and 4 bits, one batch row).
 //
 // The plane-MFMA kernels (ap_plane.hip / ap_stream.hip) multiply 2^b - 1 BINARY matrices per b-bit LUT: 3 at 2 bits, 7 at 3, 15
@@ -426,6 +615,9 @@ struct DqArgs {
 #define DQ_WAVES_N 16
 #endif
 constexpr u32 DQ_WAVES = DQ_WAVES_N;
+// (also measured slower, round 6: two or three items' plane words in flight per wave with ONE copy of the decode -- slots moved into work
+// registers behind explicit s_waitcnt vmcnt(n), re-requested 2 / 3 items ahead: w1w3 3-bit 18.0 / 19.6 vs 15.7 us, 4-bit 26.3 / 40.9 vs 23.0.
+// More plane words in flight do not help this kernel: issuing a load blocks the wave once the CU's memory pipe is full.)
 // ring depth 1: the next item's plane words are requested while this one is decoded.  Deeper rings measured SLOWER (w1w3 3-bit 15.5 /
 // 17.4 / 19.1 us, 4-bit 22.9 / 25.2 / 27.7 us at depth 1 / 2 / 3, profiles/r06_dq_kernel.txt): the unrolled decode of one item is
 // ~600 instructions (5 KB) already, and every slot of a ring is another copy of it in the instruction cache
@@ -491,21 +683,37 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
             }
         }
     };
+    auto first_requests = [&]() {
+#pragma unroll
+        for (int d = 0; d < D; d++) issue(d, w + (u32)d * DQ_WAVES);
+    };
     // the waves that stage x (the lower half) request their first items behind the activations, the others at once (the CU's
     // memory pipe serves requests in order)
     const bool stager = DQ_WAVES < 2u || w < DQ_WAVES / 2u;
-    if (!stager) {
-#pragma unroll
-        for (int d = 0; d < D; d++) issue(d, w + (u32)d * DQ_WAVES);
-    }
+    if (!stager) first_requests();
     stage_x<PRO>(G, a.x, a.normw, a.eps, xlds, red, stager, (DQ_WAVES < 2u ? 1u : DQ_WAVES / 2u) * 64u);
-    if (stager) {
-#pragma unroll
-        for (int d = 0; d < D; d++) issue(d, w + (u32)d * DQ_WAVES);
-    }
+    if (stager) first_requests();
     __syncthreads();
     // B fragments: column 0 reads the image, the other columns read zeros from beyond the block's LDS allocation (192 KiB up)
     const u32 Q = G.Q;
+    auto decode_item = [&](u32 it, const u32 (&Pw)[BITS][4], const u32 (&lw)[NRAW]) {
+        LutPools<BITS> L;
+        L.build(lw);
+        const u32 rgl = it / NU, u = it - rgl * NU;
+        const u32 q = 4u * u + g;
+        const unsigned char *bb = r == 0u ? reinterpret_cast<const unsigned char *>(xlds) + (size_t)q * 16u
+                                          : reinterpret_cast<const unsigned char *>(smem) + 0x30000u;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        DqItem<BITS>::run(Pw, L, [&](int c, int jj, u32 a01, u32 a23, u32 b01, u32 b23) {
+            const u32x4 av = {a01, a23, b01, b23};
+            const uint4 bv = *reinterpret_cast<const uint4 *>(bb + (size_t)((u32)(c * 4 + jj) * Q) * 16u);
+            const u32x4 bvv = {bv.x, bv.y, bv.z, bv.w};
+            if (jj & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc0, 0, 0, 0);
+        });
+        // D[row 4 g + e][column r]: column 0 holds the sums
+        if (r == 0u) *reinterpret_cast<f32x4 *>(part + (size_t)it * 16u + 4u * g) = acc0 + acc1;
+    };
     for (u32 it0 = w; it0 < nitems; it0 += (u32)D * DQ_WAVES) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -518,24 +726,12 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
                 Pw[p][2] = P[d][p].z;
                 Pw[p][3] = P[d][p].w;
             }
-            LutPools<BITS> L;
-            L.build(lraw[d]);
+            u32 lw[NRAW];
+#pragma unroll
+            for (int i = 0; i < NRAW; i++) lw[i] = lraw[d][i];
             issue(d, it + (u32)D * DQ_WAVES);
             if (it >= nitems) continue;  // (wave-uniform)
-            const u32 rgl = it / NU, u = it - rgl * NU;
-            const u32 q = 4u * u + g;
-            const unsigned char *bb = r == 0u ? reinterpret_cast<const unsigned char *>(xlds) + (size_t)q * 16u
-                                              : reinterpret_cast<const unsigned char *>(smem) + 0x30000u;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            DqItem<BITS>::run(Pw, L, [&](int c, int jj, u32 a01, u32 a23, u32 b01, u32 b23) {
-                const u32x4 av = {a01, a23, b01, b23};
-                const uint4 bv = *reinterpret_cast<const uint4 *>(bb + (size_t)((u32)(c * 4 + jj) * Q) * 16u);
-                const u32x4 bvv = {bv.x, bv.y, bv.z, bv.w};
-                if (jj & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc0, 0, 0, 0);
-            });
-            // D[row 4 g + e][column r]: column 0 holds the sums
-            if (r == 0u) *reinterpret_cast<f32x4 *>(part + (size_t)it * 16u + 4u * g) = acc0 + acc1;
+            decode_item(it, Pw, lw);
         }
     }
     __syncthreads();
@@ -732,6 +928,9 @@ __global__ void __launch_bounds__(256) ap_dequant_kernel(const u32 *qw, const ui
 // ----------------------------------------------------------------------------------------------
 // Launchers
 // ----------------------------------------------------------------------------------------------
+#ifndef GQ_AP_PT_DEFAULT
+#define GQ_AP_PT_DEFAULT 1  // exact mode, 2 bits: the LDS pair-table kernel (ap_gemv_pt2_kernel) instead of the v_perm kernel on long rows
+#endif
 #ifndef GQ_DQ_DEFAULT
 #define GQ_DQ_DEFAULT 6  // (bit mask over the bit widths 2, 3, 4 the decode-to-fp16 kernel may take: 3 and 4)
 #endif
@@ -825,6 +1024,31 @@ int launch_quad(const ApArgs &a, const QuadCfg &c, u32 M, int pro, hipStream_t s
         case PRO_SILUMUL: return launch_quad_d<BITS, PRO_SILUMUL>(a, c, M, s);
         default: return launch_quad_d<BITS, PRO_NONE>(a, c, M, s);
     }
+}
+
+// the 2-bit pair-table kernel on the quad kernel's configuration (+ the waves' tables behind the partial sums); GQ_ENOTSUP where a wave
+// could span more than two rows (fewer than 64 quads per row unless exactly 32) or the tables do not fit
+int launch_pt2(const ApArgs &a, const QuadCfg &c, u32 M, int pro, hipStream_t s) {
+    const u32 Q = a.K / 128u;
+    if (!(Q == 32u || Q >= 64u) || (c.T & 63u) || (Q == 32u && (c.T % 64u))) return GQ_ENOTSUP;
+    const u32 nchunks = a.K / 1024u + ((a.K % 1024u) ? 1u : 0u);
+    const size_t smem = (((size_t)a.K * 2u + (size_t)c.SPB * c.RS * nchunks * 64u + 63u) & ~(size_t)63u) + (size_t)(c.T / 64u) * 128u + 64u;
+    if (smem > 160u * 1024u) return GQ_ENOTSUP;
+    dim3 grid(c.grid, M), block(c.T);
+#define GQ_PT2(PRO_)                                                                                                            \
+    do {                                                                                                                        \
+        static GqPerDeviceOnce once;                                                                                            \
+        GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(ap_gemv_pt2_kernel<PRO_>), (int)(160u * 1024u)));        \
+        hipLaunchKernelGGL(ap_gemv_pt2_kernel<PRO_>, grid, block, smem, s, a);                                                  \
+    } while (0)
+    switch (pro) {
+        case PRO_RMSNORM: GQ_PT2(PRO_RMSNORM); break;
+        case PRO_SILUMUL: GQ_PT2(PRO_SILUMUL); break;
+        default: GQ_PT2(PRO_NONE); break;
+    }
+#undef GQ_PT2
+    GQ_HIP_CHECK(hipGetLastError());
+    return GQ_OK;
 }
 
 template <int BITS>
@@ -929,6 +1153,16 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
         !((a.epilogue & GQ_EPI_SILU_PAIRS) && ((c.SPB * c.RS) & 1u))) {
         a.RS = c.RS;
         a.SPB = c.SPB;
+        // round 6: the pair-table kernel where it measured faster -- rows of >= 8192 weights (8B w2: 11.3 vs 12.7 us; w1w3 18.0 vs 18.3:
+        // a tie; wqkv 9.5 vs 8.4 and wo 5.9 vs 5.2: slower; profiles/r06_exact_pair_table.txt).  GQ_AP_PT: 0 never, 1 (default) those
+        // rows, 2 every shape it serves
+        {
+            const int pt = gq_env_int("GQ_AP_PT", GQ_AP_PT_DEFAULT);
+            if (bits == 2 && (pt >= 2 || (pt == 1 && a.K >= 8192u))) {
+                const int rc = launch_pt2(a, c, M, pro, s);
+                if (rc != GQ_ENOTSUP) return rc;
+            }
+        }
         switch (bits) {
             case 2: return launch_quad<2>(a, c, M, pro, s);
             case 3: return launch_quad<3>(a, c, M, pro, s);

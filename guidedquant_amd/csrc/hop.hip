@@ -70,6 +70,12 @@ extern "C" int gq_hop_free(void *ptr) {
     if (ptr) GQ_HIP_CHECK(hipFree(ptr));
     return GQ_OK;
 }
+extern "C" int gq_hop_is_finegrained(const void *ptr) {
+    if (!ptr) return gq_fail(GQ_EINVAL, "null pointer argument.");
+    hipPointerAttribute_t at;
+    GQ_HIP_CHECK(hipPointerGetAttributes(&at, ptr));
+    return (at.allocationFlags & hipDeviceMallocFinegrained) ? 1 : 0;
+}
 extern "C" int gq_hop_export(void *ptr, void *handle64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     if (!ptr || !handle64) return gq_fail(GQ_EINVAL, "null pointer argument.");

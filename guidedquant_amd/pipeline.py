@@ -167,6 +167,10 @@ class PipelinedDecoder:
             self._fg = int(p.value)
             handle = (ctypes.c_ubyte * 64)()
             _lib.check(L.gq_hop_export(self._fg, handle), "gq_hop_export")
+            # what a peer on ANOTHER device writes must be fine-grained memory (a coarse-grained landing slot would work between ranks that
+            # share one GPU -- the tests -- and lose writes across xGMI): checked here, where the handle leaves the process
+            if L.gq_hop_is_finegrained(self._fg) != 1:
+                raise RuntimeError("pipeline hop: the landing block is not fine-grained device memory (gq_hop_alloc)")
 
         class _Raw:  # a torch view of raw device memory (CUDA array interface): reset() writes the words with tensor ops
             def __init__(r, ptr, n):

@@ -106,6 +106,8 @@ class TensorParallelDecoder:
             self._fg = int(p.value)
             handle = (ctypes.c_ubyte * 64)()
             _lib.check(L.gq_hop_export(self._fg, handle), "gq_hop_export")
+            if L.gq_hop_is_finegrained(self._fg) != 1:  # (peers on other devices write here: see pipeline.py::_setup_ipc)
+                raise RuntimeError("tensor-parallel exchange: the landing block is not fine-grained device memory (gq_hop_alloc)")
         self._seq = torch.as_tensor(_Raw(self._fg + self._seq_off, 4 * W, "<i4"), device=self.dev)
         self._seq.zero_()
         torch.cuda.synchronize()

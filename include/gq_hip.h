@@ -415,6 +415,10 @@ int gq_hop_free(void *ptr);
 int gq_hop_export(void *ptr, void *handle64);
 int gq_hop_import(const void *handle64, void **ptr);
 int gq_hop_close(void *ptr);
+/* 1 when `ptr` lies in memory THIS process allocated fine-grained (hipPointerGetAttributes: allocationFlags has
+ * hipDeviceMallocFinegrained), 0 when not, < 0 on error -- what pipeline.py / tp.py assert of their landing buffers before a
+ * rank on another device is given the handle. */
+int gq_hop_is_finegrained(const void *ptr);
 int gq_hop_wait_copy(const uint32_t *seq_local, const uint32_t *tick, uint32_t add, uint32_t *err, uint32_t max_spins, const void *landed,
                      void *dst, uint32_t nbytes, void *stream);
 

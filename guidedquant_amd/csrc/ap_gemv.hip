@@ -334,15 +334,21 @@ __device__ __forceinline__ void stage_x_natural(const RowGeom &G, const uint16_t
     const u32 tid = threadIdx.x, nun = G.K / 8u;
     float scale = 0.f;
     if constexpr (PRO == PRO_RMSNORM) {
+        // (the sum of squares in stage_x's order -- thread idx takes the 32 activations of (quad idx / 4, byte idx % 4) -- so that both
+        // exact kernels normalise with the same fp32 statistic, bit for bit)
         float ss = 0.f;
-        for (u32 u = stager ? tid : nun; u < nun; u += T) {
-            const uint4 t4 = ld16(x + 8u * u);
-            const u32 w[4] = {t4.x, t4.y, t4.z, t4.w};
+        for (u32 idx = stager ? tid : 4u * G.Q; idx < 4u * G.Q; idx += T) {
+            const u32 e0 = G.xindex(idx >> 2, 0u, idx & 3u, 0u);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float a = h2f(w[i] & 0xFFFF), b = h2f(w[i] >> 16);
-                ss += a * a;
-                ss += b * b;
+            for (int v = 0; v < 4; v++) {
+                const uint4 t4 = ld16(x + e0 + 8 * v);
+                const u32 w[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float a = h2f(w[i] & 0xFFFF), b = h2f(w[i] >> 16);
+                    ss += a * a;
+                    ss += b * b;
+                }
             }
         }
 #pragma unroll

@@ -377,3 +377,43 @@ def test_fast_mode_within_north_star_tolerance_of_reference_order(oracle, bits, 
     rel = np.linalg.norm(g - ref) / np.linalg.norm(ref)
     assert rel <= REL_TOL, rel
     assert rel <= 1.1 * np.linalg.norm(y64 - ref) / np.linalg.norm(ref) + 1e-5
+
+
+@pytest.mark.parametrize("pt", ["0", "2"])
+@pytest.mark.parametrize("M", [1, 3])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (1000, 8192), (520, 11008), (64, 28672), (36, 4096), (300, 2048)])
+def test_two_bit_exact_kernels_agree_with_the_oracle_on_both_decodes(oracle, N, K, M, pt):
+    """exact mode, 2 bits: the v_perm byte-pool kernel (GQ_AP_PT=0) and the LDS pair-table kernel (GQ_AP_PT=2: every shape it serves --
+    rows of 4096 weights or >= 8192; 2048 and ragged widths fall back to the first) both reproduce the reference's fp16 order bit for
+    bit: rows x widths incl. a tail chunk (11008), the 70B down projection's width, several batch rows; plus the fused prologues /
+    epilogues on the pair-table kernel against the same chain on the v_perm kernel."""
+    from guidedquant_amd import _lib, pack
+    from ap_helpers import run_fused
+    L = _lib.lib()
+    os.environ["GQ_AP_PT"] = pt
+    L.gq_reset_env_cache()
+    try:
+        bits = 2
+        rng = np.random.default_rng(N + K + M)
+        q = pack.random_planes(N, K, bits, seed=N + K)
+        lut = (rng.normal(0, 1, (N, 4)) * 10.0**rng.integers(-4, 1, (N, 1))).astype(np.float16)
+        x = (rng.normal(0, 1, (M, K)) * 10.0**rng.integers(-2, 2, (M, K))).astype(np.float16)
+        got = _run_gemv(x, q, lut, bits, M=M)
+        rows = np.unique(np.concatenate([np.arange(0, min(N, 24)), np.arange(max(0, N - 24), N), rng.integers(0, N, 32)]))
+        for m in range(M):
+            want = oracle.ap_gemv_f16(x[m], np.ascontiguousarray(q[:, rows, :]), lut[rows], bits)[0]
+            assert np.array_equal(got[m][rows].view(np.uint16), want.view(np.uint16)), (m, pt)
+        if M == 1 and N % 2 == 0 and K in (4096, 8192, 14336):  # (widths whose row step is even: the pair epilogue's condition, both kernels)
+            nw = (1 + 0.1 * rng.normal(0, 1, K)).astype(np.float16)
+            res = rng.normal(0, 1, N).astype(np.float16)
+            outs = {}
+            for p2 in ("0", pt):
+                os.environ["GQ_AP_PT"] = p2
+                L.gq_reset_env_cache()
+                outs[p2] = (run_fused(x[0], q, lut, bits, norm_weight=nw, eps=1e-5), run_fused(x[0], q, lut, bits, norm_weight=nw, eps=1e-5, flags=4, out_elems=N // 2),
+                            run_fused(x[0], q, lut, bits, residual=res, flags=1))
+            for a, b in zip(outs["0"], outs[pt]):
+                assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+    finally:
+        os.environ.pop("GQ_AP_PT", None)
+        L.gq_reset_env_cache()

@@ -60,11 +60,12 @@ class _CapturedStep:
     """State of route 2 (`generate(capture=True)`): the StaticCache, the device words the captured step reads and writes, and the
     hipGraph of one token step of the HF module tree.  A plain object -- no closure over its own state, so no reference cycle owns the
     graph -- with an explicit `close()`: the owner (`AnyPrecisionForCausalLM._evict`) destroys the graph when it drops the entry."""
-    __slots__ = ("model", "V", "top_k", "temperature", "seed", "cache", "tok64", "tok", "pos", "nxt", "ctr", "wv", "wi", "ban", "seq", "logits", "graph")
+    __slots__ = ("model", "V", "top_k", "top_p", "temperature", "seed", "cache", "tok64", "tok", "pos", "nxt", "ctr", "wv", "wi", "ban", "seq", "logits", "graph")
 
-    def __init__(self, model, config, dev, total, temperature, top_k, seed):
+    def __init__(self, model, config, dev, total, temperature, top_k, seed, top_p=1.0):
         from transformers import StaticCache
         self.model, self.V, self.top_k, self.temperature, self.seed = model, int(config.vocab_size), int(top_k), float(temperature), int(seed)
+        self.top_p = float(top_p)
         self.cache = StaticCache(config=config, max_cache_len=total)
         z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
         self.tok64 = z((1, 1), torch.long)
@@ -78,10 +79,10 @@ class _CapturedStep:
         # (positions come from the cache itself: StaticLayer.cumulative_length is a device word the layer advances in place)
         out = self.model(input_ids=self.tok64, past_key_values=self.cache, use_cache=True)
         self.logits.copy_(out.logits.view(-1))
-        _lib.check(_lib.lib().gq_sample_topk_ex(self.logits.data_ptr(), self.V, self.top_k, self.temperature, self.seed, self.ctr.data_ptr(),
-                                               self.wv.data_ptr(), self.wi.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), self.nxt.data_ptr(),
-                                               self.ban.data_ptr(), self.seq.data_ptr(), self.seq.numel(), None, None, 0, None,
-                                               _lib.current_stream_ptr()), "gq_sample_topk_ex")
+        _lib.check(_lib.lib().gq_sample_topk_p(self.logits.data_ptr(), self.V, self.top_k, self.top_p, self.temperature, self.seed, self.ctr.data_ptr(),
+                                              self.wv.data_ptr(), self.wi.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), self.nxt.data_ptr(),
+                                              self.ban.data_ptr(), self.seq.data_ptr(), self.seq.numel(), None, None, 0, None,
+                                              _lib.current_stream_ptr()), "gq_sample_topk_p")
         self.tok64.copy_(self.tok.view(1, 1))
 
     def _set_cache_length(self, n):
@@ -274,8 +275,8 @@ class AnyPrecisionForCausalLM(nn.Module):
                  "num_return_sequences", "repetition_penalty", "return_dict_in_generate"}
 
     def _route_request(self, args, kwargs):
-        """(params, None) when the request is one the fused decode routes serve -- ONE sequence, greedy or top-k (<= 64) sampling at
-        top_p = 1, no logits processors beyond min_new_tokens on EOS -- else (None, reason).  Missing sampling arguments come from
+        """(params, None) when the request is one the fused decode routes serve -- ONE sequence, greedy or top-k (<= 64) sampling with
+        or without a nucleus (top_p), no logits processors beyond min_new_tokens on EOS -- else (None, reason).  Missing sampling arguments come from
         the model's generation_config exactly as in transformers (top_k defaults to 50 there)."""
         if len(args) > 1 or any(k not in self._ROUTE_KW for k in kwargs):
             return None, "arguments outside the fused routes: %s" % sorted(k for k in kwargs if k not in self._ROUTE_KW)
@@ -321,13 +322,16 @@ class AnyPrecisionForCausalLM(nn.Module):
         if am is not None and not (tuple(am.shape) == tuple(ids.shape) and bool((am != 0).all())):
             return None, "attention_mask with masked positions"
         do_sample = bool(g("do_sample", False))
-        temperature, top_k = 0.0, 1
+        temperature, top_k, top_p = 0.0, 1, 1.0
         if do_sample:
             t_ = g("temperature", 1.0)
             temperature = 1.0 if t_ is None else float(t_)
             top_p, top_k = g("top_p", 1.0), g("top_k", 50)
-            if top_p is not None and float(top_p) < 1.0:
-                return None, "top_p < 1"
+            top_p = 1.0 if top_p is None else float(top_p)
+            if not 0.0 < top_p <= 1.0:
+                return None, "top_p outside (0, 1]"
+            # (round 6: top_p < 1 is served -- the fused sampler filters the nucleus of its top-k survivors the way transformers chains
+            # TopKLogitsWarper and TopPLogitsWarper; without a top_k <= 64 the nucleus of the FULL distribution would be needed: declined)
             # (top_k None or 0 = no top-k filtering in transformers: the full distribution, which the 64-candidate sampler does not draw from)
             if not top_k or int(top_k) < 1 or int(top_k) > 64 or temperature <= 0.0:
                 return None, "top_k outside 1..64 (the fused sampler's candidates)"
@@ -336,7 +340,7 @@ class AnyPrecisionForCausalLM(nn.Module):
         if len(eos) > 4:
             return None, "more than 4 EOS ids"
         return dict(ids=ids, T=T, max_new=int(max_new), min_new=min(int(g("min_new_tokens", 0) or 0), int(max_new)), temperature=temperature,
-                    top_k=int(top_k), eos=eos, streamer=kwargs.get("streamer"), do_sample=do_sample), None
+                    top_k=int(top_k), top_p=float(top_p), eos=eos, streamer=kwargs.get("streamer"), do_sample=do_sample), None
 
     def generate(self, *args, **kwargs):
         """`generate` of the reference's HF surface (inference_example.py:34-77).  Three routes behind the one call:
@@ -431,14 +435,14 @@ class AnyPrecisionForCausalLM(nn.Module):
         if total > dec.config.block_size:
             raise ValueError(f"prompt + max_new_tokens = {total} exceeds the model's context ({dec.config.block_size})")
         dec.setup_caches(1, total)
-        key = (self.precision, dec.max_seq_length, req["temperature"], req["top_k"])
+        key = (self.precision, dec.max_seq_length, req["temperature"], req["top_k"], req["top_p"])
         graph = self._native_cache.get(("graph",) + key)
         if graph is None:
             self._evict("graph")
             # (eight token steps per graph replay -- the host looks at the sequence once per `chunk` = 32 tokens anyway; what is left of a
             # chunk runs through the single-step graph over the same state: exactly the steps asked for)
             graph = gen.DecodeGraph(dec, self.device, native_sampling=True, fold_embed=True, seq_capacity=dec.max_seq_length + 1,
-                                    seed=self._SAMPLER_SEED, temperature=req["temperature"], top_k=req["top_k"], steps_per_replay=8)
+                                    seed=self._SAMPLER_SEED, temperature=req["temperature"], top_k=req["top_k"], top_p=req["top_p"], steps_per_replay=8)
             self._native_cache[("graph",) + key] = graph
         if req.get("do_sample"):
             graph.rng_counter.copy_(self._fresh_rng_word())
@@ -484,14 +488,14 @@ class AnyPrecisionForCausalLM(nn.Module):
         captured once per (precision, cache length, sampling) and replayed; the prompt runs eagerly through the same cache."""
         ids, T, max_new = req["ids"].to(self.device), req["T"], req["max_new"]
         total = T + max_new
-        key = ("cap", self.precision, total, req["temperature"], req["top_k"])
+        key = ("cap", self.precision, total, req["temperature"], req["top_k"], req["top_p"])
         st = self._native_cache.get(key)
         # (no_grad, not inference_mode: the first graph capture of a process creates the generator's graph-safe state tensors, and
         # inference tensors could not be updated by the captures that follow outside inference mode)
         with torch.no_grad():
             if st is None:
                 self._evict("cap")  # (the old entry's graph is destroyed HERE, before the new capture begins)
-                st = _CapturedStep(self.model, self.config, self.device, total, req["temperature"], req["top_k"], self._SAMPLER_SEED)
+                st = _CapturedStep(self.model, self.config, self.device, total, req["temperature"], req["top_k"], self._SAMPLER_SEED, req["top_p"])
                 self._native_cache[key] = st
             st.cache.reset()
             st.seq[:T].copy_(ids.view(-1).to(torch.int32))

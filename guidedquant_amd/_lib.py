@@ -23,7 +23,7 @@ EXPORTS = [
     "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows", "gq_anyprec_gemv_fused_ws", "gq_anyprec_gemv_fused_ws_bytes",
     "gq_qtip_linear_out_in", "gq_debug_stream_read", "gq_hop_alloc", "gq_hop_free", "gq_hop_export", "gq_hop_import", "gq_hop_close", "gq_hop_wait_copy",
     "gq_sample_topk_ex", "gq_anyprec_gemv_fused_ho", "gq_ssq_rows", "gq_anyprec_handover_plan", "gq_embed_lookup_ho", "gq_anyprec_gemv_qkv_rope_ho",
-    "gq_anyprec_qkv_rope_attn_supported", "gq_anyprec_gemv_qkv_rope_attn", "gq_hop_is_finegrained",
+    "gq_anyprec_qkv_rope_attn_supported", "gq_anyprec_gemv_qkv_rope_attn", "gq_hop_is_finegrained", "gq_sample_topk_p",
 ]
 ATTN_FLAG_STRIDE = 32  # include/gq_hip.h GQ_ATTN_FLAG_STRIDE
 SSQ_SLOTS = 1024  # include/gq_hip.h GQ_SSQ_SLOTS
@@ -109,6 +109,7 @@ def lib():
         L.gq_dense_gemv_f16.argtypes = [vp, vp, vp, u32, u32, vp, f32, vp]
         L.gq_sample_topk.argtypes = [vp, u32, i32, f32, u32, vp, vp, vp, vp, vp, vp, vp]
         L.gq_sample_topk_ex.argtypes = [vp, u32, i32, f32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, u32, vp, vp]
+        L.gq_sample_topk_p.argtypes = [vp, u32, i32, f32, f32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, u32, vp, vp]
         L.gq_anyprec_gemv_cpu.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, i32, i32]
         L.gq_anyprec_dequant_cpu.argtypes = [vp, vp, vp, u32, u32, i32, i32]
         L.gq_anyprec_gemm.argtypes = [vp, vp, vp, vp, u32, u32, u32, i32, vp]

@@ -658,6 +658,7 @@ struct SampleEx {
     uint16_t *x_out;
     u32 dim, vocab;
     float *ssq_out;
+    float top_p;  // nucleus threshold (round 6: gq_sample_topk_p); >= 1 or <= 0: off
 };
 
 // what both draw kernels do with the token: outputs, token / position feedback, the sequence store
@@ -778,7 +779,34 @@ __global__ void __launch_bounds__(1024) sample_stage2(const float *cand_val, con
         const u32 ctr = (u32)counter[0];
         float score = -3.0e38f;
         int tokc = 0x7FFFFFFF;
-        if ((int)l < n) {
+        // nucleus filter on the top-k survivors -- transformers' TopPLogitsWarper behind TopKLogitsWarper behind the temperature
+        // (generation/logits_process.py: probabilities of the scaled, top-k-filtered scores, cumulative sum in ASCENDING order, a token
+        // goes when the sum up to and including it is <= 1 - top_p, the most probable one always stays).  n <= 64 candidates, one per
+        // lane: the cumulative sum of a lane is a loop over the wave (ties ordered by token id, higher id first = the lower key).
+        bool keep = (int)l < n;
+        if (ex.top_p > 0.f && ex.top_p < 1.f) {
+            const float v = (int)l < n ? selv[l] / T : -3.0e38f;
+            float mx = v;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh, 64));
+            const float e = (int)l < n ? __expf(v - mx) : 0.f;
+            float z = e;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) z += __shfl_xor(z, sh, 64);
+            const float pr = e / z;
+            const int myid = (int)l < n ? seli[l] : -1;
+            float cum = 0.f;
+            int greater = 0;
+            for (int j = 0; j < n; j++) {
+                const float vj = __shfl(v, j, 64), pj = __shfl(pr, j, 64);
+                const int idj = __shfl(myid, j, 64);
+                const bool below = vj < v || (vj == v && idj > myid);  // j sorts before this lane in ascending order
+                cum += (below || j == (int)l) ? pj : 0.f;
+                greater += (vj > v || (vj == v && idj < myid)) ? 1 : 0;
+            }
+            keep = keep && (greater == 0 || !(cum <= 1.0f - ex.top_p));
+        }
+        if (keep) {
             // q ~ Exp(1) = -log(u), u in (0,1]; the random number is tied to the TOKEN id, not to the slot
             const u32 r = hash32(seed ^ hash32(ctr * 0x9E3779B9u + (u32)seli[l] + 1u));
             const float u = ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
@@ -1105,7 +1133,15 @@ extern "C" int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, flo
 extern "C" int gq_sample_topk_ex(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
                                  float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, const int *ban, int *seq_out,
                                  uint32_t seq_cap, const void *embed_table, void *x_out, uint32_t dim, float *ssq_out, void *stream) {
+    return gq_sample_topk_p(logits, vocab, top_k, 1.0f, temperature, seed, counter, work_val, work_idx, tok_io, pos_io, next_tok, ban, seq_out, seq_cap,
+                            embed_table, x_out, dim, ssq_out, stream);
+}
+extern "C" int gq_sample_topk_p(const void *logits, uint32_t vocab, int top_k, float top_p, float temperature, uint32_t seed, int *counter,
+                                float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, const int *ban, int *seq_out,
+                                uint32_t seq_cap, const void *embed_table, void *x_out, uint32_t dim, float *ssq_out, void *stream) {
+    if (!(top_p > 0.f)) return gq_fail(GQ_EINVAL, "top_p must be in (0, 1] (1 = no nucleus filter).");
     SampleEx ex{};
+    ex.top_p = top_p;
     ex.ban = ban;
     ex.seq_out = seq_out;
     ex.seq_cap = seq_cap;

@@ -213,16 +213,17 @@ class DecodeGraph:
                 logits = m.decode_native(self.tok.view(1), self.pos.view(1))
                 emb = xo = so = None
             kw = self.sampling_kwargs
-            _lib.check(_lib.lib().gq_sample_topk_ex(logits.data_ptr(), m.config.vocab_size, int(kw["top_k"]),
-                                                   float(kw.get("temperature", 1.0)), int(self.seed), self.rng_counter.data_ptr(),
+            # (top_p: nucleus filter on the top-k survivors, transformers' warper chain -- 1 = off)
+            _lib.check(_lib.lib().gq_sample_topk_p(logits.data_ptr(), m.config.vocab_size, int(kw["top_k"]), float(kw.get("top_p") or 1.0),
+                                                  float(kw.get("temperature", 1.0)), int(self.seed), self.rng_counter.data_ptr(),
                                                    self.work_val.data_ptr(), self.work_idx.data_ptr(), self.tok.data_ptr(),
                                                    self.pos.data_ptr(), self.next_tok.data_ptr(), self.ban.data_ptr(),
                                                    self.seq.data_ptr() if self.seq is not None else None,
                                                    self.seq.numel() if self.seq is not None else 0, emb, xo, m.config.dim, so,
                                                    _lib.current_stream_ptr()),
-                       "gq_sample_topk_ex")
+                       "gq_sample_topk_p")
             return
-        t, p = decode_one_token(self.model, self.tok, self.pos, **self.sampling_kwargs)
+        t, p = decode_one_token(self.model, self.tok, self.pos, **{k: v for k, v in self.sampling_kwargs.items() if k != "top_p"})
         self.next_tok.copy_(t)
         self.next_prob.copy_(p)
 

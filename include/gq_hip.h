@@ -498,6 +498,13 @@ int gq_sample_topk(const void *logits, uint32_t vocab, int top_k, float temperat
 int gq_sample_topk_ex(const void *logits, uint32_t vocab, int top_k, float temperature, uint32_t seed, int *counter,
                       float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, const int *ban, int *seq_out,
                       uint32_t seq_cap, const void *embed_table, void *x_out, uint32_t dim, float *ssq_out, void *stream);
+/* Round 6: + nucleus (top-p) filtering of the top-k survivors, as transformers chains its warpers (temperature -> TopKLogitsWarper ->
+ * TopPLogitsWarper, generation/logits_process.py): probabilities of the scaled top-k scores, cumulative sum in ascending order, a token
+ * is removed when the sum up to and including it is <= 1 - top_p; the most probable token always stays.  top_p in (0, 1]; 1 = exactly
+ * gq_sample_topk_ex.  What the HF-surface route needs for `generate(do_sample=True, top_p=0.9)` with the default top_k = 50. */
+int gq_sample_topk_p(const void *logits, uint32_t vocab, int top_k, float top_p, float temperature, uint32_t seed, int *counter,
+                     float *work_val, int *work_idx, int *tok_io, int *pos_io, int *next_tok, const int *ban, int *seq_out,
+                     uint32_t seq_cap, const void *embed_table, void *x_out, uint32_t dim, float *ssq_out, void *stream);
 
 /* Test / tuning hooks (not part of the reference's surface).  gq_reset_env_cache: drop the cached GQ_* environment
  * knobs so that a test can flip them between calls.  gq_debug_set_timing_buffer: device buffer the plane kernels write

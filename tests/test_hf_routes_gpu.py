@@ -230,8 +230,65 @@ def test_eos_min_new_tokens_streamer_and_sampling():
     s = m.generate(ids, max_new_tokens=16, do_sample=True, temperature=1.0, top_p=1.0, pad_token_id=0, attention_mask=torch.ones_like(ids),
                    cache_implementation="static")
     assert s.shape == (1, 19) and ("decoder", 2) in m._native_cache
-    # what the fused routes do not serve falls through to transformers (top_p < 1), and native=True then refuses
-    t = m.generate(ids, max_new_tokens=8, do_sample=True, top_p=0.9, pad_token_id=0)
+    # round 6: top_p < 1 on top of the default top_k is served by route 1 too (fused nucleus filter)
+    t = m.generate(ids, max_new_tokens=8, do_sample=True, top_p=0.9, pad_token_id=0, native=True)
+    assert t.shape == (1, 11)
+    # what the fused routes do not serve falls through to transformers (a top_k beyond the sampler's 64 candidates), and native=True then refuses
+    t = m.generate(ids, max_new_tokens=8, do_sample=True, top_k=100, pad_token_id=0)
     assert t.shape[1] <= 11
     with pytest.raises(ValueError):
-        m.generate(ids, max_new_tokens=8, do_sample=True, top_p=0.9, native=True)
+        m.generate(ids, max_new_tokens=8, do_sample=True, top_k=100, native=True)
+
+
+def test_nucleus_filter_of_the_fused_sampler_matches_transformers_warper_chain():
+    """gq_sample_topk_p against TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper of the installed transformers (the chain
+    `generate(do_sample=True, temperature=T, top_k=k, top_p=p)` builds): no token outside the warped support is ever drawn, every token
+    inside is, and the empirical distribution follows the warped probabilities."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    V = 4096
+    g = torch.Generator(device=d)
+    g.manual_seed(3)
+    for k, p, T in ((50, 0.8, 1.0), (64, 0.5, 0.7), (20, 0.95, 1.3), (50, 0.05, 1.0)):
+        logits = (torch.randn(V, device=d, generator=g) * 2.0).half()
+        sc = logits.float().view(1, -1)
+        ids0 = torch.zeros(1, 1, dtype=torch.long, device=d)
+        for wp in (TemperatureLogitsWarper(T), TopKLogitsWarper(k), TopPLogitsWarper(p)):
+            sc = wp(ids0, sc)
+        want = torch.softmax(sc, dim=-1).view(-1).cpu().numpy()
+        support = set(np.nonzero(want > 0)[0].tolist())
+        ctr = torch.zeros(1, dtype=torch.int32, device=d)
+        wv, wi = torch.zeros(128 * 64, dtype=torch.float32, device=d), torch.zeros(128 * 64, dtype=torch.int32, device=d)
+        nt = torch.zeros(1, dtype=torch.int32, device=d)
+        seq = torch.zeros(6001, dtype=torch.int32, device=d)
+        pos = torch.zeros(1, dtype=torch.int32, device=d)
+        tok = torch.zeros(1, dtype=torch.int32, device=d)
+        for _ in range(6000):
+            _lib.check(L.gq_sample_topk_p(logits.data_ptr(), V, k, p, T, 99, ctr.data_ptr(), wv.data_ptr(), wi.data_ptr(), tok.data_ptr(), pos.data_ptr(),
+                                          nt.data_ptr(), None, seq.data_ptr(), seq.numel(), None, None, 0, None, _lib.current_stream_ptr()), "gq_sample_topk_p")
+        torch.cuda.synchronize()
+        draws = seq[1:6001].cpu().numpy()
+        cnt = np.bincount(draws, minlength=V).astype(np.float64) / len(draws)
+        assert set(np.nonzero(cnt)[0].tolist()) <= support, (k, p, T, sorted(set(np.nonzero(cnt)[0].tolist()) - support))
+        assert np.abs(cnt - want).max() < 0.03, (k, p, T, np.abs(cnt - want).max())
+        if len(support) <= 12:  # (a small nucleus: every member shows up)
+            assert set(np.nonzero(cnt)[0].tolist()) == support
+    # top_p = 1 is the old entry point, draw for draw
+    logits = (torch.randn(V, device=d, generator=g) * 2.0).half()
+    outs = []
+    for fn in ("ex", "p"):
+        ctr = torch.zeros(1, dtype=torch.int32, device=d)
+        seq = torch.zeros(65, dtype=torch.int32, device=d)
+        pos = torch.zeros(1, dtype=torch.int32, device=d)
+        for _ in range(64):
+            if fn == "ex":
+                _lib.check(L.gq_sample_topk_ex(logits.data_ptr(), V, 50, 1.0, 7, ctr.data_ptr(), wv.data_ptr(), wi.data_ptr(), tok.data_ptr(), pos.data_ptr(),
+                                               nt.data_ptr(), None, seq.data_ptr(), seq.numel(), None, None, 0, None, _lib.current_stream_ptr()), "ex")
+            else:
+                _lib.check(L.gq_sample_topk_p(logits.data_ptr(), V, 50, 1.0, 1.0, 7, ctr.data_ptr(), wv.data_ptr(), wi.data_ptr(), tok.data_ptr(), pos.data_ptr(),
+                                              nt.data_ptr(), None, seq.data_ptr(), seq.numel(), None, None, 0, None, _lib.current_stream_ptr()), "p")
+        torch.cuda.synchronize()
+        outs.append(seq.clone())
+    assert torch.equal(outs[0], outs[1])

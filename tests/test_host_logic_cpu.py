@@ -375,7 +375,11 @@ def test_generate_routes_the_reference_call_and_declines_the_rest(tmp_path):
     assert req["top_k"] == 1 and req["temperature"] == 0.0 and req["eos"] == [7, 9] and req["min_new"] == 0
     req, _ = m._route_request((ids, ), dict(max_length=10))
     assert req["max_new"] == 7
-    for kw in (dict(max_new_tokens=4, do_sample=True, top_p=0.9), dict(max_new_tokens=4, num_beams=2), dict(max_new_tokens=4, do_sample=True, top_k=100),
+    # round 6: a nucleus on top of top-k <= 64 is served (transformers' warper chain); on top of no top-k it is not
+    req, why = m._route_request((ids, ), dict(max_new_tokens=4, do_sample=True, top_p=0.9))
+    assert why is None and req["top_p"] == 0.9 and req["top_k"] == 50
+    for kw in (dict(max_new_tokens=4, do_sample=True, top_p=0.9, top_k=100), dict(max_new_tokens=4, do_sample=True, top_p=0.0),
+               dict(max_new_tokens=4, num_beams=2), dict(max_new_tokens=4, do_sample=True, top_k=100),
                dict(max_new_tokens=4, repetition_penalty=1.2), dict(max_new_tokens=4, logits_processor=[]), dict(max_new_tokens=4, eos_token_id=[1, 2, 3, 4, 5]),
                dict(max_new_tokens=4, attention_mask=torch.tensor([[0, 1, 1]])), dict(), dict(max_new_tokens=0)):
         req, why = m._route_request((ids, ), kw)

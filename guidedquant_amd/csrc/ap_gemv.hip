@@ -19,6 +19,8 @@
 
 using namespace gq;
 
+unsigned long long *gq_debug_timing_buffer();  // ap_plane.hip (gq_debug_set_timing_buffer)
+
 namespace {
 
 struct ApArgs {
@@ -616,6 +618,7 @@ struct DqArgs {
     u32 RGB;      // 16-row groups per block
     u32 NU;       // units (512 weights) per row
     u32 part_off; // LDS offset of the partial sums
+    unsigned long long *dbg;  // GQ_STAMPS builds: the debug buffer of gq_debug_set_timing_buffer
 };
 #ifndef DQ_WAVES_N
 #define DQ_WAVES_N 16
@@ -629,6 +632,9 @@ constexpr u32 DQ_WAVES = DQ_WAVES_N;
 // ~600 instructions (5 KB) already, and every slot of a ring is another copy of it in the instruction cache
 #ifndef DQ_RING
 #define DQ_RING 1
+#endif
+#ifndef DQ_KO
+#define DQ_KO 0  // build-time knock-outs, WRONG numerics, timing only (bit mask): 1 no B reads, 2 no MFMAs, 4 no plane loads
 #endif
 // occupancy the instances are compiled for (waves per SIMD): the decode is a dependent chain (transpose -> selectors -> look-ups ->
 // MFMA), so more resident waves = fewer idle issue slots
@@ -669,7 +675,7 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
     auto issue = [&](int d, u32 it) {
         const u32 rgl = it / NU, u = it - rgl * NU;
         const u32 row = (rg0 + rgl) * 16u + r;
-        const bool ok = it < nitems && row < a.N;
+        const bool ok = it < nitems && row < a.N && !(DQ_KO & 4);  // (knock-out 4: no plane loads)
         const u32 off = ok ? (row * G.wpr + 4u * (4u * u + g)) * 4u : OOB;
 #pragma unroll
         for (int p = 0; p < BITS; p++) P[d][p] = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? off + (u32)p * plane_bytes : OOB, 0, 2 /* nt */);
@@ -712,18 +718,35 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         DqItem<BITS>::run(Pw, L, [&](int c, int jj, u32 a01, u32 a23, u32 b01, u32 b23) {
             const u32x4 av = {a01, a23, b01, b23};
+#if DQ_KO & 1  // (timing knock-out, WRONG numerics: no B reads)
+            const u32x4 bvv = {(u32)c, (u32)jj, q, Q};
+#else
             const uint4 bv = *reinterpret_cast<const uint4 *>(bb + (size_t)((u32)(c * 4 + jj) * Q) * 16u);
             const u32x4 bvv = {bv.x, bv.y, bv.z, bv.w};
+#endif
+#if DQ_KO & 2  // (no MFMAs)
+            acc0[0] += __builtin_bit_cast(float, av[0] ^ av[1] ^ av[2] ^ av[3] ^ bvv[0]);
+#else
             if (jj & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bvv), acc0, 0, 0, 0);
+#endif
         });
         // D[row 4 g + e][column r]: column 0 holds the sums
         if (r == 0u) *reinterpret_cast<f32x4 *>(part + (size_t)it * 16u + 4u * g) = acc0 + acc1;
     };
+    // (GQ_STAMPS builds: s_memrealtime per wave of the middle block -- kernel start, then per item {top, plane words in hand, next item
+    // requested, decoded}: tools/r6/dq_stamps.py)
+    unsigned long long *dqdbg = (GQ_STAMPS && da.dbg && blockIdx.x == gridDim.x / 2u && l == 0u) ? da.dbg + (size_t)w * 32u : nullptr;
+    u32 nst = 0;
+    auto dstamp = [&]() {
+        if (GQ_STAMPS && dqdbg && nst < 32u) dqdbg[nst++] = __builtin_amdgcn_s_memrealtime();
+    };
+    dstamp();
     for (u32 it0 = w; it0 < nitems; it0 += (u32)D * DQ_WAVES) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const u32 it = it0 + (u32)d * DQ_WAVES;
+            dstamp();
             u32 Pw[BITS][4];
 #pragma unroll
             for (int p = 0; p < BITS; p++) {
@@ -735,9 +758,16 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
             u32 lw[NRAW];
 #pragma unroll
             for (int i = 0; i < NRAW; i++) lw[i] = lraw[d][i];
+            if (GQ_STAMPS) {
+#pragma unroll
+                for (int p = 0; p < BITS; p++) asm volatile("" : "+v"(Pw[p][0]), "+v"(Pw[p][3]));  // (the wait for the plane words sits here)
+                dstamp();
+            }
             issue(d, it + (u32)D * DQ_WAVES);
+            if (GQ_STAMPS) dstamp();
             if (it >= nitems) continue;  // (wave-uniform)
             decode_item(it, Pw, lw);
+            if (GQ_STAMPS) dstamp();
         }
     }
     __syncthreads();
@@ -806,7 +836,7 @@ int dq_gemv_try(const ApArgs &a, u32 M, int bits, int pro, hipStream_t s) {
     if ((uint64_t)bits * a.N * (a.K / 8u) >= 0x7FFFFFFFull) return GQ_ENOTSUP;
     if ((((uintptr_t)a.qw | (uintptr_t)a.x | (uintptr_t)a.normw | (uintptr_t)a.lut) & 15u) != 0) return GQ_ENOTSUP;
     if ((a.epilogue & GQ_EPI_SILU_PAIRS) && (a.N & 1u)) return GQ_ENOTSUP;
-    DqArgs da{a, c.RGB, c.NU, c.part_off};
+    DqArgs da{a, c.RGB, c.NU, c.part_off, GQ_STAMPS ? gq_debug_timing_buffer() : nullptr};
     switch (bits) {
         case 2: return launch_dq<2>(da, c, pro, s);
         case 3: return launch_dq<3>(da, c, pro, s);

@@ -481,3 +481,19 @@ def test_converted_checkpoint_route_on_the_host(tmp_path):
     with torch.no_grad():
         lg = m(torch.tensor([[3, 9, 250]], dtype=torch.int32), torch.arange(3, dtype=torch.int32))
     assert lg.shape == (1, 3, c["V"]) and torch.isfinite(lg.float()).all()
+
+
+def test_bench_side_legs_cannot_take_the_line_with_them():
+    """bench.py (round 6): every side leg of the line runs in a child process; a leg that dies, prints nothing or hangs becomes an
+    error record in its place (round 5's driver run lost the whole line to an abort in its ninth leg)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rec = bench.run_leg_child("no_such_leg", [], 120)          # the child ends with an error (no GPU here / unknown leg): rc != 0
+    assert set(rec) >= {"error"} and rec["error"].startswith("rc ")
+    rec = bench.run_leg_child("no_such_leg", [], 0.05)          # ... or does not finish in time
+    assert rec == {"error": "timed out after 0 s"}
+    # the legs of the N = 1 line: the three records of the contract outside other_configs, then the other BASELINE configs
+    keys = [k for k, _, _, _ in bench.LEGS]
+    assert keys[:3] == ["cpu_baseline", "roofline_by_shape", "exact_mode"] and len(keys) == 11
+    assert {g for _, g, _, _ in bench.LEGS} == {None, "other_configs"}

@@ -535,23 +535,24 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int BITS>
-struct DqItem;  // run(P, L, emit): emit(c, jj, w01 @ 2 jj, w23 @ 2 jj, w01 @ 2 jj + 1, w23 @ 2 jj + 1) for c = 3..0, jj = 0..3
+struct DqItem;  // run(P, L, emit): emit(v, k, w01 @ 2 k, w23 @ 2 k, w01 @ 2 k + 1, w23 @ 2 k + 1) for word v = 0..3, pair k = 0..3
+// NO byte transpose of the quad (ap_core.h::transpose_quad, 8 v_perm per plane): the exact kernels need it to keep the reference's
+// chain order, a matrix-core product does not care which 8 weights share an operand.  A selector taken from ONE word holds the codes
+// of the same bit position j of its four bytes c = 3, 2, 1, 0 (byte 0 = c 3: pack.py's byte order); the look-up returns
+// w01 = (w[c3], w[c2]), w23 = (w[c1], w[c0]) at that j -- the activation image (stage_x_dqv) keeps the matching order.
 template <>
 struct DqItem<2> {
     template <typename E>
     __device__ __forceinline__ static void run(const u32 P[2][4], const LutPools<2> &L, E emit) {
-        u32 H[4], Lo[4];
-        transpose_quad(P[0], H);
-        transpose_quad(P[1], Lo);
 #pragma unroll
-        for (int c = 3; c >= 0; c--) {
-            const u32 Cm = bfi(0xAAAAAAAAu, H[c], Lo[c] >> 1), Dm = bfi(0xAAAAAAAAu, H[c] << 1, Lo[c]);
+        for (int v = 0; v < 4; v++) {
+            const u32 Cm = bfi(0xAAAAAAAAu, P[0][v], P[1][v] >> 1), Dm = bfi(0xAAAAAAAAu, P[0][v] << 1, P[1][v]);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 u32 a01, a23, b01, b23;
                 lookup4<2>(L, (Cm >> (6 - 2 * k)) & 0x03030303u, 0u, a01, a23);
                 lookup4<2>(L, (Dm >> (6 - 2 * k)) & 0x03030303u, 0u, b01, b23);
-                emit(c, k, a01, a23, b01, b23);
+                emit(v, k, a01, a23, b01, b23);
             }
         }
     }
@@ -560,15 +561,11 @@ template <>
 struct DqItem<3> {
     template <typename E>
     __device__ __forceinline__ static void run(const u32 P[3][4], const LutPools<3> &L, E emit) {
-        u32 T0[4], T1[4], T2[4];
-        transpose_quad(P[0], T0);
-        transpose_quad(P[1], T1);
-        transpose_quad(P[2], T2);
 #pragma unroll
-        for (int c = 3; c >= 0; c--) {
+        for (int v = 0; v < 4; v++) {
             u32 nib[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) nib[r] = bfi(0x44444444u, shl(T0[c], 2 - r), bfi(0x22222222u, shl(T1[c], 1 - r), T2[c] >> r));
+            for (int r = 0; r < 4; r++) nib[r] = bfi(0x44444444u, shl(P[0][v], 2 - r), bfi(0x22222222u, shl(P[1][v], 1 - r), P[2][v] >> r));
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 u32 w[2][2];
@@ -578,7 +575,7 @@ struct DqItem<3> {
                     const u32 S = ((s & 4) ? (nib[s & 3] >> 4) : nib[s & 3]) & 0x07070707u;
                     lookup4<3>(L, S, 0u, w[par][0], w[par][1]);
                 }
-                emit(c, k, w[0][0], w[0][1], w[1][0], w[1][1]);
+                emit(v, k, w[0][0], w[0][1], w[1][0], w[1][1]);
             }
         }
     }
@@ -587,16 +584,11 @@ template <>
 struct DqItem<4> {
     template <typename E>
     __device__ __forceinline__ static void run(const u32 P[4][4], const LutPools<4> &L, E emit) {
-        u32 T0[4], T1[4], T2[4], T3[4];
-        transpose_quad(P[0], T0);
-        transpose_quad(P[1], T1);
-        transpose_quad(P[2], T2);
-        transpose_quad(P[3], T3);
 #pragma unroll
-        for (int c = 3; c >= 0; c--) {
+        for (int v = 0; v < 4; v++) {
             u32 nib[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) nib[r] = bfi(0x44444444u, shl(T1[c], 2 - r), bfi(0x22222222u, shl(T2[c], 1 - r), T3[c] >> r));
+            for (int r = 0; r < 4; r++) nib[r] = bfi(0x44444444u, shl(P[1][v], 2 - r), bfi(0x22222222u, shl(P[2][v], 1 - r), P[3][v] >> r));
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 u32 w[2][2];
@@ -604,14 +596,104 @@ struct DqItem<4> {
                 for (int par = 0; par < 2; par++) {
                     const int s = 7 - (2 * k + par);
                     const u32 S = ((s & 4) ? (nib[s & 3] >> 4) : nib[s & 3]) & 0x07070707u;
-                    const u32 msel = ((T0[c] >> s) & 0x01010101u) | 0x0C0C0C0Cu;
+                    const u32 msel = ((P[0][v] >> s) & 0x01010101u) | 0x0C0C0C0Cu;
                     lookup4<4>(L, S, msel, w[par][0], w[par][1]);
                 }
-                emit(c, k, w[0][0], w[0][1], w[1][0], w[1][1]);
+                emit(v, k, w[0][0], w[0][1], w[1][0], w[1][1]);
             }
         }
     }
 };
+
+// The activation image of the dq kernel: 16-byte slot (v * 4 + k) * Q + q = the 8 activations that meet the A operand of (quad q,
+// word v, pair k): [x(c3, 2k), x(c2, 2k), x(c1, 2k), x(c0, 2k), x(c3, 2k+1), x(c2, 2k+1), x(c1, 2k+1), x(c0, 2k+1)], x(c, j) =
+// x[G.xindex(q, v, c, j)].  Work item = (quad q, word v): four 16-byte loads (one per byte c), four v_perm per slot.  Prologues as stage_x.
+template <int PRO>
+__device__ __forceinline__ void stage_x_dqv(const RowGeom &G, const uint16_t *x, const uint16_t *normw, float eps, uint16_t *xlds, float *red, bool stager,
+                                            u32 T) {
+    const u32 tid = threadIdx.x;
+    float scale = 0.f;
+    const u32 idx0 = stager ? tid : 4u * G.Q;
+    // (K % 1024 == 0 for this kernel: whole chunks only -- item idx = (quad q = idx / 4, word v = idx % 4) starts at activation
+    // 1024 (q / 8) + 8 (4 (q % 8) + v) = 1024 (idx / 32) + 8 (idx % 32); byte c adds 256)
+    auto xbase = [](u32 idx) -> u32 { return 1024u * (idx >> 5) + 8u * (idx & 31u); };
+    // RMSNorm in ONE memory round trip (as stage_x): the activations AND the norm weights of a thread's first item are requested up front,
+    // the sum of squares is taken from those registers, and they are normalised behind the barrier without being read again
+    u32 in0[4][4], nw0[4][4];
+    if constexpr (PRO == PRO_RMSNORM) {
+        float ss = 0.f;
+        for (u32 idx = idx0; idx < 4u * G.Q; idx += T) {
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 e0 = xbase(idx) + 256u * c;
+                const uint4 t4 = ld16(x + e0);
+                const u32 w[4] = {t4.x, t4.y, t4.z, t4.w};
+                if (idx == idx0) {
+                    const uint4 n4 = ld16(normw + e0);
+                    in0[c][0] = t4.x, in0[c][1] = t4.y, in0[c][2] = t4.z, in0[c][3] = t4.w;
+                    nw0[c][0] = n4.x, nw0[c][1] = n4.y, nw0[c][2] = n4.z, nw0[c][3] = n4.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float a = h2f(w[i] & 0xFFFF), b = h2f(w[i] >> 16);
+                    ss += a * a;
+                    ss += b * b;
+                }
+            }
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        if ((tid & 63u) == 0 && stager) red[tid >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
+        scale = 1.0f / sqrtf(tot / (float)G.K + eps);
+    }
+    for (u32 idx = idx0; idx < 4u * G.Q; idx += T) {
+        const u32 q = idx >> 2, v = idx & 3u;
+        u32 in[4][4];  // [c][k]: (x(c, 2k), x(c, 2k+1))
+#pragma unroll
+        for (u32 c = 0; c < 4; c++) {
+            const u32 e0 = xbase(idx) + 256u * c;
+            if constexpr (PRO == PRO_RMSNORM) {
+                u32 nw[4];
+                if (idx == idx0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) in[c][i] = in0[c][i], nw[i] = nw0[c][i];
+                } else {
+                    const uint4 t4 = ld16(x + e0), n4 = ld16(normw + e0);
+                    in[c][0] = t4.x, in[c][1] = t4.y, in[c][2] = t4.z, in[c][3] = t4.w;
+                    nw[0] = n4.x, nw[1] = n4.y, nw[2] = n4.z, nw[3] = n4.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint16_t a = f2h(gq_pin_f32(h2f(in[c][i] & 0xFFFF) * scale)), b = f2h(gq_pin_f32(h2f(in[c][i] >> 16) * scale));
+                    const _Float16 ra = __builtin_bit_cast(_Float16, a) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] & 0xFFFF));
+                    const _Float16 rb = __builtin_bit_cast(_Float16, b) * __builtin_bit_cast(_Float16, (uint16_t)(nw[i] >> 16));
+                    in[c][i] = (u32)__builtin_bit_cast(uint16_t, ra) | ((u32)__builtin_bit_cast(uint16_t, rb) << 16);
+                }
+            } else {
+                const uint4 t4 = ld16(x + e0);
+                in[c][0] = t4.x, in[c][1] = t4.y, in[c][2] = t4.z, in[c][3] = t4.w;
+                if constexpr (PRO == PRO_SILUMUL) {
+                    const uint4 u4 = ld16(x + G.K + e0);
+                    const u32 uw[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) in[c][i] = silu_mul_pk(in[c][i], uw[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            uint4 o;
+            o.x = perm(in[2][k], in[3][k], 0x05040100u);  // (x(c3, 2k), x(c2, 2k))
+            o.y = perm(in[0][k], in[1][k], 0x05040100u);  // (x(c1, 2k), x(c0, 2k))
+            o.z = perm(in[2][k], in[3][k], 0x07060302u);  // (x(c3, 2k+1), x(c2, 2k+1))
+            o.w = perm(in[0][k], in[1][k], 0x07060302u);  // (x(c1, 2k+1), x(c0, 2k+1))
+            *reinterpret_cast<uint4 *>(xlds + (((v * 4u + k) * G.Q + q) << 3)) = o;
+        }
+    }
+}
 
 struct DqArgs {
     ApArgs a;
@@ -703,7 +785,7 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
     // memory pipe serves requests in order)
     const bool stager = DQ_WAVES < 2u || w < DQ_WAVES / 2u;
     if (!stager) first_requests();
-    stage_x<PRO>(G, a.x, a.normw, a.eps, xlds, red, stager, (DQ_WAVES < 2u ? 1u : DQ_WAVES / 2u) * 64u);
+    stage_x_dqv<PRO>(G, a.x, a.normw, a.eps, xlds, red, stager, (DQ_WAVES < 2u ? 1u : DQ_WAVES / 2u) * 64u);
     if (stager) first_requests();
     __syncthreads();
     // B fragments: column 0 reads the image, the other columns read zeros from beyond the block's LDS allocation (192 KiB up)
@@ -716,12 +798,12 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
         const unsigned char *bb = r == 0u ? reinterpret_cast<const unsigned char *>(xlds) + (size_t)q * 16u
                                           : reinterpret_cast<const unsigned char *>(smem) + 0x30000u;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        DqItem<BITS>::run(Pw, L, [&](int c, int jj, u32 a01, u32 a23, u32 b01, u32 b23) {
+        DqItem<BITS>::run(Pw, L, [&](int v, int jj, u32 a01, u32 a23, u32 b01, u32 b23) {
             const u32x4 av = {a01, a23, b01, b23};
 #if DQ_KO & 1  // (timing knock-out, WRONG numerics: no B reads)
-            const u32x4 bvv = {(u32)c, (u32)jj, q, Q};
+            const u32x4 bvv = {(u32)v, (u32)jj, q, Q};
 #else
-            const uint4 bv = *reinterpret_cast<const uint4 *>(bb + (size_t)((u32)(c * 4 + jj) * Q) * 16u);
+            const uint4 bv = *reinterpret_cast<const uint4 *>(bb + (size_t)((u32)(v * 4 + jj) * Q) * 16u);
             const u32x4 bvv = {bv.x, bv.y, bv.z, bv.w};
 #endif
 #if DQ_KO & 2  // (no MFMAs)
@@ -1163,16 +1245,17 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
     const int def_min = local ? 16 : ((bits == 2 || pro == PRO_RMSNORM) ? 20 : 32);
     const uint64_t min_w = (uint64_t)(env_min >= 0 ? env_min : def_min) * 1000000ull;
     const int max_bits = gq_env_int("GQ_PL_MAX_BITS", 4);
-    // round 6: decode-to-fp16 on the matrix cores (ap_gemv_dq_kernel) where it measured faster than the plane kernels
-    // (profiles/r06_dq_kernel.txt, 8B shapes, decode-graph launch forms): at 4 bits the matrices of >= 20 M weights -- wqkv 9.5 vs 10.3 us,
-    // w1w3 23.2 vs 24.4, w2 14.2 vs 15.0 (wo, 16 M: 7.7 vs 6.7, stays) --, at 3 bits the RMSNorm launches below 32 M weights (wqkv 6.9
-    // vs 7.2; w1w3 16.3 vs 14.9 and w2 10.1 vs 9.4 stay), never at 2 bits (w1w3 13.5 vs 8.5).  GQ_DQ: bit mask of the widths it may take
-    // (bit b - 2; 0 = never), GQ_DQ_MIN_MWEIGHTS >= 0: every matrix of at least that many million weights at those widths.
+    // round 6: decode-to-fp16 on the matrix cores (ap_gemv_dq_kernel) where it measured faster than the other kernels
+    // (profiles/r06_dq_kernel.txt, 8B shapes, decode-graph launch forms, same box): at 4 bits every matrix of >= 16 M weights -- wqkv 9.1
+    // vs 10.3 us, wo 6.6 vs 6.8 (exact kernel), w1w3 22.9 vs 24.4, w2 13.9 vs 15.0 --, at 3 bits the matrices of 16 .. 32 M weights (wqkv
+    // 6.6 vs 7.2, wo 5.0 vs 5.3; w1w3 15.6 vs 14.7 and w2 9.6 vs 9.4 stay on the plane kernel), never at 2 bits (w1w3 11.6 vs 8.5).
+    // GQ_DQ: bit mask of the widths it may take (bit b - 2; 0 = never), GQ_DQ_MIN_MWEIGHTS >= 0: every matrix of at least that many
+    // million weights at those widths.
     {
         const int dq_mask = gq_env_int("GQ_DQ", GQ_DQ_DEFAULT), dq_min = gq_env_int("GQ_DQ_MIN_MWEIGHTS", -1);
         const uint64_t nk = (uint64_t)a.N * a.K;
         const bool dq_shape = dq_min >= 0 ? nk >= (uint64_t)dq_min * 1000000ull
-                                          : (bits == 4 ? nk >= 20000000ull : (bits == 3 && pro == PRO_RMSNORM && nk >= 20000000ull && nk < 32000000ull));
+                                          : (bits == 4 ? nk >= 16000000ull : (bits == 3 && nk >= 16000000ull && nk < 32000000ull));
         if (!force_generic && !exact_mode() && bits <= 4 && ((dq_mask >> (bits - 2)) & 1) && dq_shape && !(ho && ho->dry)) {
             const int rc = dq_gemv_try(a, M, bits, pro, s);
             if (rc != GQ_ENOTSUP) return rc;

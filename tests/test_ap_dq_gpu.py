@@ -77,11 +77,11 @@ def test_dq_kernel_silu_prologue(oracle, bits):
 
 def test_default_dispatch_sends_the_large_4_bit_matrices_here_and_nothing_at_2_bits(oracle):
     """the same launch with the kernel switched off (GQ_DQ=0) runs the plane kernel: other summation order, so the two fast-mode results
-    differ in the last bits for a 4-bit 25 M-weight matrix under the default dispatch -- and are identical where the default does not use it"""
+    differ in the last bits for a 4-bit 25 M-weight (and a 3-bit 16 M-weight) matrix under the default dispatch -- and are identical where the default does not use it"""
     from guidedquant_amd import _lib
     L = _lib.lib()
     res = {}
-    for bits, N, K in ((4, 6144, 4096), (2, 6144, 4096), (4, 4096, 4096)):
+    for bits, N, K in ((4, 6144, 4096), (2, 6144, 4096), (4, 2048, 4096), (3, 4096, 4096)):
         rng, q, lut = _layer(N, K, bits, 5 + bits + N)
         x = rng.normal(0, 1, K).astype(np.float16)
         for dq in (None, "0"):
@@ -92,8 +92,9 @@ def test_default_dispatch_sends_the_large_4_bit_matrices_here_and_nothing_at_2_b
                 os.environ["GQ_DQ"] = dq
             L.gq_reset_env_cache()
             res[(bits, N, dq)] = run_fused(x, q, lut, bits)
-        if N * K >= 20e6:  # (the 16 M-weight 4-bit matrix runs the exact-order kernel under the default dispatch: another envelope)
+        if N * K >= 16e6:  # (the 8 M-weight 4-bit matrix runs the exact-order kernel under the default dispatch: another envelope)
             _check_fast(res[(bits, N, None)], x, q, lut, bits, oracle, rows=_rows(rng, N))
     assert not np.array_equal(res[(4, 6144, None)].view(np.uint16), res[(4, 6144, "0")].view(np.uint16))
     assert np.array_equal(res[(2, 6144, None)].view(np.uint16), res[(2, 6144, "0")].view(np.uint16))
-    assert np.array_equal(res[(4, 4096, None)].view(np.uint16), res[(4, 4096, "0")].view(np.uint16))
+    assert np.array_equal(res[(4, 2048, None)].view(np.uint16), res[(4, 2048, "0")].view(np.uint16))
+    assert not np.array_equal(res[(3, 4096, None)].view(np.uint16), res[(3, 4096, "0")].view(np.uint16))  # (3-bit wo: here since round 6)

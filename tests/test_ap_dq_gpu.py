@@ -41,8 +41,9 @@ def _rows(rng, N, n=48):
     return np.unique(np.concatenate([np.arange(0, min(24, N)), np.arange(max(0, N - 24), N), rng.integers(0, N, n)]))
 
 
-# 8B wqkv / wo / w1w3 / w2, a 1B width, a 70B width, ragged row counts (the last 16-row group partly / almost empty)
-SHAPES = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (3072, 2048), (10240, 8192), (1000, 4096), (4097, 1024)]
+# 8B wqkv / wo / w1w3 / w2, a 1B width, a 70B width, ragged row counts (the last 16-row group partly / almost empty), the 70B down
+# projection's width (more staging items than staging threads: the re-read path of stage_x_dqv)
+SHAPES = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (3072, 2048), (10240, 8192), (1000, 4096), (4097, 1024), (520, 28672)]
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])

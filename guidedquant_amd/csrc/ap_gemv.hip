@@ -514,20 +514,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) a
 // The plane-MFMA kernels (ap_plane.hip / ap_stream.hip) multiply 2^b - 1 BINARY matrices per b-bit LUT: 3 at 2 bits, 7 at 3, 15
 // at 4 -- 24 / 56 / 120 FP4 x BF8 MFMAs of 32 cycles per 16 rows x 1024 weights, with ~8 VALU instructions per MFMA to build the
 // operands: at 4 bits ~1,040 instructions per block, instruction-issue-bound at 2.3 x the matrix floor (w1w3 24 us, 0.30 of the
-// HBM roofline).  The decode of the exact kernels (ap_core.h: plane bytes transposed across the 4 words of a quad, v_perm_b32
-// look-ups in the row's LUT held as VGPR byte pools) grows far more slowly with b -- 1.75 / 2.2 / 4.2 VALU operations per weight --
-// and what it yields, packed fp16 pairs (w_v0, w_v1), (w_v2, w_v3) of the four words of a quad at one bit position, IS an A
-// fragment of v_mfma_f32_16x16x32_f16: lane (row r = l % 16, quad g = l / 16) holds 8 weights of row r, and the K index of a
-// matrix-core product is only a label -- any 8 weights do, as long as the B fragment of lane (column, g) holds the 8 activations
-// that belong to them.  Those are exactly one 16-byte slot of the lane-linear activation image the exact kernels stage in LDS
-// (ap_core.h::xlds_pos: [(v0, v1) @ j, (v2, v3) @ j, (v0, v1) @ j + 1, (v2, v3) @ j + 1] of (quad, byte c, j / 2)).  So:
+// HBM roofline).  The decode of the exact kernels (ap_core.h: v_perm_b32 look-ups in the row's LUT held as VGPR byte pools) grows far
+// more slowly with b -- 1.6 / 2.2 / 3.9 VALU operations per weight -- and what it yields, packed fp16 pairs of four weights at one bit
+// position, IS an A fragment of v_mfma_f32_16x16x32_f16: lane (row r = l % 16, quad g = l / 16) holds 8 weights of row r, and the K
+// index of a matrix-core product is only a label -- any 8 weights do, as long as the B fragment of lane (column, g) holds the 8
+// activations that belong to them: one 16-byte slot of an activation image staged in LDS in the decode's own order (the first version
+// used the exact kernels' image, ap_core.h::xlds_pos, and their byte transpose of the quad; the second -- DqItem / stage_x_dqv below --
+// drops the transpose: profiles/r06_dq_kernel.txt).  So:
 //   * A = two look-ups (4 VGPRs), B = one ds_read_b128 of the staged image (column 0 reads it, columns 1..15 read zeros from
 //     outside the block's LDS allocation -- idle columns fed real data cost 8 % in clocks), one MFMA
 //     of 16 cycles per 16 rows x 32 weights: 32 per 16 x 1024 block instead of 56 / 120, no bf8 pieces, no image build, no
 //     extraction of large activations, no Moebius coefficients;
 //   * products of fp16 values are exact in the fp32 accumulator, sums in fp32, one fp16 rounding: the fast-mode envelope
 //     (tests/ap_helpers.py::_check_fast) -- not the reference's fp16 accumulation order (that is the exact mode);
-//   * prologues (RMSNorm, SiLU * up) are stage_x's, with the reference's rounding points; plain / residual / gate-up pair epilogues.
+//   * prologues (RMSNorm, SiLU * up) as stage_x has them, with the reference's rounding points; plain / residual / gate-up pair epilogues.
 // Work: item = (16-row group, unit of 4 quads = 512 weights per row); wave w of a 16-wave block takes items w, w + 16, ..; the
 // K-split partial sums of a row group meet in LDS and are added in unit order (deterministic).
 // ----------------------------------------------------------------------------------------------

@@ -731,7 +731,9 @@ constexpr u32 DQ_WAVES = DQ_WAVES_N;
 template <int BITS>
 constexpr int dq_wpe() { return BITS <= 3 ? DQ_WPE3 : DQ_WPE4; }
 
-template <int BITS, int PRO>
+// QT: quads per row compiled in (32: K = 4096, 112: K = 14336 -- the 8B widths; 0: read from the launch): the sixteen B-fragment
+// addresses of an item are then immediate offsets of ONE base register instead of sixteen v_add (7 % of the 3-bit item's VALU)
+template <int BITS, int PRO, int QT>
 __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per_eu(dq_wpe<BITS>()))) ap_gemv_dq_kernel(DqArgs da) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ApArgs &a = da.a;
@@ -789,7 +791,7 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
     if (stager) first_requests();
     __syncthreads();
     // B fragments: column 0 reads the image, the other columns read zeros from beyond the block's LDS allocation (192 KiB up)
-    const u32 Q = G.Q;
+    const u32 Q = QT ? (u32)QT : G.Q;
     auto decode_item = [&](u32 it, const u32 (&Pw)[BITS][4], const u32 (&lw)[NRAW]) {
         LutPools<BITS> L;
         L.build(lw);
@@ -894,14 +896,22 @@ bool pick_dq_cfg(u32 N, u32 K, int bits, DqCfg &c) {
     c.smem = (size_t)c.part_off + (size_t)c.RGB * c.NU * 64u + 64u;
     return c.smem <= 150u * 1024u;
 }
-template <int BITS, int PRO>
-int launch_dq_inst(const DqArgs &da, const DqCfg &c, hipStream_t s) {
+template <int BITS, int PRO, int QT>
+int launch_dq_q(const DqArgs &da, const DqCfg &c, hipStream_t s) {
     static GqPerDeviceOnce once;
-    auto kern = ap_gemv_dq_kernel<BITS, PRO>;
+    auto kern = ap_gemv_dq_kernel<BITS, PRO, QT>;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     hipLaunchKernelGGL(kern, dim3(c.grid), dim3(64u * DQ_WAVES), c.smem, s, da);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
+}
+template <int BITS, int PRO>
+int launch_dq_inst(const DqArgs &da, const DqCfg &c, hipStream_t s) {
+    switch (da.a.K) {
+        case 4096u: return launch_dq_q<BITS, PRO, 32>(da, c, s);
+        case 14336u: return launch_dq_q<BITS, PRO, 112>(da, c, s);
+        default: return launch_dq_q<BITS, PRO, 0>(da, c, s);
+    }
 }
 template <int BITS>
 int launch_dq(const DqArgs &da, const DqCfg &c, int pro, hipStream_t s) {
@@ -1248,14 +1258,17 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
     // round 6: decode-to-fp16 on the matrix cores (ap_gemv_dq_kernel) where it measured faster than the other kernels
     // (profiles/r06_dq_kernel.txt, 8B shapes, decode-graph launch forms, same box): at 4 bits every matrix of >= 16 M weights -- wqkv 9.1
     // vs 10.3 us, wo 6.6 vs 6.8 (exact kernel), w1w3 22.9 vs 24.4, w2 13.9 vs 15.0 --, at 3 bits the matrices of 16 .. 32 M weights (wqkv
-    // 6.6 vs 7.2, wo 5.0 vs 5.3; w1w3 15.6 vs 14.7 and w2 9.6 vs 9.4 stay on the plane kernel), never at 2 bits (w1w3 11.6 vs 8.5).
+    // 6.5 vs 7.2, wo 4.9 vs 5.3) and the long-row launches without the RMSNorm prologue below 100 M (w2 9.35 vs 9.65; w1w3 15.3 vs 14.8
+    // stays on the plane kernel), never at 2 bits (w1w3 11.6 vs 8.5).
     // GQ_DQ: bit mask of the widths it may take (bit b - 2; 0 = never), GQ_DQ_MIN_MWEIGHTS >= 0: every matrix of at least that many
     // million weights at those widths.
     {
         const int dq_mask = gq_env_int("GQ_DQ", GQ_DQ_DEFAULT), dq_min = gq_env_int("GQ_DQ_MIN_MWEIGHTS", -1);
         const uint64_t nk = (uint64_t)a.N * a.K;
         const bool dq_shape = dq_min >= 0 ? nk >= (uint64_t)dq_min * 1000000ull
-                                          : (bits == 4 ? nk >= 16000000ull : (bits == 3 && nk >= 16000000ull && nk < 32000000ull));
+                                          : (bits == 4 ? nk >= 16000000ull
+                                                       : (bits == 3 && nk >= 16000000ull &&
+                                                          (nk < 32000000ull || (pro != PRO_RMSNORM && a.K >= 8192u && nk < 100000000ull))));
         if (!force_generic && !exact_mode() && bits <= 4 && ((dq_mask >> (bits - 2)) & 1) && dq_shape && !(ho && ho->dry)) {
             const int rc = dq_gemv_try(a, M, bits, pro, s);
             if (rc != GQ_ENOTSUP) return rc;

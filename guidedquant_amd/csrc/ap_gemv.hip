@@ -596,8 +596,15 @@ struct DqItem<4> {
                 for (int par = 0; par < 2; par++) {
                     const int s = 7 - (2 * k + par);
                     const u32 S = ((s & 4) ? (nib[s & 3] >> 4) : nib[s & 3]) & 0x07070707u;
-                    const u32 msel = ((P[0][v] >> s) & 0x01010101u) | 0x0C0C0C0Cu;
-                    lookup4<4>(L, S, msel, w[par][0], w[par][1]);
+                    // the MSB plane picks the pool: 0x00 / 0xFF per byte as x * 255 = (x << 8) - x (mod 2^32: exact for bytes of 0 / 1) -- two
+                    // VOP2 operations instead of ap_core.h's selector OR + v_perm.  (A 24-bit multiply by 255 is one operation and WRONG: it
+                    // drops byte 3 -- 531 tokens/s and 11 failed tests.)
+                    const u32 mb = (P[0][v] >> s) & 0x01010101u;
+                    const u32 m = (mb << 8) - mb;
+                    const u32 lo = bfi(m, perm(L.lo[3], L.lo[2], S), perm(L.lo[1], L.lo[0], S));
+                    const u32 hi = bfi(m, perm(L.hi[3], L.hi[2], S), perm(L.hi[1], L.hi[0], S));
+                    w[par][0] = perm(hi, lo, 0x05010400u);
+                    w[par][1] = perm(hi, lo, 0x07030602u);
                 }
                 emit(v, k, w[0][0], w[0][1], w[1][0], w[1][1]);
             }

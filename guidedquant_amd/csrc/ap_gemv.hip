@@ -1273,9 +1273,12 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
         const int dq_mask = gq_env_int("GQ_DQ", GQ_DQ_DEFAULT), dq_min = gq_env_int("GQ_DQ_MIN_MWEIGHTS", -1);
         const uint64_t nk = (uint64_t)a.N * a.K;
         const bool dq_shape = dq_min >= 0 ? nk >= (uint64_t)dq_min * 1000000ull
-                                          : (bits == 4 ? nk >= 16000000ull
-                                                       : (bits == 3 && nk >= 16000000ull &&
-                                                          (nk < 32000000ull || (pro != PRO_RMSNORM && a.K >= 8192u && nk < 100000000ull))));
+                                          // (and at least one 16-row group per CU: Llama-3.2-1B's w2, 2048 x 8192 = 128 blocks, is faster on the
+                                          // exact kernel -- 4-bit 1B decode 1555 vs 1508 tokens/s; Llama-3.3-70B at 4 bits: 72 -> 86 tokens/s here)
+                                          : (a.N >= 4096u &&
+                                             (bits == 4 ? nk >= 16000000ull
+                                                        : (bits == 3 && nk >= 16000000ull &&
+                                                           (nk < 32000000ull || (pro != PRO_RMSNORM && a.K >= 8192u && nk < 100000000ull)))));
         if (!force_generic && !exact_mode() && bits <= 4 && ((dq_mask >> (bits - 2)) & 1) && dq_shape && !(ho && ho->dry)) {
             const int rc = dq_gemv_try(a, M, bits, pro, s);
             if (rc != GQ_ENOTSUP) return rc;

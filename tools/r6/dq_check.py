@@ -30,6 +30,9 @@ def setenv(**kw):
     L.gq_reset_env_cache()
 
 
+# MODEL=70b: Llama-3.3-70B's launches (timing only makes sense with CHECK=0: the accuracy pass uses the 8B shapes)
+SHAPES = {"8b": bench.SHAPES_8B, "70b": {"wqkv": (10240, 8192), "wo": (8192, 8192), "w1w3": (57344, 8192), "w2": (8192, 28672)},
+          "7b": {"wqkv": (12288, 4096), "wo": (4096, 4096), "w1w3": (22016, 4096)}}[os.environ.get("MODEL", "8b")]
 bits_list = [int(b) for b in os.environ.get("BITS", "2,3,4").split(",")]
 if os.environ.get("CHECK", "1") != "0":
     for bits in bits_list:
@@ -55,7 +58,7 @@ if os.environ.get("CHECK", "1") != "0":
             assert np.array_equal(got_r.view(np.uint16), (res.astype(np.float16) + got.astype(np.float16)).view(np.uint16))
             print("ok   bits", bits, N, K, flush=True)
 for bits in bits_list:
-    for nm, (N, K) in bench.SHAPES_8B.items():
+    for nm, (N, K) in SHAPES.items():
         form = {"wqkv": "norm", "wo": "resid", "w1w3": "norm_pairs", "w2": "resid"}[nm]
         row = {}
         for tag, dq in (("default", 0), ("dq", 7), ("default2", 0), ("dq2", 7)):

@@ -39,6 +39,7 @@ struct ApArgs {
     size_t ws_bytes;
     const float *ssq_in;   // statistics hand-over (gq_anyprec_gemv_fused_ho): partial sums of squares of x / of the outputs
     float *ssq_out;
+    unsigned long long *dbg = nullptr;  // GQ_STAMPS builds: the debug buffer of gq_debug_set_timing_buffer (tools/r6/exact_stamps.py)
 };
 
 __device__ __forceinline__ uint4 ld16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -166,18 +167,109 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
 // chunks in ascending order per lane (anyprec.cu:505), then the 16,8,4,2,1 shuffle tree (anyprec.cu:363-370).
 // Called by 32 consecutive lanes (t = lane & 31).  Returns the row value in lane t == 0.
 // ----------------------------------------------------------------------------------------------
+// The chain is what the reference computes; how the values travel is this chip's: the partials of four chunks are read from LDS in
+// one round trip, the 16-lane step is one v_permlane16_swap (rows 0 / 1 of the wave exchanged in registers), the 8 / 4 / 2 / 1 steps are
+// DPP operands of the adds (row_ror:8, row_shl:4, quad_perm) -- lane t < sh receives lane t + sh exactly as __shfl_down(.., sh, 32) hands
+// it over, the other lanes' values are never used.  (Round 6: with one ds_read / ds_bpermute round trip per add the epilogue of a block
+// was 0.6 us per pass of T / 32 rows -- 2.8 of the 12.7 us of a w1w3 block; tools/r6/exact_stamps.py.)
+__device__ __forceinline__ uint16_t h_add_dpp16(uint16_t p) {  // p[t] + p[t + 16], t < 16 of every 32
+    const u32 v = p;
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
+    return h_add((uint16_t)r[0], (uint16_t)r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ uint16_t h_add_dpp(uint16_t p) {
+    return h_add(p, (uint16_t)__builtin_amdgcn_update_dpp(0, (int)(u32)p, CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ uint16_t reduce_tree(uint16_t p) {
+    p = h_add_dpp16(p);
+    p = h_add_dpp<0x128>(p);  // row_ror:8   lane t <- t + 8 (mod 16)
+    p = h_add_dpp<0x104>(p);  // row_shl:4   lane t <- t + 4
+    p = h_add_dpp<0x4E>(p);   // quad_perm [2,3,0,1]
+    p = h_add_dpp<0xB1>(p);   // quad_perm [1,0,3,2]
+    return p;
+}
 __device__ __forceinline__ uint16_t reduce_row(const RowGeom &G, const uint16_t *sv, u32 t, u32 c0, u32 c1) {
     uint16_t p = 0;
-    for (u32 i = c0; i < c1; i++) {
-        if (i == G.nfull && t >= G.eff) break;
-        p = h_add(p, sv[i * 32u + t]);
-    }
+    for (u32 i0 = c0; i0 < c1; i0 += 4u) {
+        uint16_t v[4];
+        bool ok[4];
 #pragma unroll
-    for (int sh = 16; sh >= 1; sh >>= 1) {
-        uint16_t o = (uint16_t)__shfl_down((int)p, sh, 32);
-        p = h_add(p, o);
+        for (u32 j = 0; j < 4u; j++) {
+            const u32 i = i0 + j;
+            ok[j] = i < c1 && !(i == G.nfull && t >= G.eff);  // (the lanes past the end of a partial last chunk hold no partial: no add)
+            v[j] = sv[(ok[j] ? i : c0) * 32u + t];
+        }
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++) p = ok[j] ? h_add(p, v[j]) : p;
     }
-    return p;
+    return reduce_tree(p);
+}
+
+// NCH > 0: rows of exactly NCH full chunks (no predicates, one LDS round trip for all partials of a row)
+template <int NCH>
+__device__ __forceinline__ uint16_t reduce_row_n(const RowGeom &G, const uint16_t *sv, u32 t) {
+    if constexpr (NCH == 0) return reduce_row(G, sv, t, 0u, G.nchunks);
+    else {
+        uint16_t v[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; i++) v[i] = sv[(u32)i * 32u + t];
+        uint16_t p = 0;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) p = h_add(p, v[i]);
+        return reduce_tree(p);
+    }
+}
+
+// Ordered reduction + epilogue of the R rows of a block, 32 lanes per row, TWO rows per 32-lane group and trip (their LDS round trips
+// and add chains are independent: the compiler interleaves them); the residual is requested before the row's partials are read.
+template <int NCH>
+__device__ __forceinline__ void rows_epilogue_n(const RowGeom &G, const ApArgs &a, const uint16_t *sv, u32 svrow, u32 R, u32 row0, u32 m,
+                                                u32 tid, u32 T) {
+    const u32 t = tid & 31u, stride = T >> 5;
+    const bool pairs = a.epilogue & GQ_EPI_SILU_PAIRS;
+    for (u32 r0 = tid >> 5; r0 < R; r0 += 2u * stride) {
+        const u32 r1 = r0 + stride;
+        const bool has1 = r1 < R;
+        const u32 row[2] = {row0 + r0, row0 + r1};
+        const bool live[2] = {true, has1};
+        uint16_t res[2] = {0, 0};
+        if (!pairs && a.resid) {
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (live[e] && row[e] < a.N) res[e] = a.resid[(size_t)m * a.N + row[e]];
+        }
+        uint16_t y[2];
+        y[0] = reduce_row_n<NCH>(G, sv + (size_t)r0 * svrow, t);
+        y[1] = reduce_row_n<NCH>(G, sv + (size_t)(has1 ? r1 : r0) * svrow, t);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if (pairs) {
+                // rows (2i, 2i+1) = (gate_i, up_i) sit in the two halves of the wave: F.silu(gate) * up on fp16 values
+                // (inference/model.py:266), written to out[i]
+                const u32 yy = y[e];
+                auto sw = __builtin_amdgcn_permlane32_swap(yy, yy, false, false);  // sw[1]: lanes 32..63 of y in both halves
+                const uint16_t yo = (uint16_t)sw[1];
+                if (live[e] && t == 0 && !(tid & 32u) && row[e] + 1u < a.N) {
+                    const float gv = (float)__builtin_bit_cast(_Float16, y[e]);
+                    const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, yo);
+                    a.out[(size_t)m * (a.N >> 1) + (row[e] >> 1)] = __builtin_bit_cast(uint16_t, o);
+                }
+            } else if (live[e] && t == 0 && row[e] < a.N) {
+                if (a.resid) y[e] = h_add(res[e], y[e]);
+                a.out[(size_t)m * a.N + row[e]] = y[e];
+            }
+        }
+    }
+}
+__device__ __forceinline__ void rows_epilogue(const RowGeom &G, const ApArgs &a, const uint16_t *sv, u32 svrow, u32 R, u32 row0, u32 m, u32 tid,
+                                              u32 T) {
+    // (compiled-in chunk counts of the Llama rows: K = 4096, 8192, 14336; everything else -- partial last chunks too -- on the general one)
+    const u32 nch = G.eff ? 0u : G.nchunks;
+    if (nch == 4u) rows_epilogue_n<4>(G, a, sv, svrow, R, row0, m, tid, T);
+    else if (nch == 8u) rows_epilogue_n<8>(G, a, sv, svrow, R, row0, m, tid, T);
+    else if (nch == 14u) rows_epilogue_n<14>(G, a, sv, svrow, R, row0, m, tid, T);
+    else rows_epilogue_n<0>(G, a, sv, svrow, R, row0, m, tid, T);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -206,6 +298,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
     const bool active = tid < RS * G.Q;
     const u32 rs = active ? tid / G.Q : 0u;
     const u32 q = active ? tid - rs * G.Q : 0u;
+    // (GQ_STAMPS builds: s_memrealtime per wave of the middle block -- start, x in registers, after every step, loop barrier, end)
+    unsigned long long *qdbg = (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2u && (tid & 63u) == 0u) ? a.dbg + (size_t)(tid >> 6) * 32u : nullptr;
+    u32 nst = 0;
+    auto qstamp = [&]() {
+        if (GQ_STAMPS && qdbg && nst < 32u) qdbg[nst++] = __builtin_amdgcn_s_memrealtime();
+    };
+    qstamp();
 
     constexpr int NRAW = (1 << BITS) / 2;
     constexpr u32 OOB = 0x80000000u;
@@ -266,6 +365,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
             xr.r[c][jj][2] = v.z;
             xr.r[c][jj][3] = v.w;
         }
+    if (GQ_STAMPS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        qstamp();
+    }
 
     // 3. decode + packed fp16 FMA chains, one item per step
     u32 chunk, t0, tpw;
@@ -274,6 +377,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
     for (u32 i = 0; i < SPB; i += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
+            if (GQ_STAMPS) {  // (words in hand)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                qstamp();
+            }
             u32 Pw[BITS][4];
 #pragma unroll
             for (int p = 0; p < BITS; p++) {
@@ -289,29 +396,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
             Item<BITS>::run(Pw, L, xr, s01, s23);
             if (active && i + (u32)d < SPB)
                 *reinterpret_cast<uint2 *>(svp + (size_t)(i + (u32)d) * RS * svrow) = make_uint2(s01, s23);
+            if (GQ_STAMPS) qstamp();
         }
     }
     __syncthreads();
+    if (GQ_STAMPS) qstamp();
 
-    // 4. ordered reduction + epilogue, 32 lanes per row
-    const u32 t = tid & 31u;
-    for (u32 rl2 = tid >> 5; rl2 < SPB * RS; rl2 += T >> 5) {
-        const u32 row = row0 + rl2;
-        uint16_t y = reduce_row(G, sv + (size_t)rl2 * svrow, t, 0u, G.nchunks);
-        if (a.epilogue & GQ_EPI_SILU_PAIRS) {
-            // rows (2i, 2i+1) = (gate_i, up_i) sit in the two halves of the wave: F.silu(gate) * up on fp16 values
-            // (inference/model.py:266), written to out[i]
-            const uint16_t yo = (uint16_t)__shfl_xor((int)y, 32);
-            if (t == 0 && !(tid & 32u) && row + 1u < a.N) {
-                const float gv = (float)__builtin_bit_cast(_Float16, y);
-                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, yo);
-                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
-            }
-        } else if (t == 0 && row < a.N) {
-            if (a.resid) y = h_add(a.resid[(size_t)m * a.N + row], y);
-            a.out[(size_t)m * a.N + row] = y;
-        }
-    }
+    // 4. ordered reduction + epilogue
+    rows_epilogue(G, a, sv, svrow, SPB * RS, row0, m, tid, T);
+    if (GQ_STAMPS) qstamp();
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -490,22 +583,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) a
     }
     __syncthreads();
     // ordered reduction + epilogue: as ap_gemv_quad_kernel
-    const u32 t = tid & 31u;
-    for (u32 rl2 = tid >> 5; rl2 < SPB * RS; rl2 += T >> 5) {
-        const u32 row = row0 + rl2;
-        uint16_t y = reduce_row(G, sv + (size_t)rl2 * svrow, t, 0u, G.nchunks);
-        if (a.epilogue & GQ_EPI_SILU_PAIRS) {
-            const uint16_t yo = (uint16_t)__shfl_xor((int)y, 32);
-            if (t == 0 && !(tid & 32u) && row + 1u < a.N) {
-                const float gv = (float)__builtin_bit_cast(_Float16, y);
-                const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, yo);
-                a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
-            }
-        } else if (t == 0 && row < a.N) {
-            if (a.resid) y = h_add(a.resid[(size_t)m * a.N + row], y);
-            a.out[(size_t)m * a.N + row] = y;
-        }
-    }
+    rows_epilogue(G, a, sv, svrow, SPB * RS, row0, m, tid, T);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1092,6 +1170,9 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c, int pro = PRO_NONE) {
             bestT = T;
         }
     }
+    // rows of more than 8192 weights: the widest block with the same row slots per step -- the spare waves shorten the activation
+    // staging and the ordered reduction (8B w2, K = 14336: 448 -> 512 threads, 10.9 -> 10.1 us per launch in exact mode)
+    if (bestT && Q > 64u && 512u / Q == bestT / Q) bestT = 512u;
     const int envT = gq_env_int("GQ_AP_T", 0);
     if (envT >= 64 && envT <= 512 && envT % 64 == 0 && (u32)envT >= Q) bestT = (u32)envT;
     if (!bestT) return false;
@@ -1135,7 +1216,9 @@ int launch_quad_inst(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
     auto kern = ap_gemv_quad_kernel<BITS, D, PRO>;
     GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     dim3 grid(c.grid, M), block(c.T);
-    hipLaunchKernelGGL(kern, grid, block, c.smem, s, a);
+    ApArgs ad = a;
+    if (GQ_STAMPS) ad.dbg = gq_debug_timing_buffer();
+    hipLaunchKernelGGL(kern, grid, block, c.smem, s, ad);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
 }

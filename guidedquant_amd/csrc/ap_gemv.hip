@@ -281,8 +281,39 @@ __device__ __forceinline__ void rows_epilogue(const RowGeom &G, const ApArgs &a,
 // answers with zeros and no memory traffic, so the loop has no divergent control flow and the compiler's
 // vmcnt bookkeeping stays exact.  The lane's activations stay in 64 VGPRs for the whole loop.
 // ----------------------------------------------------------------------------------------------
-template <int BITS, int D, int PRO>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <= 3 && D == 1 ? 3 : 2))) ap_gemv_quad_kernel(ApArgs a) {
+// ----------------------------------------------------------------------------------------------
+// INREG (rows of 4096 weights: Q = 32, a row is one half of a wave): the ordered reduction of a row step stays in registers.
+// Lane hl = q of the half-wave holds the packed chunk partials of CUDA lanes t = 4 (q % 8) + v, v = 0..3, of chunk q / 8.  The chunk
+// sums of anyprec.cu:505 (chunks ascending, starting from +0) meet in lanes hl < 8: own value, lane + 8 (row_shl:8), lane + 16
+// (v_permlane16_swap), lane + 24 (row_shl:8 of that); the shuffle tree of anyprec.cu:363-370 is t + 16 = lane + 4 (row_shl:4), t + 8
+// = lane ^ 2, t + 4 = lane ^ 1 (quad_perm), t + 2 = the second register, t + 1 = the upper half -- the same additions in the same
+// order, ~30 VALU per step instead of the LDS partials + block barrier + reduction pass (1.2 of the 11.6 us of a w1w3 block,
+// 0.6 of the 3.4 us of a wo block: profiles/r06_exact_epilogue.txt).  The row's value lands in lane hl = 0.
+// ----------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ u32 mov_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ u32 inreg_chunk_sum4(u32 s) {
+    const u32 c1 = mov_dpp<0x108>(s);  // row_shl:8
+    auto sw = __builtin_amdgcn_permlane16_swap(s, s, false, false);
+    const u32 c2 = sw[1];
+    const u32 c3 = mov_dpp<0x108>(c2);
+    u32 p = pk_add(0u, s);
+    p = pk_add(p, c1);
+    p = pk_add(p, c2);
+    return pk_add(p, c3);
+}
+__device__ __forceinline__ uint16_t inreg_reduce_row(u32 s01, u32 s23) {
+    u32 p01 = inreg_chunk_sum4(s01), p23 = inreg_chunk_sum4(s23);
+    p01 = pk_add(p01, mov_dpp<0x104>(p01)), p23 = pk_add(p23, mov_dpp<0x104>(p23));  // t + 16: row_shl:4
+    p01 = pk_add(p01, mov_dpp<0x4E>(p01)), p23 = pk_add(p23, mov_dpp<0x4E>(p23));    // t + 8: quad_perm [2,3,0,1]
+    p01 = pk_add(p01, mov_dpp<0xB1>(p01)), p23 = pk_add(p23, mov_dpp<0xB1>(p23));    // t + 4: quad_perm [1,0,3,2]
+    const u32 pp = pk_add(p01, p23);                                                // t + 2
+    return h_add((uint16_t)(pp & 0xFFFFu), (uint16_t)(pp >> 16));                  // t + 1
+}
+
+template <int BITS, int D, int PRO, bool INREG = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(INREG && BITS == 2 ? 4 : ((BITS <= 3 || INREG) && D == 1 ? 3 : 2))))
+ap_gemv_quad_kernel(ApArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RowGeom G;
     G.init(a.K);
@@ -299,12 +330,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
     const u32 rs = active ? tid / G.Q : 0u;
     const u32 q = active ? tid - rs * G.Q : 0u;
     // (GQ_STAMPS builds: s_memrealtime per wave of the middle block -- start, x in registers, after every step, loop barrier, end)
-    unsigned long long *qdbg = (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2u && (tid & 63u) == 0u) ? a.dbg + (size_t)(tid >> 6) * 32u : nullptr;
+    // (GQ_STAMPS == 2: start / end of EVERY block instead -- wave 0 of block b writes dbg[2 b], dbg[2 b + 1]: the dispatch ramp of a launch)
+    unsigned long long *qdbg = (GQ_STAMPS == 1 && a.dbg && blockIdx.x == gridDim.x / 2u && (tid & 63u) == 0u) ? a.dbg + (size_t)(tid >> 6) * 32u
+                               : ((GQ_STAMPS == 2 && a.dbg && tid == 0u && blockIdx.y == 0u) ? a.dbg + 2u * (size_t)blockIdx.x : nullptr);
     u32 nst = 0;
     auto qstamp = [&]() {
-        if (GQ_STAMPS && qdbg && nst < 32u) qdbg[nst++] = __builtin_amdgcn_s_memrealtime();
+        if (GQ_STAMPS == 1 && qdbg && nst < 32u) qdbg[nst++] = __builtin_amdgcn_s_memrealtime();
     };
     qstamp();
+    if (GQ_STAMPS == 2 && qdbg) qdbg[0] = __builtin_amdgcn_s_memrealtime();
 
     constexpr int NRAW = (1 << BITS) / 2;
     constexpr u32 OOB = 0x80000000u;
@@ -365,7 +399,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
             xr.r[c][jj][2] = v.z;
             xr.r[c][jj][3] = v.w;
         }
-    if (GQ_STAMPS) {
+    if (GQ_STAMPS == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         qstamp();
     }
@@ -377,7 +411,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
     for (u32 i = 0; i < SPB; i += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            if (GQ_STAMPS) {  // (words in hand)
+            if (GQ_STAMPS == 1) {  // (words in hand)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 qstamp();
             }
@@ -392,12 +426,42 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
             LutPools<BITS> L;
             L.build(lraw[d]);
             issue(d, i + (u32)d + (u32)D);  // refill this ring slot (its registers are now copied out)
+            const u32 row = row0 + (i + (u32)d) * RS + rs;
+            const bool rvalid = i + (u32)d < SPB && row < a.N;
+            uint16_t res = 0;
+            if constexpr (INREG) {
+                if (a.resid && !(a.epilogue & GQ_EPI_SILU_PAIRS) && rvalid) res = a.resid[(size_t)m * a.N + row];
+            }
             u32 s01, s23;
             Item<BITS>::run(Pw, L, xr, s01, s23);
-            if (active && i + (u32)d < SPB)
-                *reinterpret_cast<uint2 *>(svp + (size_t)(i + (u32)d) * RS * svrow) = make_uint2(s01, s23);
+            if constexpr (INREG) {
+                uint16_t y = inreg_reduce_row(s01, s23);
+                const bool lead = (tid & 31u) == 0u;
+                if (a.epilogue & GQ_EPI_SILU_PAIRS) {
+                    // rows (2i, 2i+1) = (gate_i, up_i) sit in the two halves of the wave: F.silu(gate) * up on fp16 values
+                    // (inference/model.py:266), written to out[i]
+                    const u32 yy = y;
+                    auto sw = __builtin_amdgcn_permlane32_swap(yy, yy, false, false);  // sw[1]: lanes 32..63 of y in both halves
+                    if (lead && !(tid & 32u) && rvalid && row + 1u < a.N) {
+                        const float gv = (float)__builtin_bit_cast(_Float16, y);
+                        const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, (uint16_t)sw[1]);
+                        a.out[(size_t)m * (a.N >> 1) + (row >> 1)] = __builtin_bit_cast(uint16_t, o);
+                    }
+                } else if (lead && rvalid) {
+                    if (a.resid) y = h_add(res, y);
+                    a.out[(size_t)m * a.N + row] = y;
+                }
+            } else {
+                if (active && i + (u32)d < SPB)
+                    *reinterpret_cast<uint2 *>(svp + (size_t)(i + (u32)d) * RS * svrow) = make_uint2(s01, s23);
+            }
             if (GQ_STAMPS) qstamp();
         }
+    }
+    if constexpr (INREG) {
+        if (GQ_STAMPS) qstamp();
+        if (GQ_STAMPS == 2 && qdbg) qdbg[1] = __builtin_amdgcn_s_memrealtime();
+        return;
     }
     __syncthreads();
     if (GQ_STAMPS) qstamp();
@@ -405,6 +469,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BITS <
     // 4. ordered reduction + epilogue
     rows_epilogue(G, a, sv, svrow, SPB * RS, row0, m, tid, T);
     if (GQ_STAMPS) qstamp();
+    if (GQ_STAMPS == 2 && qdbg) qdbg[1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -479,7 +544,7 @@ __device__ __forceinline__ void stage_x_natural(const RowGeom &G, const uint16_t
 }
 
 template <int PRO>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3))) ap_gemv_pt2_kernel(ApArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) ap_gemv_pt2_kernel(ApArgs a) {  // (105 VGPRs)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BITS = 2, NRAW = 2;
     RowGeom G;
@@ -940,24 +1005,36 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
         }
     }
     __syncthreads();
-    // ordered K-split sum + epilogue: one thread per row of the block
+    // ordered K-split sum + epilogue: one thread per row of the block.  The residual is requested BEFORE the sums are read, and the
+    // partial sums of eight units come in one LDS round trip (added in unit order as before): with one dependent ds_read per unit and the
+    // residual behind the sum, the tail of a w2 launch (28 units) was 28 LDS round trips + one memory round trip long.
     const bool pairs = (a.epilogue & GQ_EPI_SILU_PAIRS) != 0u;
     for (u32 rl = tid; rl < rgb * 16u; rl += 64u * DQ_WAVES) {
         const u32 row = rg0 * 16u + rl;
+        uint16_t res = 0;
+        if (!pairs && a.resid && row < a.N) res = a.resid[row];
         const float *pp = part + (size_t)(rl >> 4) * NU * 16u + (rl & 15u);
         float y = 0.f;
-        for (u32 u = 0; u < NU; u++) y += pp[(size_t)u * 16u];
+        u32 u = 0;
+        for (; u + 8u <= NU; u += 8u) {
+            float v[8];
+#pragma unroll
+            for (u32 j = 0; j < 8u; j++) v[j] = pp[(size_t)(u + j) * 16u];
+#pragma unroll
+            for (u32 j = 0; j < 8u; j++) y += v[j];
+        }
+        for (; u < NU; u++) y += pp[(size_t)u * 16u];
         _Float16 yh = (_Float16)y;
         if (pairs) {
             // rows (2 i, 2 i + 1) = (gate_i, up_i): F.silu(gate) * up on fp16 values (inference/model.py:266), written to out[i]
-            const uint16_t yo = (uint16_t)__shfl_xor((int)__builtin_bit_cast(uint16_t, yh), 1);
+            const uint16_t yo = (uint16_t)__builtin_amdgcn_update_dpp(0, (int)__builtin_bit_cast(uint16_t, yh), 0xB1, 0xF, 0xF, true);  // lane ^ 1
             if (!(rl & 1u) && row + 1u < a.N) {
                 const float gv = (float)yh;
                 const _Float16 o = (_Float16)(gv / (1.0f + __expf(-gv))) * __builtin_bit_cast(_Float16, yo);
                 gq_store_wt(a.out + (row >> 1), __builtin_bit_cast(uint16_t, o));
             }
         } else if (row < a.N) {
-            if (a.resid) yh = __builtin_bit_cast(_Float16, a.resid[row]) + yh;
+            if (a.resid) yh = __builtin_bit_cast(_Float16, res) + yh;
             gq_store_wt(a.out + row, __builtin_bit_cast(uint16_t, yh));
         }
     }
@@ -1142,7 +1219,7 @@ __global__ void __launch_bounds__(256) ap_dequant_kernel(const u32 *qw, const ui
 // Launchers
 // ----------------------------------------------------------------------------------------------
 #ifndef GQ_AP_PT_DEFAULT
-#define GQ_AP_PT_DEFAULT 1  // exact mode, 2 bits: the LDS pair-table kernel (ap_gemv_pt2_kernel) instead of the v_perm kernel on long rows
+#define GQ_AP_PT_DEFAULT 0  // exact mode, 2 bits: the LDS pair-table kernel (ap_gemv_pt2_kernel) instead of the v_perm kernel: 1 long rows, 2 all
 #endif
 #ifndef GQ_DQ_DEFAULT
 #define GQ_DQ_DEFAULT 6  // (bit mask over the bit widths 2, 3, 4 the decode-to-fp16 kernel may take: 3 and 4)
@@ -1154,7 +1231,8 @@ struct QuadCfg {
 
 int num_cus() { return gq_cu_count(); }
 
-bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c, int pro = PRO_NONE) {
+// `pt2`: the configuration is for the 2-bit pair-table kernel (4 waves per SIMD)
+bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c, int pro = PRO_NONE, bool pt2 = false) {
     if (K % 128u) return false;
     const u32 Q = K / 128u;
     if (Q > 512u) return false;
@@ -1172,7 +1250,8 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c, int pro = PRO_NONE) {
     }
     // rows of more than 8192 weights: the widest block with the same row slots per step -- the spare waves shorten the activation
     // staging and the ordered reduction (8B w2, K = 14336: 448 -> 512 threads, 10.9 -> 10.1 us per launch in exact mode)
-    if (bestT && Q > 64u && 512u / Q == bestT / Q) bestT = 512u;
+    // (and rows of exactly 8192: 512 threads = 8 row slots instead of 4 -- Llama-3.3-70B's wqkv 12.4 vs 15.2 us, wo 8.7 vs 10.5, w1w3 41.7 vs 45.9)
+    if (bestT && (Q == 64u || (Q > 64u && 512u / Q == bestT / Q))) bestT = 512u;
     const int envT = gq_env_int("GQ_AP_T", 0);
     if (envT >= 64 && envT <= 512 && envT % 64 == 0 && (u32)envT >= Q) bestT = (u32)envT;
     if (!bestT) return false;
@@ -1192,6 +1271,13 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c, int pro = PRO_NONE) {
     // 2-3 resident blocks of a CU repeat that side by side -- one block per CU then (measured, 8B wqkv: 3-bit 8.8 -> 8.4 us, 4-bit
     // 11.9 -> 11.0; the large matrices keep the deeper grid: w1w3 exact 2-bit 17.2 vs 21.9 us with one block per CU)
     if (pro == PRO_RMSNORM && steps <= cus * bpc_def) bpc_def = 1u;
+    // never more blocks per CU than the instance's occupancy holds at once (round 6, per-block start stamps: 8B w2 in exact mode, 512-thread
+    // blocks of a 3-waves-per-SIMD kernel = ONE resident block per CU, was launched as 512 blocks -- two rounds of 5 us each;
+    // profiles/r06_exact_epilogue.txt).  Waves per SIMD: the kernels' amdgpu_waves_per_eu attributes.
+    const bool inreg = !pt2 && d == 1 && K == 4096u && c.T % 64u == 0u && c.RS * 32u == c.T;
+    const u32 wpe = pt2 ? 4u : (inreg ? (bits == 2 ? 4u : 3u) : (bits <= 3 && d == 1 ? 3u : 2u));
+    const u32 bpc_max = std::max(1u, wpe * 4u / ((c.T + 63u) / 64u));
+    if (bpc_def > bpc_max) bpc_def = bpc_max;
     u32 bpc = (u32)gq_env_int("GQ_AP_BPC", (int)bpc_def);
     if (bpc < 1) bpc = 1;
     u32 target = cus * bpc;
@@ -1212,12 +1298,23 @@ bool pick_quad_cfg(u32 N, u32 K, int bits, QuadCfg &c, int pro = PRO_NONE) {
 
 template <int BITS, int D, int PRO>
 int launch_quad_inst(const ApArgs &a, const QuadCfg &c, u32 M, hipStream_t s) {
-    static GqPerDeviceOnce once;
-    auto kern = ap_gemv_quad_kernel<BITS, D, PRO>;
-    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     dim3 grid(c.grid, M), block(c.T);
     ApArgs ad = a;
     if (GQ_STAMPS) ad.dbg = gq_debug_timing_buffer();
+    // rows of 4096 weights at the shipped ring depth: the ordered reduction in registers (INREG above)
+    if constexpr (D == 1) {
+        if (a.K == 4096u && c.T % 64u == 0u && c.RS * 32u == c.T && gq_env_int("GQ_AP_INREG", 1) != 0) {
+            static GqPerDeviceOnce once_r;
+            auto kern_r = ap_gemv_quad_kernel<BITS, D, PRO, true>;
+            GQ_HIP_CHECK(once_r.max_dynamic_lds(reinterpret_cast<const void *>(kern_r), (int)(160u * 1024u)));
+            hipLaunchKernelGGL(kern_r, grid, block, c.smem, s, ad);
+            GQ_HIP_CHECK(hipGetLastError());
+            return GQ_OK;
+        }
+    }
+    static GqPerDeviceOnce once;
+    auto kern = ap_gemv_quad_kernel<BITS, D, PRO>;
+    GQ_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160u * 1024u)));
     hipLaunchKernelGGL(kern, grid, block, c.smem, s, ad);
     GQ_HIP_CHECK(hipGetLastError());
     return GQ_OK;
@@ -1380,13 +1477,19 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
         !((a.epilogue & GQ_EPI_SILU_PAIRS) && ((c.SPB * c.RS) & 1u))) {
         a.RS = c.RS;
         a.SPB = c.SPB;
-        // round 6: the pair-table kernel where it measured faster -- rows of >= 8192 weights (8B w2: 11.3 vs 12.7 us; w1w3 18.0 vs 18.3:
-        // a tie; wqkv 9.5 vs 8.4 and wo 5.9 vs 5.2: slower; profiles/r06_exact_pair_table.txt).  GQ_AP_PT: 0 never, 1 (default) those
-        // rows, 2 every shape it serves
+        // round 6: the pair-table kernel (GQ_AP_PT: 0 never -- the default --, 1 rows of >= 8192 weights, 2 every shape it serves).  It had
+        // measured faster on 8B w2 (11.3 vs 12.7 us) while BOTH kernels ran that launch in two rounds of blocks (pick_quad_cfg: blocks per
+        // CU beyond the occupancy); in one round the v_perm kernel is the faster one on every Llama shape (8B w2 8.9 vs 9.9 us; 70B w2 26.0
+        // vs 33.6, wqkv 12.4 vs 13.5, wo 8.7 vs 10.0) except 70B w1w3 (41.7 vs 38.1): profiles/r06_exact_pair_table.txt, r06_exact_epilogue.txt
         {
             const int pt = gq_env_int("GQ_AP_PT", GQ_AP_PT_DEFAULT);
-            if (bits == 2 && (pt >= 2 || (pt == 1 && a.K >= 8192u))) {
-                const int rc = launch_pt2(a, c, M, pro, s);
+            QuadCfg cp;
+            if (bits == 2 && (pt >= 2 || (pt == 1 && a.K >= 8192u)) && pick_quad_cfg(a.N, a.K, bits, cp, pro, true) &&
+                !((a.epilogue & GQ_EPI_SILU_PAIRS) && ((cp.SPB * cp.RS) & 1u))) {
+                ApArgs ap = a;
+                ap.RS = cp.RS;
+                ap.SPB = cp.SPB;
+                const int rc = launch_pt2(ap, cp, M, pro, s);
                 if (rc != GQ_ENOTSUP) return rc;
             }
         }

@@ -570,13 +570,13 @@ __global__ void __launch_bounds__(pl_threads<BITS>(), BITS == 2 ? PL_WPE : (pl_t
     float *part = red + 64u * MBA + 2u * hot_cap;     // [item][batch row][subset][16 rows]
     const u32 rg0 = blockIdx.x * a.RGB;
     auto stamp = [&](int i) {
-        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
+        if (GQ_STAMPS == 1 && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
     };
     stamp(0);
     if PL_XF(32u) return;
     const bool early = w < E;
     auto stamp2 = [&](int i) {  // finer stamps of the prologue (second table of tools/phase_timing.py)
-        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[128u + w * 16u + (u32)i] = __builtin_readcyclecounter();
+        if (GQ_STAMPS == 1 && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[128u + w * 16u + (u32)i] = __builtin_readcyclecounter();
     };
 
     // ---------------------------------------------------------------- 0. activation loads, then the first tiles
@@ -1090,9 +1090,11 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     const u32 my_steps = items_w * cpi;
     const u32 chunk0 = (w & (CS - 1u)) * cpi;
     auto stamp = [&](int i) {
-        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
+        if (GQ_STAMPS == 1 && a.dbg && blockIdx.x == gridDim.x / 2 && l == 0) a.dbg[w * 8u + (u32)i] = __builtin_readcyclecounter();
     };
     stamp(0);
+    // (GQ_STAMPS == 2: start / end of EVERY block, s_memrealtime -- dbg[2 b], dbg[2 b + 1]; tools/r6/block_ramp.py)
+    if (GQ_STAMPS == 2 && a.dbg && tid == 0u && blockIdx.y == 0u) a.dbg[2u * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     // A wave that is still building its image shares its SIMD with older waves already in their main loops; instruction issue is
     // arbitrated by priority, then age, so the latest-started waves (whose activations also land last) would build their images in
     // the slots the others leave over -- and the block ends with them.  Prologue work goes first, and the later a wave started the
@@ -1358,6 +1360,10 @@ __global__ void __launch_bounds__(BITS == 2 ? 1024 : 512) ap_plane_local_kernel(
     for (u32 i = 0; i < W; i++) X += red[32 + i];
     plane_epilogue<BITS, SPEC>(a, lutl, part, X, rg0, m, tid, T, NP1 * 16u);
     stamp(5);
+    if (GQ_STAMPS == 2 && a.dbg && blockIdx.y == 0u) {
+        __syncthreads();
+        if (tid == 0u) a.dbg[2u * blockIdx.x + 1u] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 struct PlaneCfg {

@@ -364,7 +364,9 @@ __device__ __forceinline__ void ap_stream_body(const StreamArgs &a) {
     // phase stamps (tools/phase_timing.py): kept in LDS and written out at the very end -- a global store per stamp sits in
     // vmcnt and turns the next wait for a load into a wait for the store's acknowledgement (~1,000 cycles each)
     unsigned long long *dbgl = reinterpret_cast<unsigned long long *>(smem + a.dbg_off) + w * 24u;
-    const bool dbg_on = GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2;
+    const bool dbg_on = GQ_STAMPS == 1 && a.dbg && blockIdx.x == gridDim.x / 2;
+    // (GQ_STAMPS == 2: start / end of EVERY block, s_memrealtime -- dbg[2 b], dbg[2 b + 1]; tools/r6/block_ramp.py)
+    if (GQ_STAMPS == 2 && a.dbg && tid == 0u && blockIdx.y == 0u) a.dbg[2u * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     auto stamp = [&](int i) {
         if (dbg_on && l == 0) dbgl[i] = __builtin_readcyclecounter();
     };
@@ -1001,6 +1003,10 @@ __device__ __forceinline__ void ap_stream_body(const StreamArgs &a) {
         const unsigned long long v = dbgl[l];
         if (l < 8u) a.dbg[w * 8u + l] = v;
         else a.dbg[128u + w * 16u + (l - 8u)] = v;
+    }
+    if (GQ_STAMPS == 2 && a.dbg && blockIdx.y == 0u) {
+        __syncthreads();
+        if (tid == 0u) a.dbg[2u * blockIdx.x + 1u] = __builtin_amdgcn_s_memrealtime();
     }
 }
 template <int BITS, int PRO, int NPU, bool PSUM, int EPI = EPI_ANY>

@@ -31,10 +31,11 @@ def test_no_kernel_spills_vgprs_or_uses_scratch():
 
 
 def test_exact_gemv_instances_fit_their_occupancy():
-    """ap_gemv_quad_kernel<BITS, D, PRO>: D = 1 at 2 / 3 bits is built for 3 waves per SIMD (<= 168 VGPRs), everything else for 2."""
+    """ap_gemv_quad_kernel<BITS, D, PRO, INREG>: D = 1 at 2 / 3 bits is built for 3 waves per SIMD (<= 168 VGPRs), the in-register
+    reduction instances (INREG, D = 1) for 4 waves at 2 bits (<= 128) and 3 at 3 / 4 bits, everything else for 2."""
     import kernel_resources as kr
     ks = [k for k in kr.kernels_of(os.path.join(ROOT, "guidedquant_amd", "csrc", "ap_gemv.o")) if "ap_gemv_quad_kernel" in k[0]]
-    assert len(ks) == 33  # bits 2, 3: D 1..4; bits 4: D 1..3; x 3 prologues
+    assert len(ks) == 42  # bits 2, 3: D 1..4; bits 4: D 1..3; x 3 prologues; + INREG: 3 bit widths x 3 prologues
     for k in ks:
-        bits, d = int(k[0].split("ILi")[1][0]), int(k[0].split("ELi")[1][0])
-        assert k[1] <= (168 if bits <= 3 and d == 1 else 256), k
+        bits, d, inreg = int(k[0].split("ILi")[1][0]), int(k[0].split("ELi")[1][0]), "ELb1E" in k[0]
+        assert k[1] <= ((128 if bits == 2 else 168) if inreg else (168 if bits <= 3 and d == 1 else 256)), k

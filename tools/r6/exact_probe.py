@@ -13,9 +13,10 @@ def setenv(**kw):
     L.gq_reset_env_cache()
 bits = int(os.environ.get("BITS", "2"))
 forms = {"wqkv": "norm", "wo": "resid", "w1w3": "norm_pairs", "w2": "resid"}
+SHAPES = {"8b": bench.SHAPES_8B, "70b": {"wqkv": (10240, 8192), "wo": (8192, 8192), "w1w3": (57344, 8192), "w2": (8192, 28672)}}[os.environ.get("MODEL", "8b")]
 for nm in os.environ.get("SHAPES", "w1w3,w2,wqkv,wo").split(","):
-    N, K = bench.SHAPES_8B[nm]
-    for cfg in [{}] + [{"GQ_AP_D": d, "GQ_AP_BPC": b, **pt} for pt in ({"GQ_AP_PT": 0}, {}) for d in (1, 2) for b in (2, 3, 4, 5)] + [{"GQ_AP_D": 2, "GQ_AP_BPC": 2, "GQ_AP_T": 512}, {"GQ_AP_D": 1, "GQ_AP_BPC": 1, "GQ_AP_T": 512}]:
+    N, K = SHAPES[nm]
+    for cfg in json.loads(os.environ.get("CFGS", "[{}]")):
         setenv(GQ_AP_D=None, GQ_AP_BPC=None, GQ_AP_T=None, GQ_AP_PT=None)
         setenv(**cfg)
         try:

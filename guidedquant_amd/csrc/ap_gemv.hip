@@ -105,12 +105,11 @@ __device__ __forceinline__ void stage_x(const RowGeom &G, const uint16_t *x, con
                 }
             }
         }
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        ss = gq_wave_allsum(ss);
         if ((tid & 63u) == 0 && stager) red[tid >> 6] = ss;
         __syncthreads();
-        float tot = 0.f;
-        for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
+        // (the stager waves' sums: one LDS round trip + the same register tree, instead of one dependent ds_read per wave)
+        const float tot = gq_wave_allsum((tid & 63u) < (T + 63u) / 64u ? red[tid & 63u] : 0.f);
         scale = 1.0f / sqrtf(tot / (float)G.K + eps);
     }
     for (u32 idx = idx0; idx < 4u * G.Q; idx += T) {
@@ -511,12 +510,11 @@ __device__ __forceinline__ void stage_x_natural(const RowGeom &G, const uint16_t
                 }
             }
         }
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        ss = gq_wave_allsum(ss);
         if ((tid & 63u) == 0 && stager) red[tid >> 6] = ss;
         __syncthreads();
-        float tot = 0.f;
-        for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
+        // (the stager waves' sums: one LDS round trip + the same register tree, instead of one dependent ds_read per wave)
+        const float tot = gq_wave_allsum((tid & 63u) < (T + 63u) / 64u ? red[tid & 63u] : 0.f);
         scale = 1.0f / sqrtf(tot / (float)G.K + eps);
     }
     for (u32 u = stager ? tid : nun; u < nun; u += T) {
@@ -791,12 +789,11 @@ __device__ __forceinline__ void stage_x_dqv(const RowGeom &G, const uint16_t *x,
                 }
             }
         }
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        ss = gq_wave_allsum(ss);
         if ((tid & 63u) == 0 && stager) red[tid >> 6] = ss;
         __syncthreads();
-        float tot = 0.f;
-        for (u32 w = 0; w < (T + 63u) / 64u; w++) tot += red[w];
+        // (the stager waves' sums: one LDS round trip + the same register tree, instead of one dependent ds_read per wave)
+        const float tot = gq_wave_allsum((tid & 63u) < (T + 63u) / 64u ? red[tid & 63u] : 0.f);
         scale = 1.0f / sqrtf(tot / (float)G.K + eps);
     }
     for (u32 idx = idx0; idx < 4u * G.Q; idx += T) {

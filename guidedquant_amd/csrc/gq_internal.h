@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/gq_hip.h"
 
@@ -59,6 +60,26 @@ struct GqPerDeviceOnce {
 __device__ __forceinline__ float gq_pin_f32(float v) {
     asm volatile("" : "+v"(v));
     return v;
+}
+
+// the sum of a value over the 64 lanes of a wave, in every lane, without the LDS crossbar: quad_perm / row mirrors (DPP operands of the
+// adds) inside a row of 16, v_permlane16_swap / v_permlane32_swap across rows.  (Round 6: six ds_bpermute + wait + add per statistic --
+// what __shfl_xor compiles to -- sat between the activations' arrival and the first normalised value of every RMSNorm launch.)  A fixed
+// tree: deterministic; the exact / dq GEMV kernels and the QTIP prologues take their RMSNorm statistic through it (kernels that must agree bit for bit do).
+__device__ __forceinline__ float gq_wave_allsum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    const uint32_t b16 = __builtin_bit_cast(uint32_t, v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(b16, b16, false, false);
+    v = __builtin_bit_cast(float, (uint32_t)r16[0]) + __builtin_bit_cast(float, (uint32_t)r16[1]);
+    const uint32_t b32 = __builtin_bit_cast(uint32_t, v);
+    auto r32 = __builtin_amdgcn_permlane32_swap(b32, b32, false, false);
+    return __builtin_bit_cast(float, (uint32_t)r32[0]) + __builtin_bit_cast(float, (uint32_t)r32[1]);
 }
 
 // Hand-off stores: what a launch of the decode step writes is read by the NEXT launch, mostly from other XCDs.  A plain store

@@ -721,12 +721,11 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
                         ss += f * f;
                     }
             }
-            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            ss = gq_wave_allsum(ss);  // (round 6: register tree instead of six ds_bpermute round trips)
             if ((tid & 63u) == 0) redf[tid >> 6] = ss;
             __syncthreads();
-            {  // every thread adds the wave sums in the same order (broadcast reads): no second barrier, no serial thread
-                float t = 0.f;
-                for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
+            {  // every wave adds the wave sums through the same tree (one LDS round trip): no second barrier, no serial thread
+                const float t = gq_wave_allsum((tid & 63u) < (T >> 6) ? redf[tid & 63u] : 0.f);
                 nscale = 1.0f / sqrtf(t / (float)K + a.eps);
             }
         }
@@ -887,11 +886,10 @@ __global__ void __launch_bounds__(1024) qtip_out_in_kernel(QtipOutInArgs a) {
             const float f = (float)__builtin_bit_cast(h16, hs[8u * u + e]);
             ss += f * f;
         }
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    ss = gq_wave_allsum(ss);
     if ((tid & 63u) == 0) redf[tid >> 6] = ss;
     __syncthreads();
-    float t = 0.f;
-    for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
+    const float t = gq_wave_allsum((tid & 63u) < (T >> 6) ? redf[tid & 63u] : 0.f);  // (as qtip_linear_in_kernel's prologue: the same tree)
     const float nscale = 1.0f / sqrtf(t / (float)K + a.eps);
 #pragma unroll
     for (u32 k = 0; k < NU; k++) {
@@ -1034,16 +1032,10 @@ __global__ void __launch_bounds__(1024) qtip_transform_kernel(QtipXfArgs a) {
                 const float f = (float)__builtin_bit_cast(h16, a.x[i]);
                 ss += f * f;
             }
-            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            ss = gq_wave_allsum(ss);
             if ((tid & 63u) == 0) redf[tid >> 6] = ss;
             __syncthreads();
-            if (tid == 0) {
-                float t = 0.f;
-                for (u32 i = 0; i < (T >> 6); i++) t += redf[i];
-                redf[16] = 1.0f / sqrtf(t / (float)n + a.eps);
-            }
-            __syncthreads();
-            rs = redf[16];
+            rs = 1.0f / sqrtf(gq_wave_allsum((tid & 63u) < (T >> 6) ? redf[tid & 63u] : 0.f) / (float)n + a.eps);
         }
         for (u32 u = tid; u < n / 8u; u += T) {  // 8 activations per 16-byte load
             const uint4 xq = reinterpret_cast<const uint4 *>(a.x)[u];

@@ -434,7 +434,12 @@ class AnyPrecisionForCausalLM(nn.Module):
         total = T + max_new
         if total > dec.config.block_size:
             raise ValueError(f"prompt + max_new_tokens = {total} exceeds the model's context ({dec.config.block_size})")
-        dec.setup_caches(1, total)
+        # caches (and with them the captured graphs, keyed by the cache length) grow in powers of two from 256 positions: a serving loop
+        # with varying lengths re-captures at most log2 times, not per request (the attention launch reads rows up to the position
+        # only; a longer cache costs memory, not time).  Beyond 16384 positions the request's own length (the fallback route's
+        # causal mask is quadratic in it).
+        cap = total if total > 16384 else max(256, 1 << (total - 1).bit_length())
+        dec.setup_caches(1, min(cap, dec.config.block_size))
         key = (self.precision, dec.max_seq_length, req["temperature"], req["top_k"], req["top_p"])
         graph = self._native_cache.get(("graph",) + key)
         if graph is None:

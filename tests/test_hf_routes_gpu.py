@@ -177,9 +177,19 @@ def test_evicted_graphs_are_destroyed_before_the_next_capture():
         for n in (5, 9, 6):
             outs.append(m.generate(ids, max_new_tokens=n, do_sample=False, native=False, capture=True, pad_token_id=0))
             assert sum(1 for k in m._native_cache if k[0] == "cap") == 1
+        graphs = []
         for n in (5, 9, 6):
             outs.append(m.generate(ids, max_new_tokens=n, do_sample=False, pad_token_id=0))
             assert sum(1 for k in m._native_cache if k[0] == "graph") == 1
+            graphs.append(next(v for k, v in m._native_cache.items() if k[0] == "graph"))
+        # (round 6: the fused route's caches grow in powers of two from 256 positions -- the three lengths share ONE capture ..)
+        assert graphs[0] is graphs[1] is graphs[2]
+        # (.. and other sampling parameters evict it and capture again, here under the eager collector)
+        for temp in (0.7, 0.9):
+            m.generate(ids, max_new_tokens=5, do_sample=True, temperature=temp, top_k=8, pad_token_id=0)
+            assert sum(1 for k in m._native_cache if k[0] == "graph") == 1
+            assert next(v for k, v in m._native_cache.items() if k[0] == "graph") is not graphs[0]
+        assert graphs[0].graph is None  # destroyed at eviction
         assert gc.isenabled()
     finally:
         gc.set_threshold(*old)

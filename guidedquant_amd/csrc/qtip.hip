@@ -657,6 +657,9 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     constexpr u32 NU = 2;  // 8-element units per thread held in registers (K <= 16 T)
     const bool inreg = !a.nprev && K <= 8u * NU * T && PRO != QPRO_PRE && PRO != QPRO_ROWS &&
                        !(((uintptr_t)xg | (uintptr_t)x2g | (uintptr_t)a.normw | (uintptr_t)L.SU) & 15u);
+    // the first pass of the Sylvester transform fused into the element-wise stage: units of whole waves (K / 8 a multiple of 64, or
+    // fewer than 64: the first lanes of wave 0), every unit of a wave in the same loop trip, K >= 64
+    const bool fused_first = inreg && K >= 64u && !(QT_ABL & 32) && ((K / 8u) % 64u == 0u || K / 8u < 64u) ;
     uint4 xq[NU], x2q[NU], nwq[NU];
     float4 su0[NU], su1[NU];
     // QPRO_ROWS: x is the fp32 vector gq_qtip_mlp_mid left -- the Kf x Kf factor product of the transform-in is done (column by
@@ -683,9 +686,18 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
             if constexpr (PRO == QPRO_SILUMUL) x2q[k] = ok ? reinterpret_cast<const uint4 *>(x2g)[u] : make_uint4(0u, 0u, 0u, 0u);
         }
     }
+    // (prologue stamps of GQ_STAMPS builds: kept in registers and written out behind the engine -- a global store per stamp sits in vmcnt
+    // and turns the next wait for a load into a wait for the store's acknowledgement, ~1,000 cycles each)
     u32 pst = 0;
+    unsigned long long pstv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto pstamp = [&]() {
-        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63u) == 0 && pst < 8u) a.dbg[128u + (tid >> 6) * 8u + pst++] = __builtin_readcyclecounter();
+        if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2) {
+            const unsigned long long now = __builtin_readcyclecounter();
+#pragma unroll
+            for (u32 i = 0; i < 8u; i++)
+                if (i == pst) pstv[i] = now;
+            pst++;
+        }
     };
     auto prologue = [&]() {
         pstamp();
@@ -762,6 +774,9 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
                     for (int e = 0; e < 8; e++)
                         o[e] = elem((uint16_t)(xw[e >> 1] >> (16 * (e & 1))), (uint16_t)(x2w[e >> 1] >> (16 * (e & 1))),
                                     (uint16_t)(nw[e >> 1] >> (16 * (e & 1))), su[e]);
+                    // (round 6) unit u IS work item u of the transform's first pass: its register / cross-lane stages run on the
+                    // values where they are -- one LDS round trip and one barrier less than store, barrier, fwht_first_pass
+                    if (fused_first) gq_fwht::fwht_item_stages<8u>(o, u, gq_fwht::fwht_mmax<8u>(K));
                     reinterpret_cast<float4 *>(v)[2u * u] = make_float4(o[0], o[1], o[2], o[3]);
                     reinterpret_cast<float4 *>(v)[2u * u + 1u] = make_float4(o[4], o[5], o[6], o[7]);
                 }
@@ -773,7 +788,12 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
         __syncthreads();
         pstamp();
 #if !(QT_ABL & 32)
-        fwht_lds(v, K, PRO == QPRO_ROWS ? a.P : K);
+        {
+            const u32 Pt = PRO == QPRO_ROWS ? a.P : K;
+            const u32 hnext = fused_first ? 16u * gq_fwht::fwht_mmax<8u>(K) : gq_fwht::fwht_first_pass(v, K, Pt);
+            if (GQ_STAMPS) pstamp();
+            gq_fwht::fwht_rest(v, K, Pt, hnext);
+        }
 #endif
         pstamp();
         // fp32 -> fp16, IN PLACE (xs is the front half of v): every thread takes its (<= NU) units of 8 values into
@@ -811,6 +831,11 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     // number of items of this block, expressed in the engine's index space (j = blockIdx.x + r * gridDim.x < nitems)
     const u32 total = (L.M / 32u) * a.ksplit, mine = bl < total ? (total - bl + L.nblk - 1u) / L.nblk : 0u;
     qtip_engine<R, SX, WC>(tab, xs, part, stg, L.comp, (L.M / 32u) * nK2 * 128u * R, mine ? blockIdx.x + (mine - 1u) * gridDim.x + 1u : 0u, item_of, prologue, a.dbg);
+    if (GQ_STAMPS && a.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63u) == 0) {
+#pragma unroll
+        for (u32 i = 0; i < 8u; i++)
+            if (pstv[i]) a.dbg[128u + (tid >> 6) * 8u + i] = pstv[i];
+    }
     if (a.fin_ctr) {
         // Every sum of this block is written (by wave 0, in program order before this point).  Release them to the device,
         // count the block in; the block that completes the count acquires the others' sums and transforms them.  No block

@@ -47,7 +47,7 @@ for name, Ms, K, pro, ks in (("qkv", [4096, 4096, 4096], 4096, 1, 1), ("qkv", [4
     t = dbg.cpu().numpy()[:128].reshape(16, 8)
     t2 = dbg.cpu().numpy()[128:].reshape(16, 8)
     t0 = t[t > 0].min()
-    print(name, Ms, K, "ksplit", ks, " engine: [start, tiles requested, prologue done, (main loop done, flushed) per item]; prologue: [entered, table stored, norm done, v written, fwht done]")
+    print(name, Ms, K, "ksplit", ks, " engine: [start, tiles requested, prologue done, (main loop done, flushed) per item]; prologue: [entered, table stored, norm done, v written, fwht first pass, fwht done]")
     for w in (0, 5, 10, 15):
         print("  wave", w, [int(v - t0) for v in t[w] if v > 0], " prologue", [int(v - t0) for v in t2[w] if v > 0])
     del tr

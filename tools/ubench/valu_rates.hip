@@ -56,6 +56,13 @@ constexpr int ITER = 2048;
 #define A_ANDSDWA(i) asm volatile("v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(r[i]) : "v"(a));
 #define A_CVTPKU8(i) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(r[i]) : "v"(a));
 #define A_SAD(i) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b));
+#define A_SWAP16(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 8) & 15]));
+#define A_SWAP32(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 8) & 15]));
+#define A_ADDDPP(i) asm volatile("v_add_f32_dpp %0, %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(r[i]) : "v"(a));
+// a DEPENDENT chain: every instruction reads what the previous one wrote (the latency, not the rate)
+#define A_ADDDPP_CHAIN(i) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(r[0]));
+#define A_SWAP16_CHAIN(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r[0]), "+v"(r[1]));
+#define A_ADD_CHAIN(i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(r[0]));
 #define A_MFMA444(i)
 
 KERNEL3(k_perm, A_PERM)
@@ -88,6 +95,12 @@ KERNEL3(k_movdpp, A_MOVDPP)
 KERNEL3(k_permsgpr, A_PERMSGPR)
 KERNEL3(k_andsdwa, A_ANDSDWA)
 KERNEL3(k_sad, A_SAD)
+KERNEL3(k_swap16, A_SWAP16)
+KERNEL3(k_swap32, A_SWAP32)
+KERNEL3(k_adddpp, A_ADDDPP)
+KERNEL3(k_adddpp_chain, A_ADDDPP_CHAIN)
+KERNEL3(k_swap16_chain, A_SWAP16_CHAIN)
+KERNEL3(k_add_chain, A_ADD_CHAIN)
 
 // LDS random 4-byte reads (conflict pattern set by address), 16 outstanding per iteration
 __global__ void k_ldsread(uint32_t *out, uint32_t seed) {
@@ -125,6 +138,8 @@ int main() {
         {"v_alignbit_b32", k_alignbit}, {"v_lshl_add_u32", k_lshladd}, {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3},
         {"v_pk_lshrrev_b16", k_pklshr16}, {"v_pk_mad_u16", k_pkmadu16}, {"v_mov_b32_dpp", k_movdpp},
         {"v_and_b32_sdwa", k_andsdwa}, {"v_sad_u8", k_sad},
+        {"v_permlane16_swap_b32", k_swap16}, {"v_permlane32_swap_b32", k_swap32}, {"v_add_f32_dpp row_ror:8", k_adddpp},
+        {"v_add_f32 (dependent chain)", k_add_chain}, {"v_add_f32_dpp (dependent chain)", k_adddpp_chain}, {"v_permlane16_swap (dep. chain)", k_swap16_chain},
         {"ds_bpermute_b32(+wait)", k_bperm}, {"ds_read_b32 x16", k_ldsread}};
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));

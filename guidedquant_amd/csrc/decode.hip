@@ -36,6 +36,17 @@ __device__ __forceinline__ float wave_reduce(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// KV group of query head h: h / (H / Hkv).  Both divisions sit in front of the first load of an attention launch (the cache base
+// needs g) -- ~25 scalar / vector instructions each on this chip (no integer divide); the group size is a power of two for every
+// Llama (1, 4, 8): shifts then, the general quotient otherwise.  (Scalar: H, Hkv are kernel arguments, h is wave-uniform.)
+__device__ __forceinline__ u32 kv_group_of(u32 h, u32 H, u32 Hkv) {
+    if (H == Hkv) return h;
+    if (H == 4u * Hkv) return h >> 2;
+    if (H == 8u * Hkv) return h >> 3;
+    if (H == 2u * Hkv) return h >> 1;
+    return h / (H / Hkv);
+}
+
 // ------------------------------------------------------------------------------------------------ embedding
 __global__ void embed_kernel(const int *tok, const uint16_t *table, uint16_t *out, u32 D, u32 V) {
     u32 t = (u32)tok[0];
@@ -99,7 +110,7 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
     float *red = vcur + HD;                       // [4 * HD] (+ 2 * NW scratch at 4*HD)
     float *red2 = red + 4 * HD + 2 * NW;          // [NW waves * positions-per-wave-instruction][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
-    const u32 h = blockIdx.x, group = H / Hkv, g = h / group;
+    const u32 h = blockIdx.x, g = kv_group_of(h, H, Hkv);
     const uint16_t *q = qkv + (size_t)h * HD;
     const uint16_t *k = qkv + (size_t)H * HD + (size_t)g * HD;
     const uint16_t *v = qkv + (size_t)(H + Hkv) * HD + (size_t)g * HD;
@@ -213,7 +224,7 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_decode_kernel(const uint
         qs[d] = (float)qe;
         kcur[d] = (float)ke;
         vcur[d] = h2f(vd_b);
-        if (h % group == 0 && has_cur) {
+        if (h == g * (H / Hkv) && has_cur) {  // (the first head of its KV group; off the critical path)
             kcg[(size_t)pos * HD + d] = h2u(ke);
             vcg[(size_t)pos * HD + d] = vd_b;
         }
@@ -354,9 +365,9 @@ __global__ void __launch_bounds__(64 * ATTN_WAVES) attn_roped_kernel(const uint1
     float *red2 = sc + (size_t)QH * 2u * NS;      // [QH][NS][HD] partial outputs
     const u32 tid = threadIdx.x, w = tid >> 6, l = tid & 63u;
 #ifdef GQ_ATTN_PROBE  // timing probe (tools/r5): blockIdx.y = identical copies of the whole-group form, every copy writes the same outputs
-    const u32 h0 = blockIdx.x * QH, g = h0 / (H / Hkv), sp = 0u;
+    const u32 h0 = blockIdx.x * QH, g = kv_group_of(h0, H, Hkv), sp = 0u;
 #else
-    const u32 h0 = blockIdx.x * QH, g = h0 / (H / Hkv), sp = blockIdx.y;
+    const u32 h0 = blockIdx.x * QH, g = kv_group_of(h0, H, Hkv), sp = blockIdx.y;
 #endif
     const u32 sub = l / LPP, ld = l % LPP;
     const uint16_t *kcg = kc + (size_t)g * max_seq * HD, *vcg = vc + (size_t)g * max_seq * HD;

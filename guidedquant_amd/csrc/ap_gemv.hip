@@ -903,8 +903,9 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
     constexpr int D = DQ_RING;
     u32x4 P[D][BITS];
     u32 lraw[D][NRAW];
-    auto issue = [&](int d, u32 it) {
-        const u32 rgl = it / NU, u = it - rgl * NU;
+    // (item it = (row group rgl, unit u) = (it / NU, it % NU): the loop below carries the pair along -- an integer division is ~30
+    // instructions on this chip, and NU = 28 for the 14336-wide rows)
+    auto issue = [&](int d, u32 it, u32 rgl, u32 u) {
         const u32 row = (rg0 + rgl) * 16u + r;
         const bool ok = it < nitems && row < a.N && !(DQ_KO & 4);  // (knock-out 4: no plane loads)
         const u32 off = ok ? (row * G.wpr + 4u * (4u * u + g)) * 4u : OOB;
@@ -928,7 +929,10 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
     };
     auto first_requests = [&]() {
 #pragma unroll
-        for (int d = 0; d < D; d++) issue(d, w + (u32)d * DQ_WAVES);
+        for (int d = 0; d < D; d++) {
+            const u32 it = w + (u32)d * DQ_WAVES;
+            issue(d, it, it / NU, it % NU);
+        }
     };
     // the waves that stage x (the lower half) request their first items behind the activations, the others at once (the CU's
     // memory pipe serves requests in order)
@@ -939,10 +943,9 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
     __syncthreads();
     // B fragments: column 0 reads the image, the other columns read zeros from beyond the block's LDS allocation (192 KiB up)
     const u32 Q = QT ? (u32)QT : G.Q;
-    auto decode_item = [&](u32 it, const u32 (&Pw)[BITS][4], const u32 (&lw)[NRAW]) {
+    auto decode_item = [&](u32 it, u32 u, const u32 (&Pw)[BITS][4], const u32 (&lw)[NRAW]) {
         LutPools<BITS> L;
         L.build(lw);
-        const u32 rgl = it / NU, u = it - rgl * NU;
         const u32 q = 4u * u + g;
         const unsigned char *bb = r == 0u ? reinterpret_cast<const unsigned char *>(xlds) + (size_t)q * 16u
                                           : reinterpret_cast<const unsigned char *>(smem) + 0x30000u;
@@ -973,6 +976,11 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
         if (GQ_STAMPS && dqdbg && nst < 32u) dqdbg[nst++] = __builtin_amdgcn_s_memrealtime();
     };
     dstamp();
+    static_assert(D == 1, "the (row group, unit) pair of an item is carried for ring depth 1");
+    const u32 step_rg = DQ_WAVES / NU, step_u = DQ_WAVES - step_rg * NU;  // one division per launch
+    u32 c_rg = w / NU, c_u = w - c_rg * NU;                                 // (row group, unit) of the item being decoded
+    u32 n_rg = c_rg + step_rg, n_u = c_u + step_u;                           // .. and of the one being requested
+    if (n_u >= NU) n_u -= NU, n_rg++;
     for (u32 it0 = w; it0 < nitems; it0 += (u32)D * DQ_WAVES) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -994,10 +1002,14 @@ __global__ void __launch_bounds__(64 * DQ_WAVES) __attribute__((amdgpu_waves_per
                 for (int p = 0; p < BITS; p++) asm volatile("" : "+v"(Pw[p][0]), "+v"(Pw[p][3]));  // (the wait for the plane words sits here)
                 dstamp();
             }
-            issue(d, it + (u32)D * DQ_WAVES);
+            issue(d, it + (u32)D * DQ_WAVES, n_rg, n_u);
             if (GQ_STAMPS) dstamp();
+            const u32 u_now = c_u;
+            c_rg = n_rg, c_u = n_u;
+            n_rg += step_rg, n_u += step_u;
+            if (n_u >= NU) n_u -= NU, n_rg++;
             if (it >= nitems) continue;  // (wave-uniform)
-            decode_item(it, Pw, lw);
+            decode_item(it, u_now, Pw, lw);
             if (GQ_STAMPS) dstamp();
         }
     }

@@ -18,7 +18,7 @@ EXPORTS = [
     "gq_qtip_matvec", "gq_hadamard", "gq_anyprec_gemv_fused", "gq_set_ap_mode", "gq_embed_lookup", "gq_attn_decode",
     "gq_dense_gemv_f16", "gq_sample_topk", "gq_qtip_linear_in", "gq_qtip_linear_out", "gq_qtip_transform", "gq_lutgemm_gemv_ws", "gq_attn_decode_split",
     "gq_attn_decode_qtip", "gq_qtip_linear_out_seg",
-    "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer",
+    "gq_qtip_plan_ksplit", "gq_qtip_linear", "gq_anyprec_gemv_cpu", "gq_anyprec_dequant_cpu", "gq_anyprec_gemm", "gq_anyprec_gemm_ws", "gq_anyprec_gemm_ws_bytes", "gq_rmsnorm_rows", "gq_rope_cache_rows", "gq_silu_mul_rows", "gq_anyprec_pack", "gq_lnq_cd_block", "gq_reset_env_cache", "gq_debug_set_timing_buffer", "gq_debug_set_qtip_timing_buffer", "gq_debug_exact_plan",
     "gq_anyprec_qkv_rope_supported", "gq_anyprec_gemv_qkv_rope", "gq_attn_decode_roped", "gq_selfcheck", "gq_hop_send", "gq_hop_wait",
     "gq_qtip_mlp_mid", "gq_qtip_linear_in_rows", "gq_anyprec_gemv_fused_ws", "gq_anyprec_gemv_fused_ws_bytes",
     "gq_qtip_linear_out_in", "gq_debug_stream_read", "gq_hop_alloc", "gq_hop_free", "gq_hop_export", "gq_hop_import", "gq_hop_close", "gq_hop_wait_copy",
@@ -122,6 +122,7 @@ def lib():
         L.gq_lnq_cd_block.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, vp]
         L.gq_debug_set_timing_buffer.argtypes = [vp]
         L.gq_debug_set_qtip_timing_buffer.argtypes = [vp]
+        L.gq_debug_exact_plan.argtypes = [u32, u32, i32, i32, vp]
         L.gq_hop_send.argtypes = [vp, vp, u32, vp, vp, u32, vp]
         L.gq_hop_wait.argtypes = [vp, vp, u32, vp, u32, vp]
         L.gq_debug_stream_read.argtypes = [vp, ctypes.c_size_t, vp, vp]

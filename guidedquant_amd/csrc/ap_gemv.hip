@@ -1350,6 +1350,16 @@ int launch_quad(const ApArgs &a, const QuadCfg &c, u32 M, int pro, hipStream_t s
     }
 }
 
+}  // namespace
+extern "C" int gq_debug_exact_plan(uint32_t N, uint32_t K, int bits, int prologue, uint32_t *plan) {
+    QuadCfg c;
+    if (!plan || bits < 2 || bits > 4 || !pick_quad_cfg(N, K, bits, c, prologue)) return GQ_ENOTSUP;
+    const bool inreg = c.D == 1u && K == 4096u && c.T % 64u == 0u && c.RS * 32u == c.T;
+    const u32 wpe = inreg ? (bits == 2 ? 4u : 3u) : (bits <= 3 && c.D == 1u ? 3u : 2u);  // (the kernels' amdgpu_waves_per_eu attributes)
+    plan[0] = c.T, plan[1] = c.RS, plan[2] = c.SPB, plan[3] = c.D, plan[4] = c.grid, plan[5] = std::max(1u, wpe * 4u / ((c.T + 63u) / 64u));
+    return GQ_OK;
+}
+namespace {
 // the 2-bit pair-table kernel on the quad kernel's configuration (+ the waves' tables behind the partial sums); GQ_ENOTSUP where a wave
 // could span more than two rows (fewer than 64 quads per row unless exactly 32) or the tables do not fit
 int launch_pt2(const ApArgs &a, const QuadCfg &c, u32 M, int pro, hipStream_t s) {

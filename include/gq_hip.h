@@ -512,6 +512,11 @@ int gq_sample_topk_p(const void *logits, uint32_t vocab, int top_k, float top_p,
 void gq_reset_env_cache(void);
 void gq_debug_set_timing_buffer(void *device_buffer);
 void gq_debug_set_qtip_timing_buffer(void *device_buffer); /* u64 [16 waves][8] phase stamps of gq_qtip_matvec's middle block */
+/* The launch plan of the exact-order AP-GEMV kernel (ap_gemv.hip::pick_quad_cfg) for a shape, without launching: plan[0..5] = threads per
+ * block, row slots per step, row steps per block, ring depth, blocks of the launch, and the blocks per CU the instance's occupancy holds at
+ * once.  prologue: 0 none, 1 RMSNorm, 2 SiLU * up.  Returns GQ_ENOTSUP when the fast exact path does not serve the shape.  For the test that
+ * no plan asks for more resident blocks than fit (a round-6 find: such a launch runs in two rounds). */
+int gq_debug_exact_plan(uint32_t N, uint32_t K, int bits, int prologue, uint32_t *plan);
 
 #ifdef __cplusplus
 }

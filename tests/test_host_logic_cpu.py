@@ -497,3 +497,29 @@ def test_bench_side_legs_cannot_take_the_line_with_them():
     keys = [k for k, _, _, _ in bench.LEGS]
     assert keys[:3] == ["cpu_baseline", "roofline_by_shape", "exact_mode"] and len(keys) == 11
     assert {g for _, g, _, _ in bench.LEGS} == {None, "other_configs"}
+
+
+def test_exact_gemv_plans_fit_the_occupancy():
+    """round 6: the exact-order kernel's planner never asks for more resident blocks per CU than the instance's occupancy holds (8B w2 had
+    been launched as 512 blocks of a kernel that fits ONE 512-thread block per CU: two rounds of blocks, 10.5 instead of 8.9 us).
+    gq_debug_exact_plan = pick_quad_cfg without a launch (256 CUs assumed without a device)."""
+    import ctypes
+    from guidedquant_amd import _lib
+    L = _lib.lib()
+    shapes = {"8b": [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)], "70b": [(10240, 8192), (8192, 8192), (57344, 8192), (8192, 28672)],
+              "1b": [(3072, 2048), (2048, 2048), (16384, 2048), (2048, 8192)], "7b": [(12288, 4096), (22016, 4096), (4096, 11008)]}
+    seen = 0
+    for model, shp in shapes.items():
+        for N, K in shp:
+            for bits in (2, 3, 4):
+                for pro in (0, 1):
+                    plan = (ctypes.c_uint32 * 6)()
+                    rc = L.gq_debug_exact_plan(N, K, bits, pro, plan)
+                    if rc != 0:
+                        continue
+                    T, RS, SPB, D, grid, bpc = list(plan)
+                    seen += 1
+                    assert T % 64 == 0 and 64 <= T <= 512 and RS >= 1 and SPB >= 1 and 1 <= D <= 4, (model, N, K, bits, pro, list(plan))
+                    assert grid * SPB * RS >= N, (model, N, K, bits, pro, list(plan))          # every row has a slot
+                    assert grid <= 256 * bpc, (model, N, K, bits, pro, list(plan))             # one round of blocks
+    assert seen >= 60

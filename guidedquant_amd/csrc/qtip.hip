@@ -228,7 +228,8 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     stamp(std::integral_constant<int, 0>{});
     u32 j = blockIdx.x;
     if (j >= nitems) return;  // (whole block)
-    QtItem cur = item_of(j);
+    u32 ord = 0;  // ordinal of the block's current item (item_of takes it: no division to recover it from j)
+    QtItem cur = item_of(j, 0u);
     // Queue refill without vector ALU work: the lane part of the address is a constant VGPR, the chunk a scalar offset.
     // A slot with nothing left to fetch re-reads the last chunk of the item (a cache hit, never used).
     auto fetch = [&](u32 p, const QtItem &it, u32 c) {
@@ -375,7 +376,7 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
     for (;;) {
         const u32 jn = j + gridDim.x;
         const bool has_next = jn < nitems;
-        const QtItem nxt = has_next ? item_of(jn) : cur;
+        const QtItem nxt = has_next ? item_of(jn, ord + 1u) : cur;
         const u32 chi = (cur.k2hi + CH - 1u) / CH, first = cur.k2lo / CH + w;
         const u32 cnt = first < chi ? (chi - first + W - 1u) / W : 0u;  // chunks of this wave in this item
         const u32 nl = (cnt + PF - 1u) / PF;
@@ -453,6 +454,7 @@ __device__ __forceinline__ void qtip_engine(const u32 *tab, const uint16_t *xsp,
         if (!has_next) break;
         cur = nxt;
         j = jn;
+        ord++;
     }
 }
 
@@ -465,7 +467,7 @@ __global__ void __launch_bounds__(1024) qtip_matvec_kernel(float *out, const u32
     float *part = reinterpret_cast<float *>(xsp + K);            // [2][waves][32 rows]
     unsigned char *stg = reinterpret_cast<unsigned char *>(part + 2u * (blockDim.x >> 6) * 32u);  // [waves] 1 KiB chunk slots
     const u32 T = blockDim.x, tid = threadIdx.x, nK2 = K / 32u;
-    auto item_of = [&](u32 j) {
+    auto item_of = [&](u32 j, u32) {
         return QtItem{j * nK2 * 128u * R, out + (size_t)j * 32u, 0u, nK2};
     };
     // codebook words and activations first, the tile blocks behind them (in-order return)
@@ -823,8 +825,15 @@ __global__ void __launch_bounds__(1024) qtip_linear_in_kernel(QtipInArgs a) {
     constexpr u32 CH = QtChunk<R>::CH;
     const u32 nK2 = K / 32u, nch = (nK2 + CH - 1u) / CH, kpart = ((nch + a.ksplit - 1u) / a.ksplit) * CH, bl = blockIdx.x - L.blk0;
     // item t of this linear = (band t / ksplit, K range t % ksplit); this block takes t = bl, bl + nblk, ...
-    auto item_of = [&](u32 jj) {  // jj = blockIdx.x + r * gridDim.x  ->  t = bl + r * nblk
-        const u32 r = (jj - blockIdx.x) / gridDim.x, t = bl + r * L.nblk, band = t / a.ksplit, ks = t % a.ksplit;
+    // (no integer divide on this chip, and the item feeds the addresses of the NEXT item's first chunks at every item boundary: the
+    // ordinal r comes from the engine, the K range by shifts / a constant divisor)
+    auto item_of = [&](u32, u32 r) {  // item r of this block: jj = blockIdx.x + r * gridDim.x  ->  t = bl + r * nblk
+        const u32 t = bl + r * L.nblk;
+        u32 band, ks;
+        if (a.ksplit == 1u) band = t, ks = 0u;
+        else if (a.ksplit == 2u) band = t >> 1, ks = t & 1u;
+        else if (a.ksplit == 4u) band = t >> 2, ks = t & 3u;
+        else band = t / 3u, ks = t - 3u * band;
         const u32 lo = ks * kpart, hi = lo + kpart < nK2 ? lo + kpart : nK2;
         return QtItem{band * nK2 * 128u * R, L.y32 + (size_t)ks * L.M + (size_t)band * 32u, lo, hi};
     };

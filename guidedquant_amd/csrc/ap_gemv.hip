@@ -1466,7 +1466,9 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
     // vs 10.3 us, wo 6.6 vs 6.8 (exact kernel), w1w3 22.9 vs 24.4, w2 13.9 vs 15.0 --, at 3 bits the matrices of 16 .. 32 M weights (wqkv
     // 6.5 vs 7.2, wo 4.9 vs 5.3; Llama-2-7B's wqkv 50 M 8.1 vs 9.5, w1w3 90 M 12.7 vs 14.2) up to 100 M, and the long-row launches
     // without the RMSNorm prologue at any size (8B w2 9.35 vs 9.65, 70B w2 235 M 26.5 vs 34.8; 70B wqkv 84 M 13.2 vs 14.8); the big
-    // RMSNorm + pair launches stay on the plane kernel (8B w1w3 117 M 15.3 vs 14.8, 70B w1w3 470 M 46.8 vs 44.2); never at 2 bits
+    // RMSNorm + pair launches stay on the plane kernel (70B w1w3 470 M 45.7 vs 43.0; 8B w1w3 117 M was 15.3 vs 14.8 and, with the item
+    // loop's divisions gone, is 14.6 vs 14.8 alone and 13.5 vs 14.0 in the decode graph: 3-bit decode 720 -> 736 tokens/s -- the bound moved
+    // from 100 M to 200 M); never at 2 bits
     // (8B w1w3 11.6 vs 8.5, 70B w1w3 37 vs 25).
     // GQ_DQ: bit mask of the widths it may take (bit b - 2; 0 = never), GQ_DQ_MIN_MWEIGHTS >= 0: every matrix of at least that many
     // million weights at those widths.
@@ -1479,7 +1481,7 @@ int ap_gemv_dispatch_inner(ApArgs a, u32 M, int bits, hipStream_t s, GqHandover 
                                           : (a.N >= 4096u &&
                                              (bits == 4 ? nk >= 16000000ull
                                                         : (bits == 3 && nk >= 16000000ull &&
-                                                           (nk < 100000000ull || (pro != PRO_RMSNORM && a.K >= 8192u)))));
+                                                           (nk < 200000000ull || (pro != PRO_RMSNORM && a.K >= 8192u)))));
         if (!force_generic && !exact_mode() && bits <= 4 && ((dq_mask >> (bits - 2)) & 1) && dq_shape && !(ho && ho->dry)) {
             const int rc = dq_gemv_try(a, M, bits, pro, s);
             if (rc != GQ_ENOTSUP) return rc;

@@ -63,6 +63,11 @@ constexpr int ITER = 2048;
 #define A_ADDDPP_CHAIN(i) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(r[0]));
 #define A_SWAP16_CHAIN(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r[0]), "+v"(r[1]));
 #define A_ADD_CHAIN(i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(r[0]));
+#define A_CNDMASK_S(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "s"(m64));
+#define A_CNDMASK_V(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(a) : );
+#define A_CMP(i) asm volatile("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(cm[i & 3]) : "v"(r[i]), "v"(a));
+#define A_MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+#define A_MULHI(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
 #define A_MFMA444(i)
 
 KERNEL3(k_perm, A_PERM)
@@ -102,6 +107,36 @@ KERNEL3(k_adddpp_chain, A_ADDDPP_CHAIN)
 KERNEL3(k_swap16_chain, A_SWAP16_CHAIN)
 KERNEL3(k_add_chain, A_ADD_CHAIN)
 
+__global__ void k_cndmask_s(uint32_t *out, uint32_t seed) {
+    uint32_t r[16], a = seed + threadIdx.x;
+    unsigned long long m64 = 0x5555555555555555ull * (seed | 1u);
+    _Pragma("unroll") for (int i = 0; i < 16; i++) r[i] = a + i;
+    for (int it = 0; it < ITER; it++) { REP16(A_CNDMASK_S) }
+    uint32_t s = 0;
+    _Pragma("unroll") for (int i = 0; i < 16; i++) s ^= r[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_cndmask_v(uint32_t *out, uint32_t seed) {
+    uint32_t r[16], a = seed + threadIdx.x;
+    _Pragma("unroll") for (int i = 0; i < 16; i++) r[i] = a + i;
+    asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc");
+    for (int it = 0; it < ITER; it++) { REP16(A_CNDMASK_V) }
+    uint32_t s = 0;
+    _Pragma("unroll") for (int i = 0; i < 16; i++) s ^= r[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_cmp(uint32_t *out, uint32_t seed) {
+    uint32_t r[16], a = seed + threadIdx.x;
+    unsigned long long cm[4] = {0, 0, 0, 0};
+    _Pragma("unroll") for (int i = 0; i < 16; i++) r[i] = a + i;
+    for (int it = 0; it < ITER; it++) { REP16(A_CMP) }
+    uint32_t s = (uint32_t)(cm[0] ^ cm[1] ^ cm[2] ^ cm[3]);
+    _Pragma("unroll") for (int i = 0; i < 16; i++) s ^= r[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+KERNEL3(k_mullo, A_MULLO)
+KERNEL3(k_mulhi, A_MULHI)
+
 // LDS random 4-byte reads (conflict pattern set by address), 16 outstanding per iteration
 __global__ void k_ldsread(uint32_t *out, uint32_t seed) {
     __shared__ uint32_t lds[4096];
@@ -138,6 +173,8 @@ int main() {
         {"v_alignbit_b32", k_alignbit}, {"v_lshl_add_u32", k_lshladd}, {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3},
         {"v_pk_lshrrev_b16", k_pklshr16}, {"v_pk_mad_u16", k_pkmadu16}, {"v_mov_b32_dpp", k_movdpp},
         {"v_and_b32_sdwa", k_andsdwa}, {"v_sad_u8", k_sad},
+        {"v_cndmask_b32_e64 (sgpr pair)", k_cndmask_s}, {"v_cndmask_b32_e32 (vcc set once)", k_cndmask_v}, {"v_cmp_lt_u32_e64 -> sgpr", k_cmp},
+        {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi},
         {"v_permlane16_swap_b32", k_swap16}, {"v_permlane32_swap_b32", k_swap32}, {"v_add_f32_dpp row_ror:8", k_adddpp},
         {"v_add_f32 (dependent chain)", k_add_chain}, {"v_add_f32_dpp (dependent chain)", k_adddpp_chain}, {"v_permlane16_swap (dep. chain)", k_swap16_chain},
         {"ds_bpermute_b32(+wait)", k_bperm}, {"ds_read_b32 x16", k_ldsread}};
